@@ -1,0 +1,95 @@
+"""ctypes binding of libfastnerf.so (the C ABI declared in include/fastnerf.h).
+
+The product path has NO CPU fallback: if the library is missing or a call
+fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libfastnerf.so')
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_int64
+F = C.c_float
+D = C.c_double
+U64 = C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/fastnerf.h one to one
+SIGNATURES = {
+    'fastnerf_version': (I, []),
+    'fastnerf_last_error': (C.c_char_p, []),
+    'fastnerf_device_cus': (I, []),
+    'fastnerf_gen_rays': (I, [I, I, F, F, F, F, P, P, P, P]),
+    'fastnerf_gen_rays_pixels': (I, [L, P, P, F, F, F, F, P, P, P]),
+    'fastnerf_ndc_rays': (I, [L, I, I, D, F, P, P, P, P, P]),
+    'fastnerf_pack_rays': (I, [L, P, P, F, F, I, I, I, D, P, P]),
+    'fastnerf_sample_coarse': (I, [L, I, P, I, I, P, U64, P, P]),
+    'fastnerf_posenc': (I, [L, I, P, P, P]),
+    'fastnerf_mlp_pack': (I, [P, P, P, P]),
+    'fastnerf_mlp_fwd': (I, [L, I, P, P, P, P, P, P, P]),
+    'fastnerf_mlp_bwd_partial_floats': (L, []),
+    'fastnerf_mlp_bwd': (I, [L, I, P, P, P, P, P, P, P, P]),
+    'fastnerf_raw2outputs_fwd': (I, [L, I, P, P, P, P, I, P, P, P, P, P, P]),
+    'fastnerf_raw2outputs_bwd': (I, [L, I, P, P, P, P, I, P, P, P]),
+    'fastnerf_sample_pdf_merge': (I, [L, I, I, P, P, I, P, U64, P, P, P, P]),
+    'fastnerf_sample_pdf': (I, [L, I, I, P, P, I, P, U64, P, P]),
+    'fastnerf_mse_leafmax': (I, [L, P, P, P, F, P, P, P, P, I, P, P]),
+    'fastnerf_adam_step': (I, [L, P, P, P, P, D, D, D, D, I, P]),
+    'fastnerf_tree_create': (P, [I, I, I, I]),
+    'fastnerf_tree_destroy': (None, [P]),
+    'fastnerf_tree_num_leaves': (I, [P, I]),
+    'fastnerf_tree_max_leaves': (I, [P]),
+    'fastnerf_tree_min_area': (D, [P, I]),
+    'fastnerf_tree_get_leaves': (I, [P, I, P]),
+    'fastnerf_tree_set_leaves': (I, [P, I, I, P, D]),
+    'fastnerf_tree_leaf_plan': (I, [P, I, D, I, P]),
+    'fastnerf_tree_adjust': (L, [P, P, I, D]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes library; raise loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(the HIP path has no CPU fallback)')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc is None or rc < 0:
+        msg = lib().fastnerf_last_error()
+        raise RuntimeError(f'{what} failed ({rc}): {msg.decode() if msg else "?"}')
+    return rc
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous fp32/int32 tensor, or NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return t.data_ptr()
+
+
+def stream():
+    """The HIP stream torch is currently enqueueing on."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('fastnerf ops run on the GPU only (no CPU fallback): got a CPU tensor')

@@ -1,0 +1,813 @@
+// mlp.hip -- the 8x256 NeRF MLP (model.py:8-63) as fused fp32-MFMA kernels for gfx950.
+//
+//   mlp_fwd     : one persistent workgroup per CU walks tiles of 128 points.  A tile's
+//                 activations [128 x 256] fp32 live in LDS (128 KiB, XOR-swizzled so that
+//                 ds_read_b128 A-fragments are bank-conflict free) next to its positional
+//                 encoding [128 x 64] (32 KiB) -- together exactly the CU's 160 KiB.  Points
+//                 are generated on the fly (pts = o + d*z), encoded with accurate sinf/cosf,
+//                 and pushed through all layers without touching HBM; only raw [P,4] (and, in
+//                 training, the activations backward needs) are written.  8 waves = 2(M) x 4(N),
+//                 each wave owns a 64x64 output block = 2x2 tiles of v_mfma_f32_32x32x2_f32
+//                 (exact fp32, 157 TF peak).  Weights are streamed L2 -> VGPR in a pre-packed
+//                 "fragment order" so that every B load is one contiguous 1 KiB wave access.
+//   mlp_bwd_dx  : same structure with transposed weights, chaining dY back through the layers.
+//   mlp_bwd_dw  : per layer dW = dY^T X over all points; 4 waves x 256 accumulator registers
+//                 hold the whole 256x256 dW of a workgroup's point chunk (split-K over
+//                 workgroups, deterministic second-pass reduction).
+//
+// K is permuted identically for A and B (lanes 0-31 take k0..k0+3, lanes 32-63 k0+4..k0+7 of
+// every 8-wide k-step) which is legal because a dot product does not care about summation
+// order beyond rounding; parity with the reference is therefore "fp32 rounding class"
+// (<=1e-6 relative), not bitwise.
+#include "common.h"
+#include "mlp_layout.h"
+
+using namespace fnl;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TM 128         // points per tile (fwd / dx)
+#define NTHR 512       // threads per workgroup (fwd / dx)
+#define LDS_H (TM * 256)
+#define LDS_E (TM * 64)
+#define LDS_BYTES ((LDS_H + LDS_E) * 4)
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus > 0) return g_num_cus;
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
+  if (g_num_cus <= 0) g_num_cus = 256;
+  return g_num_cus;
+}
+
+// =========================================================================================
+// weight packing
+// =========================================================================================
+struct PackDesc {
+  int64_t src_off;   // flat offset of the [out][in] weight
+  int64_t dst_off;   // packed offset
+  int ld;            // source row length (fan-in)
+  int n_rows;        // fwd: N (out features); bwd: K (= out features)
+  int n_cols;        // fwd: Kp (padded fan-in);  bwd: 256 (in features written)
+  int segA_pad, segA_valid, segB_valid;  // fwd: k' -> source column mapping
+  int col0;          // bwd: first source column
+  int transposed;
+};
+struct PackTable {
+  PackDesc d[19];
+};
+
+// fwd  : dst[((nt*KS+ks)*64 + l)*4 + t] = W'[nt*32 + (l&31)][ks*8 + (l>>5)*4 + t]
+// bwd  : dst[((jt*KS+ks)*64 + l)*4 + t] = W [ks*8 + (l>>5)*4 + t][col0 + jt*32 + (l&31)]
+__global__ void __launch_bounds__(256) pack_kernel(PackTable tab, const float* __restrict__ params,
+                                                    float* __restrict__ pf, float* __restrict__ pb) {
+  const PackDesc d = tab.d[blockIdx.y];
+  const int64_t total = (int64_t)d.n_rows * d.n_cols;
+  float* dst = (d.transposed ? pb : pf) + d.dst_off;
+  const float* src = params + d.src_off;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e & 3);
+    const int l = (int)((e >> 2) & 63);
+    const int64_t blk = e >> 8;  // tile*KS + ks
+    float v = 0.f;
+    if (!d.transposed) {
+      const int KS = d.n_cols / 8;
+      const int nt = (int)(blk / KS), ks = (int)(blk % KS);
+      const int n = nt * 32 + (l & 31);
+      const int kp = ks * 8 + (l >> 5) * 4 + t;
+      int col = -1;
+      if (kp < d.segA_pad) {
+        if (kp < d.segA_valid) col = kp;
+      } else {
+        const int q = kp - d.segA_pad;
+        if (q < d.segB_valid) col = d.segA_valid + q;
+      }
+      if (col >= 0) v = src[(int64_t)n * d.ld + col];
+    } else {
+      const int KS = d.n_rows / 8;
+      const int jt = (int)(blk / KS), ks = (int)(blk % KS);
+      const int o = ks * 8 + (l >> 5) * 4 + t;
+      const int c = d.col0 + jt * 32 + (l & 31);
+      v = src[(int64_t)o * d.ld + c];
+    }
+    dst[e] = v;
+  }
+}
+
+static PackTable make_pack_table() {
+  PackTable T;
+  int n = 0;
+  for (int l = 0; l < 8; ++l) {
+    PackDesc d{};
+    d.src_off = L_W(l); d.dst_off = PF_OFF(l); d.ld = L_K(l); d.n_rows = 256; d.n_cols = PF_KP(l);
+    if (l == 0) { d.segA_pad = 64; d.segA_valid = 63; d.segB_valid = 0; }
+    else if (l == 5) { d.segA_pad = 64; d.segA_valid = 63; d.segB_valid = 256; }
+    else { d.segA_pad = 256; d.segA_valid = 256; d.segB_valid = 0; }
+    T.d[n++] = d;
+  }
+  { PackDesc d{}; d.src_off = F_W; d.dst_off = PF_OFF(8); d.ld = 256; d.n_rows = 256; d.n_cols = 256;
+    d.segA_pad = 256; d.segA_valid = 256; T.d[n++] = d; }
+  { PackDesc d{}; d.src_off = V_W; d.dst_off = PF_OFF(9); d.ld = 283; d.n_rows = 128; d.n_cols = 288;
+    d.segA_pad = 256; d.segA_valid = 256; d.segB_valid = 27; T.d[n++] = d; }
+  // transposed: views(feat part), feature, pts 7,6,5(h part),4,3,2,1
+  { PackDesc d{}; d.transposed = 1; d.src_off = V_W; d.dst_off = PB_OFF(0); d.ld = 283; d.n_rows = 128; d.n_cols = 256; d.col0 = 0; T.d[n++] = d; }
+  { PackDesc d{}; d.transposed = 1; d.src_off = F_W; d.dst_off = PB_OFF(1); d.ld = 256; d.n_rows = 256; d.n_cols = 256; d.col0 = 0; T.d[n++] = d; }
+  const int order[7] = {7, 6, 5, 4, 3, 2, 1};
+  for (int j = 0; j < 7; ++j) {
+    const int l = order[j];
+    PackDesc d{}; d.transposed = 1; d.src_off = L_W(l); d.dst_off = PB_OFF(2 + j); d.ld = L_K(l); d.n_rows = 256; d.n_cols = 256;
+    d.col0 = (l == 5) ? 63 : 0;
+    T.d[n++] = d;
+  }
+  return T;
+}
+
+extern "C" int fastnerf_mlp_pack(const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream) {
+  FN_CHECK_ARG(params && packed_fwd && packed_bwd, "null pointer");
+  static const PackTable T = make_pack_table();
+  hipLaunchKernelGGL(pack_kernel, dim3(64, 19), dim3(256), 0, fn::S(stream), T, params, packed_fwd, packed_bwd);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+// =========================================================================================
+// tile GEMM pieces shared by fwd and bwd_dx
+// =========================================================================================
+// LDS swizzle: 16-byte slot index XOR (row & 15); conflict-free for ds_read_b128 A-fragments
+// (rows = lanes) and for the ds_write_b32 epilogue (32 consecutive columns of one row).
+__device__ __forceinline__ int hidx(int m, int k) { return m * 256 + ((((k >> 2) ^ (m & 15)) << 2) | (k & 3)); }
+__device__ __forceinline__ int eidx(int m, int k) { return m * 64 + ((((k >> 2) ^ (m & 15)) << 2) | (k & 3)); }
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// accumulate `nks` k-steps (8 wide) of A (LDS, rows wm*64.., E or H layout, first k-step
+// a_ks0) times packed B (global, this layer's k-steps b_ks0.., KS k-steps per n-tile).
+template <int NT, bool A_IS_E>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks,
+                                         const float4* __restrict__ Bp, int KS, int b_ks0, int nt0, int wm, int lane) {
+  asm volatile("" : "+v"(lane));  // keep per-call address math inside the call (no cross-layer hoisting)
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const float* arow[2];
+  int axor[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = wm * 64 + mt * 32 + lrow;
+    arow[mt] = As + m * (A_IS_E ? 64 : 256);
+    axor[mt] = m & 15;
+  }
+  const float4* bptr[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 64 + lane;
+
+  // ping-pong register sets (no copies: a copy of a just-issued load would force vmcnt(0))
+  float4 a0[2], b0[NT], a1[2], b1[NT];
+  auto load_ab = [&](float4 (&a)[2], float4 (&b)[NT], int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bptr[nt][ks * 64];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      a[mt] = *reinterpret_cast<const float4*>(arow[mt] + ((((a_ks0 + ks) * 2 + lhalf) ^ axor[mt]) << 2));
+  };
+  auto mfma16 = [&](const float4 (&a)[2], const float4 (&b)[NT]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float av = (t == 0) ? a[mt].x : (t == 1) ? a[mt].y : (t == 2) ? a[mt].z : a[mt].w;
+          const float bv = (t == 0) ? b[nt].x : (t == 1) ? b[nt].y : (t == 2) ? b[nt].z : b[nt].w;
+          acc[mt][nt] = mfma(av, bv, acc[mt][nt]);
+        }
+      }
+    }
+  };
+  load_ab(a0, b0, 0);
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks += 2) {  // nks is even for every layer
+    load_ab(a1, b1, ks + 1);
+    mfma16(a0, b0);
+    if (ks + 2 < nks) load_ab(a0, b0, ks + 2);
+    mfma16(a1, b1);
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+}
+
+// C layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// forward epilogue: + bias, optional ReLU, write H (LDS) and optionally the saved activation
+template <int NT, bool RELU>
+__device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const float* __restrict__ bias, float* Hs,
+                                             int wm, int wn, int lane, float* __restrict__ save, int ldsave,
+                                             int valid) {
+  asm volatile("" : "+v"(lane));
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (wn * NT + nt) * 32 + (lane & 31);
+    const float bv = bias[n];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + mt * 32 + crow(r, lane);
+        float v = acc[mt][nt][r] + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        Hs[hidx(m, n)] = v;
+        if (save != nullptr && m < valid) save[(unsigned)(m * ldsave + n)] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
+    }
+  }
+}
+
+// =========================================================================================
+// forward
+// =========================================================================================
+template <bool SAVE>
+__global__ void __launch_bounds__(NTHR, 2)
+mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
+               const float* __restrict__ params, const float* __restrict__ packed, float* __restrict__ raw,
+               float* __restrict__ act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;
+  float* Es = smem + LDS_H;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const float4* pk = reinterpret_cast<const float4*>(packed);
+  const int64_t ntiles = (P + TM - 1) / TM;
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * TM;
+    const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
+    // ---- phase A: points + positional encoding -> Es ---------------------------------
+    const int pm = tid >> 2, pq = tid & 3;
+    int64_t pp = p0 + pm;
+    if (pp >= P) pp = P - 1;
+    const int64_t ray = pp / S;
+    const float* rr = rays + ray * 11;
+    {
+      const float zz = zv[pp];
+      float x[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[c] = fadd(rr[c], fmul(rr[3 + c], zz));
+      if (pq == 0) {
+        Es[eidx(pm, 0)] = x[0]; Es[eidx(pm, 1)] = x[1]; Es[eidx(pm, 2)] = x[2];
+        Es[eidx(pm, 63)] = 0.f;
+      }
+      for (int j = pq; j < 30; j += 4) {
+        const int k = j / 3, dim = j - 3 * k;
+        const float a = fmul(x[dim], (float)(1 << k));
+        Es[eidx(pm, 3 + 6 * k + dim)] = sinf(a);
+        Es[eidx(pm, 6 + 6 * k + dim)] = cosf(a);
+      }
+    }
+    __syncthreads();
+    if (SAVE) {
+      float* ape = act + act_pe(P) + p0 * 64;
+      for (int i = tid; i < TM * 16; i += NTHR) {
+        const int m = i >> 4, sl = i & 15;
+        if (m < valid)
+          *reinterpret_cast<float4*>(ape + m * 64 + sl * 4) =
+              *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2));
+      }
+    }
+    f32x16 acc[2][2];
+    // ---- L0 : pe64 -> 256 -------------------------------------------------------------
+    zero_acc<2>(acc);
+    gemm_seg<2, true>(acc, Es, 0, 8, pk + PF_OFF(0) / 4, 8, 0, wn * 2, wm, lane);
+    epilogue_fwd<2, true>(acc, params + L_B(0), Hs, wm, wn, lane, SAVE ? act + act_h(P, 0) + p0 * 256 : nullptr, 256, valid);
+    __syncthreads();
+    // ---- L1..L7 -----------------------------------------------------------------------
+#pragma unroll 1
+    for (int l = 1; l < 8; ++l) {
+      zero_acc<2>(acc);
+      const float4* B = pk + PF_OFF(0) / 4;  // placeholder, set below
+      int64_t off;
+      switch (l) {
+        case 1: off = PF_OFF(1); break; case 2: off = PF_OFF(2); break; case 3: off = PF_OFF(3); break;
+        case 4: off = PF_OFF(4); break; case 5: off = PF_OFF(5); break; case 6: off = PF_OFF(6); break;
+        default: off = PF_OFF(7); break;
+      }
+      B = pk + off / 4;
+      if (l == 5) {
+        gemm_seg<2, true>(acc, Es, 0, 8, B, 40, 0, wn * 2, wm, lane);
+        gemm_seg<2, false>(acc, Hs, 0, 32, B, 40, 8, wn * 2, wm, lane);
+      } else {
+        gemm_seg<2, false>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane);
+      }
+      int64_t boff;
+      switch (l) {
+        case 1: boff = L_B(1); break; case 2: boff = L_B(2); break; case 3: boff = L_B(3); break;
+        case 4: boff = L_B(4); break; case 5: boff = L_B(5); break; case 6: boff = L_B(6); break;
+        default: boff = L_B(7); break;
+      }
+      __syncthreads();  // every wave has finished reading H
+      epilogue_fwd<2, true>(acc, params + boff, Hs, wm, wn, lane,
+                            SAVE ? act + act_h(P, l) + p0 * 256 : nullptr, 256, valid);
+      __syncthreads();
+    }
+    // ---- alpha head (VALU) + view-direction encoding -> Es ---------------------------
+    float alpha_val = 0.f;
+    {
+      const float* wa = params + A_W;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = pq * 64 + i * 4;
+        const float4 h = *reinterpret_cast<const float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2));
+        const float4 w = *reinterpret_cast<const float4*>(wa + k);
+        s = fmaf(h.x, w.x, s); s = fmaf(h.y, w.y, s); s = fmaf(h.z, w.z, s); s = fmaf(h.w, w.w, s);
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      alpha_val = s + params[A_B];
+      float v[3] = {rr[8], rr[9], rr[10]};
+      if (pq == 0) {
+        Es[eidx(pm, 0)] = v[0]; Es[eidx(pm, 1)] = v[1]; Es[eidx(pm, 2)] = v[2];
+#pragma unroll
+        for (int c = 27; c < 32; ++c) Es[eidx(pm, c)] = 0.f;
+      }
+      for (int j = pq; j < 12; j += 4) {
+        const int k = j / 3, dim = j - 3 * k;
+        const float a = fmul(v[dim], (float)(1 << k));
+        Es[eidx(pm, 3 + 6 * k + dim)] = sinf(a);
+        Es[eidx(pm, 6 + 6 * k + dim)] = cosf(a);
+      }
+    }
+    // ---- feature layer (no ReLU) ------------------------------------------------------
+    zero_acc<2>(acc);
+    gemm_seg<2, false>(acc, Hs, 0, 32, pk + PF_OFF(8) / 4, 32, 0, wn * 2, wm, lane);
+    __syncthreads();
+    epilogue_fwd<2, false>(acc, params + F_B, Hs, wm, wn, lane, SAVE ? act + act_feat(P) + p0 * 256 : nullptr, 256, valid);
+    __syncthreads();
+    if (SAVE) {
+      float* avp = act + act_vpe(P) + p0 * 32;
+      for (int i = tid; i < TM * 8; i += NTHR) {
+        const int m = i >> 3, sl = i & 7;
+        if (m < valid)
+          *reinterpret_cast<float4*>(avp + m * 32 + sl * 4) =
+              *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2));
+      }
+    }
+    // ---- view layer: [feat | vpe32] -> 128, ReLU ---------------------------------------
+    {
+      f32x16 av[2][1];
+      zero_acc<1>(av);
+      gemm_seg<1, false>(av, Hs, 0, 32, pk + PF_OFF(9) / 4, 36, 0, wn, wm, lane);
+      gemm_seg<1, true>(av, Es, 0, 4, pk + PF_OFF(9) / 4, 36, 32, wn, wm, lane);
+      __syncthreads();
+      epilogue_fwd<1, true>(av, params + V_B, Hs, wm, wn, lane, SAVE ? act + act_hv(P) + p0 * 128 : nullptr, 128, valid);
+      __syncthreads();
+    }
+    // ---- rgb head (VALU) + output -------------------------------------------------------
+    {
+      const float* wr = params + R_W;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = pq * 32 + i * 4;
+        const float4 h = *reinterpret_cast<const float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2));
+        const float4 w0 = *reinterpret_cast<const float4*>(wr + k);
+        const float4 w1 = *reinterpret_cast<const float4*>(wr + 128 + k);
+        const float4 w2 = *reinterpret_cast<const float4*>(wr + 256 + k);
+        s0 = fmaf(h.x, w0.x, s0); s0 = fmaf(h.y, w0.y, s0); s0 = fmaf(h.z, w0.z, s0); s0 = fmaf(h.w, w0.w, s0);
+        s1 = fmaf(h.x, w1.x, s1); s1 = fmaf(h.y, w1.y, s1); s1 = fmaf(h.z, w1.z, s1); s1 = fmaf(h.w, w1.w, s1);
+        s2 = fmaf(h.x, w2.x, s2); s2 = fmaf(h.y, w2.y, s2); s2 = fmaf(h.z, w2.z, s2); s2 = fmaf(h.w, w2.w, s2);
+      }
+      s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+      s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+      s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+      if (pq == 0 && pm < valid) {
+        float4 o;
+        o.x = s0 + params[R_B]; o.y = s1 + params[R_B + 1]; o.z = s2 + params[R_B + 2]; o.w = alpha_val;
+        *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
+      }
+    }
+    __syncthreads();  // H / Es are rewritten by the next tile
+  }
+}
+
+extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const float* z, const float* params,
+                                const float* packed_fwd, float* raw, float* act, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 1, "n>=0, S>=1");
+  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
+  if (n == 0) return 0;
+  const int64_t P = n * S;
+  const int64_t ntiles = (P + TM - 1) / TM;
+  int grid = num_cus();
+  if (ntiles < grid) grid = (int)ntiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_done = true;
+  }
+  if (act)
+    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, fn::S(stream), P, S, rays11, z, params,
+                       packed_fwd, raw, act);
+  else
+    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, fn::S(stream), P, S, rays11, z,
+                       params, packed_fwd, raw, act);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+// =========================================================================================
+// backward: dX chain
+// =========================================================================================
+// epilogue: optional rank-1 term (dalpha x wa), ReLU mask from the saved activation, write H
+// and the pre-activation gradient buffer.
+template <bool MASK, bool RANK1>
+__device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs, const float* Es_dalpha,
+                                            const float* __restrict__ wa, const float* __restrict__ hmask,
+                                            float* __restrict__ dsave, int wm, int wn, int lane, int valid) {
+  asm volatile("" : "+v"(lane));
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = (wn * 2 + nt) * 32 + (lane & 31);
+    const float wan = RANK1 ? wa[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + mt * 32 + crow(r, lane);
+        float v = acc[mt][nt][r];
+        if (RANK1) v = fmaf(Es_dalpha[m], wan, v);
+        const bool ok = m < valid;
+        if (MASK) {
+          const float h = ok ? hmask[(unsigned)(m * 256 + n)] : 0.f;
+          v = (h > 0.f) ? v : 0.f;
+        }
+        Hs[hidx(m, n)] = v;
+        if (ok) dsave[(unsigned)(m * 256 + n)] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NTHR, 2)
+mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __restrict__ act,
+                  const float* __restrict__ params, const float* __restrict__ packed_t, float* __restrict__ dact) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;
+  float* Es = smem + LDS_H;  // Es[0..127] = dalpha of the tile's rows
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const float4* pk = reinterpret_cast<const float4*>(packed_t);
+  const int64_t ntiles = (P + TM - 1) / TM;
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * TM;
+    const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
+    // ---- phase A: dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] --------------------------
+    {
+      const int pm = tid >> 2, pq = tid & 3;
+      const bool ok = pm < valid;
+      const int64_t pp = ok ? p0 + pm : P - 1;
+      const float4 dr = *reinterpret_cast<const float4*>(draw + pp * 4);
+      if (pq == 0) Es[pm] = ok ? dr.w : 0.f;
+      const float* wr = params + R_W;
+      const float* hv = act + act_hv(P) + pp * 128;
+      float* dyv = dact + dact_yv(P) + pp * 128;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = pq * 32 + i * 4;
+        const float4 h = *reinterpret_cast<const float4*>(hv + k);
+        const float4 w0 = *reinterpret_cast<const float4*>(wr + k);
+        const float4 w1 = *reinterpret_cast<const float4*>(wr + 128 + k);
+        const float4 w2 = *reinterpret_cast<const float4*>(wr + 256 + k);
+        float4 o;
+        o.x = (h.x > 0.f) ? fmaf(dr.z, w2.x, fmaf(dr.y, w1.x, dr.x * w0.x)) : 0.f;
+        o.y = (h.y > 0.f) ? fmaf(dr.z, w2.y, fmaf(dr.y, w1.y, dr.x * w0.y)) : 0.f;
+        o.z = (h.z > 0.f) ? fmaf(dr.z, w2.z, fmaf(dr.y, w1.z, dr.x * w0.z)) : 0.f;
+        o.w = (h.w > 0.f) ? fmaf(dr.z, w2.w, fmaf(dr.y, w1.w, dr.x * w0.w)) : 0.f;
+        if (!ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = o;
+        if (ok) *reinterpret_cast<float4*>(dyv + k) = o;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+    // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ------------------------------------------
+    zero_acc<2>(acc);
+    gemm_seg<2, false>(acc, Hs, 0, 16, pk + PB_OFF(0) / 4, 16, 0, wn * 2, wm, lane);
+    __syncthreads();
+    epilogue_dx<false, false>(acc, Hs, Es, nullptr, nullptr, dact + dact_feat(P) + p0 * 256, wm, wn, lane, valid);
+    __syncthreads();
+    // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ------------------------------------
+    zero_acc<2>(acc);
+    gemm_seg<2, false>(acc, Hs, 0, 32, pk + PB_OFF(1) / 4, 32, 0, wn * 2, wm, lane);
+    __syncthreads();
+    epilogue_dx<true, true>(acc, Hs, Es, params + A_W, act + act_h(P, 7) + p0 * 256,
+                            dact + dact_y(P, 7) + p0 * 256, wm, wn, lane, valid);
+    __syncthreads();
+    // ---- dY_{l-1} = (dY_l . W_l) * [h_{l-1} > 0],  l = 7..1 ------------------------------
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+      int64_t off;
+      switch (l) {
+        case 7: off = PB_OFF(2); break; case 6: off = PB_OFF(3); break; case 5: off = PB_OFF(4); break;
+        case 4: off = PB_OFF(5); break; case 3: off = PB_OFF(6); break; case 2: off = PB_OFF(7); break;
+        default: off = PB_OFF(8); break;
+      }
+      zero_acc<2>(acc);
+      gemm_seg<2, false>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane);
+      __syncthreads();
+      epilogue_dx<true, false>(acc, Hs, Es, nullptr, act + act_h(P, l - 1) + p0 * 256,
+                               dact + dact_y(P, l - 1) + p0 * 256, wm, wn, lane, valid);
+      __syncthreads();
+    }
+  }
+}
+
+// =========================================================================================
+// backward: dW = dY^T X  (split over workgroups by point chunk, partials reduced afterwards)
+// =========================================================================================
+#define DW_MT 32  // points per LDS stage
+
+// WO x WI waves (WO*WI == 4), each wave TO x TI MFMA tiles:  NO = WO*TO*32, KI = WI*TI*32
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+__global__ void __launch_bounds__(256, 1)
+mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
+                  const float* __restrict__ draw /*RANK1: dalpha = draw[p*4+3]*/, float* __restrict__ partial_w,
+                  float* __restrict__ partial_b, float* __restrict__ partial_r) {
+  constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;  // floats per LDS stage (+32 dalpha)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave / WI, wi = wave % WI;
+  // contiguous chunk of points for this workgroup (multiple of DW_MT)
+  const int64_t ntile_all = (P + DW_MT - 1) / DW_MT;
+  const int64_t per = (ntile_all + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = blockIdx.x * per;
+  int64_t t1 = t0 + per;
+  if (t1 > ntile_all) t1 = ntile_all;
+
+  f32x16 acc[TO][TI];
+#pragma unroll
+  for (int a = 0; a < TO; ++a)
+#pragma unroll
+    for (int b = 0; b < TI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f, rsum = 0.f;
+
+  constexpr int YV = DW_MT * NO / 4 / 256;  // float4 per thread for the dY stage
+  constexpr int XV = DW_MT * KI / 4 / 256;  // float4 per thread for the X stage
+  static_assert(DW_MT * NO % 1024 == 0 && DW_MT * KI % 1024 == 0, "stage split");
+  float4 ry[YV], rx[XV];
+  float rda = 0.f;
+
+  auto load_stage = [&](int64_t t) {
+    const int64_t pbase = t * DW_MT;
+#pragma unroll
+    for (int i = 0; i < YV; ++i) {
+      const int e = (i * 256 + tid) * 4;
+      const int m = e / NO, c = e % NO;
+      const int64_t p = pbase + m;
+      ry[i] = (p < P) ? *reinterpret_cast<const float4*>(dY + p * ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int e = (i * 256 + tid) * 4;
+      const int m = e / KI, c = e % KI;
+      const int64_t p = pbase + m;
+      rx[i] = (p < P) ? *reinterpret_cast<const float4*>(X + p * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (RANK1 && tid < DW_MT) {
+      const int64_t p = pbase + tid;
+      rda = (p < P) ? draw[p * 4 + 3] : 0.f;
+    }
+  };
+  auto store_stage = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < YV; ++i) *reinterpret_cast<float4*>(st + (i * 256 + tid) * 4) = ry[i];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(st + DW_MT * NO + (i * 256 + tid) * 4) = rx[i];
+    if (RANK1 && tid < DW_MT) st[DW_MT * (NO + KI) + tid] = rda;
+  };
+
+  if (t0 < t1) {
+    load_stage(t0);
+    store_stage(smem);
+  }
+  __syncthreads();
+  for (int64_t t = t0; t < t1; ++t) {
+    float* cur = smem + ((t - t0) & 1) * STAGE;
+    float* nxt = smem + (((t - t0) & 1) ^ 1) * STAGE;
+    if (t + 1 < t1) load_stage(t + 1);
+    const float* Ys = cur;
+    const float* Xs = cur + DW_MT * NO;
+    // MFMA over the stage's 32 points, 2 per step
+#pragma unroll 4
+    for (int k2 = 0; k2 < DW_MT / 2; ++k2) {
+      const int m = k2 * 2 + (lane >> 5);
+      float a[TO], b[TI];
+#pragma unroll
+      for (int i = 0; i < TO; ++i) a[i] = Ys[m * NO + (wo * TO + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TI; ++j) b[j] = Xs[m * KI + (wi * TI + j) * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TO; ++i)
+#pragma unroll
+        for (int j = 0; j < TI; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+    }
+    if (BIAS) {
+      if (tid < NO) {
+#pragma unroll 8
+        for (int m = 0; m < DW_MT; ++m) bsum += Ys[m * NO + tid];
+      }
+    }
+    if (RANK1) {
+      if (tid < KI) {
+        const float* da = cur + DW_MT * (NO + KI);
+#pragma unroll 8
+        for (int m = 0; m < DW_MT; ++m) rsum = fmaf(da[m], Xs[m * KI + tid], rsum);
+      }
+    }
+    if (t + 1 < t1) store_stage(nxt);
+    __syncthreads();
+  }
+  // write partials
+  float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (wo * TO + i) * 32 + crow(r, lane);
+        const int c = (wi * TI + j) * 32 + (lane & 31);
+        pw[(int64_t)o * KI + c] = acc[i][j][r];
+      }
+  if (BIAS && tid < NO) partial_b[(int64_t)blockIdx.x * NO + tid] = bsum;
+  if (RANK1 && tid < KI) partial_r[(int64_t)blockIdx.x * KI + tid] = rsum;
+}
+
+// rgb head + alpha bias gradients (VALU reduction over points): per-workgroup partials
+//   out[wg][0..383] = dWr[c][k], [384..386] = dbr[c], [387] = dba
+__global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float* __restrict__ draw,
+                                                          const float* __restrict__ hv,
+                                                          float* __restrict__ partial) {
+  const int k = threadIdx.x;
+  const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+  const int64_t pa = blockIdx.x * per;
+  int64_t pb = pa + per;
+  if (pb > P) pb = P;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, sb = 0.f;
+  for (int64_t p = pa; p < pb; ++p) {
+    const float4 d = *reinterpret_cast<const float4*>(draw + p * 4);
+    const float h = hv[p * 128 + k];
+    s0 = fmaf(d.x, h, s0); s1 = fmaf(d.y, h, s1); s2 = fmaf(d.z, h, s2);
+    if (k < 4) sb += (k == 0) ? d.x : (k == 1) ? d.y : (k == 2) ? d.z : d.w;
+  }
+  float* o = partial + (int64_t)blockIdx.x * 388;
+  o[k] = s0; o[128 + k] = s1; o[256 + k] = s2;
+  if (k < 4) o[384 + k] = sb;
+}
+
+// dst[r*ld + c] = sum_wg partial[wg][r][c]
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nwg,
+                                                               int64_t wg_stride, int rows, int cols,
+                                                               float* __restrict__ dst, int ld, int valid_cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    if (c >= valid_cols) continue;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += partial[(int64_t)w * wg_stride + e];
+    dst[(int64_t)r * ld + c] = s;
+  }
+}
+
+static const int64_t DW_PARTIAL_W = 256 * 256;  // floats per workgroup, largest job
+extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
+  return (int64_t)num_cus() * (DW_PARTIAL_W + 256 + 256);
+}
+
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* partial,
+                     int nwg, hipStream_t st) {
+  constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
+  const size_t lds = 2 * STAGE * sizeof(float);
+  auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1>;
+  static bool attr = false;
+  if (!attr) {
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  float* pw = partial;
+  float* pb = partial + (int64_t)nwg * DW_PARTIAL_W;
+  float* pr = pb + (int64_t)nwg * 256;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_reduce(const float* partial, int nwg, int rows, int cols, float* dst, int ld, int valid_cols,
+                         hipStream_t st) {
+  const int64_t total = (int64_t)rows * cols;
+  int g = (int)((total + 255) / 256);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(g), dim3(256), 0, st, partial, nwg, total, rows, cols, dst, ld,
+                     valid_cols);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float* act, const float* params,
+                                const float* packed_bwd, float* dact, float* partial, float* grads,
+                                fn_stream_t stream) {
+  FN_CHECK_ARG(n > 0 && S >= 1, "n>0, S>=1");
+  FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads, "null pointer");
+  hipStream_t st = fn::S(stream);
+  const int64_t P = n * S;
+  const int64_t ntiles = (P + TM - 1) / TM;
+  int grid = num_cus();
+  if (ntiles < grid) grid = (int)ntiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_dx_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact);
+  FN_LAUNCH_CHECK();
+
+  // ---- dW jobs -----------------------------------------------------------------------------
+  const int64_t nt32 = (P + DW_MT - 1) / DW_MT;
+  int nwg = num_cus();
+  if (nt32 < nwg) nwg = (int)nt32;
+  const float* pw = partial;
+  const float* pb = partial + (int64_t)nwg * DW_PARTIAL_W;
+  const float* pr = pb + (int64_t)nwg * 256;
+  int rc;
+  const float* a_pe = act + act_pe(P);
+  // L0: dY0^T pe64  -> [256][63] (+bias)
+  if ((rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, partial, nwg, st))) return rc;
+  if ((rc = launch_reduce(pw, nwg, 256, 64, grads + L_W(0), 63, 63, st))) return rc;
+  if ((rc = launch_reduce(pb, nwg, 1, 256, grads + L_B(0), 256, 256, st))) return rc;
+  // L1..L7 (h part) (+bias); L5 also has the pe part
+  for (int l = 1; l < 8; ++l) {
+    const int64_t woff = (l == 1) ? L_W(1) : (l == 2) ? L_W(2) : (l == 3) ? L_W(3) : (l == 4) ? L_W(4)
+                        : (l == 5) ? L_W(5) : (l == 6) ? L_W(6) : L_W(7);
+    const int64_t boff = (l == 1) ? L_B(1) : (l == 2) ? L_B(2) : (l == 3) ? L_B(3) : (l == 4) ? L_B(4)
+                        : (l == 5) ? L_B(5) : (l == 6) ? L_B(6) : L_B(7);
+    const int ld = (l == 5) ? 319 : 256;
+    const int c0 = (l == 5) ? 63 : 0;
+    if ((rc = launch_dw<2, 2, 4, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, l - 1), 256, nullptr, partial, nwg, st))) return rc;
+    if ((rc = launch_reduce(pw, nwg, 256, 256, grads + woff + c0, ld, 256, st))) return rc;
+    if ((rc = launch_reduce(pb, nwg, 1, 256, grads + boff, 256, 256, st))) return rc;
+    if (l == 5) {
+      if ((rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, partial, nwg, st))) return rc;
+      if ((rc = launch_reduce(pw, nwg, 256, 64, grads + L_W(5), 319, 63, st))) return rc;
+    }
+  }
+  // feature layer: dfeat^T h7 (+bias) and the alpha head as a rank-1 row: dWa = sum dalpha * h7
+  if ((rc = launch_dw<2, 2, 4, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, 7), 256, draw, partial, nwg, st))) return rc;
+  if ((rc = launch_reduce(pw, nwg, 256, 256, grads + F_W, 256, 256, st))) return rc;
+  if ((rc = launch_reduce(pb, nwg, 1, 256, grads + F_B, 256, 256, st))) return rc;
+  if ((rc = launch_reduce(pr, nwg, 1, 256, grads + A_W, 256, 256, st))) return rc;
+  // view layer: dYv^T [feat | vpe] (+bias)
+  if ((rc = launch_dw<2, 2, 2, 4, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P), 256, nullptr, partial, nwg, st))) return rc;
+  if ((rc = launch_reduce(pw, nwg, 128, 256, grads + V_W, 283, 256, st))) return rc;
+  if ((rc = launch_reduce(pb, nwg, 1, 128, grads + V_B, 128, 128, st))) return rc;
+  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P), 32, nullptr, partial, nwg, st))) return rc;
+  if ((rc = launch_reduce(pw, nwg, 128, 32, grads + V_W + 256, 283, 27, st))) return rc;
+  // rgb head + alpha bias
+  {
+    int hg = num_cus();
+    if (P < hg) hg = (int)P;
+    hipLaunchKernelGGL(head_grads_kernel, dim3(hg), dim3(128), 0, st, P, draw, act + act_hv(P), partial);
+    FN_LAUNCH_CHECK();
+    if ((rc = launch_reduce(partial, hg, 1, 388, grads + R_W, 388, 387, st))) return rc;  // dWr (384) + dbr (3)
+    // dba is element 387 of each partial row -> grads[A_B]
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partial + 387, hg, (int64_t)388, 1, 1,
+                       grads + A_B, 1, 1);
+    FN_LAUNCH_CHECK();
+  }
+  return 0;
+}

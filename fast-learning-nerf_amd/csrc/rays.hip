@@ -1,0 +1,261 @@
+// rays.hip -- ray generation, NDC warp, ray packing, coarse stratified sampling and the
+// stand-alone positional encoder for gfx950.  All kernels are HBM-write bound and tiny next
+// to the MLP; they use one lane per output row with coalesced 12/44-byte records.
+//
+// Reference semantics (nerf-ours/): get_rays run_nerf_helpers.py:68-78, ndc_rays :91-108,
+// render() prologue render.py:59-80, coarse sampler render.py:244-266, Embedder :15-63.
+// fp32 op order follows the reference (mul and add rounded separately; build uses
+// -ffp-contract=off).
+#include <stdarg.h>
+#include "common.h"
+
+namespace fn {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+}  // namespace fn
+
+extern "C" int fastnerf_version(void) { return 1; }
+extern "C" const char* fastnerf_last_error(void) { return fn::g_err.c_str(); }
+extern "C" int fastnerf_device_cus(void) {
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    fn::set_error("fastnerf_device_cus: no HIP device");
+    return -2;
+  }
+  return p.multiProcessorCount;
+}
+
+struct Cam {
+  float r[12];  // c2w 3x4 row-major
+};
+
+__device__ __forceinline__ void pixel_ray(float row, float col, float fx, float fy, float cx, float cy,
+                                          const float* __restrict__ c, float d[3]) {
+  const float dx = (col - cx) / fx;
+  const float dy = -(row - cy) / fy;
+  const float dz = -1.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    d[k] = fadd(fadd(fmul(dx, c[4 * k + 0]), fmul(dy, c[4 * k + 1])), fmul(dz, c[4 * k + 2]));
+}
+
+__global__ void gen_rays_kernel(int H, int W, float fx, float fy, float cx, float cy, Cam cam,
+                                float* __restrict__ ro, float* __restrict__ rd) {
+  const int64_t n = (int64_t)H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / W), col = (int)(i % W);
+    float d[3];
+    pixel_ray((float)row, (float)col, fx, fy, cx, cy, cam.r, d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rd[i * 3 + k] = d[k];
+      ro[i * 3 + k] = cam.r[4 * k + 3];
+    }
+  }
+}
+
+__global__ void gen_rays_pixels_kernel(int64_t n, const int32_t* __restrict__ pix, const float* __restrict__ poses,
+                                       float fx, float fy, float cx, float cy, float* __restrict__ ro,
+                                       float* __restrict__ rd) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int img = pix[i * 3 + 0];
+    const float* c = poses + (int64_t)img * 12;
+    float cc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) cc[k] = c[k];
+    float d[3];
+    pixel_ray((float)pix[i * 3 + 1], (float)pix[i * 3 + 2], fx, fy, cx, cy, cc, d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rd[i * 3 + k] = d[k];
+      ro[i * 3 + k] = cc[4 * k + 3];
+    }
+  }
+}
+
+__device__ __forceinline__ void ndc_one(float sx, float sy, float near, const float o[3], const float d[3],
+                                        float no[3], float nd[3]) {
+  const float t = -(near + o[2]) / d[2];
+  float p[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = fadd(o[k], fmul(t, d[k]));
+  no[0] = fmul(sx, p[0]) / p[2];
+  no[1] = fmul(sy, p[1]) / p[2];
+  no[2] = fadd(1.0f, fmul(2.0f, near) / p[2]);
+  nd[0] = fmul(sx, fsub(d[0] / d[2], p[0] / p[2]));
+  nd[1] = fmul(sy, fsub(d[1] / d[2], p[1] / p[2]));
+  nd[2] = fmul(-2.0f, near) / p[2];
+}
+
+__global__ void ndc_kernel(int64_t n, float sx, float sy, float near, const float* __restrict__ ro,
+                           const float* __restrict__ rd, float* __restrict__ oo, float* __restrict__ od) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float o[3] = {ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2]};
+    float d[3] = {rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]};
+    float no[3], nd[3];
+    ndc_one(sx, sy, near, o, d, no, nd);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      oo[i * 3 + k] = no[k];
+      od[i * 3 + k] = nd[k];
+    }
+  }
+}
+
+__global__ void pack_rays_kernel(int64_t n, const float* __restrict__ ro, const float* __restrict__ rd, float near,
+                                 float far, int ndc, float sx, float sy, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float o[3] = {ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2]};
+    float d[3] = {rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]};
+    const float nrm = sqrtf(fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2])));
+    float v[3] = {d[0] / nrm, d[1] / nrm, d[2] / nrm};
+    if (ndc) {
+      float no[3], nd[3];
+      ndc_one(sx, sy, 1.0f, o, d, no, nd);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { o[k] = no[k]; d[k] = nd[k]; }
+    }
+    float* r = out + i * 11;
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+    r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    r[6] = near; r[7] = far;
+    r[8] = v[0]; r[9] = v[1]; r[10] = v[2];
+  }
+}
+
+// torch.linspace(0,1,S) fp32: symmetric evaluation (start+step*i below the midpoint,
+// end-step*(S-1-i) above it).
+__device__ __forceinline__ float lin01(int i, int S) {
+  const float step = 1.0f / (float)(S - 1);
+  return (i < S / 2) ? fmul(step, (float)i) : fsub(1.0f, fmul(step, (float)(S - 1 - i)));
+}
+
+__device__ __forceinline__ float coarse_depth(float near, float far, int i, int S, int lindisp) {
+  if (S == 1) return near;
+  const float t = lin01(i, S);
+  if (!lindisp) return fadd(fmul(near, fsub(1.0f, t)), fmul(far, t));
+  return 1.0f / fadd(fmul(1.0f / near, fsub(1.0f, t)), fmul(1.0f / far, t));
+}
+
+__global__ void sample_coarse_kernel(int64_t n, int S, const float* __restrict__ rays, int lindisp, int perturb,
+                                     const float* __restrict__ t_rand, uint64_t seed, float* __restrict__ z) {
+  const int64_t total = n * S;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / S;
+    const int s = (int)(i % S);
+    const float near = rays[r * 11 + 6], far = rays[r * 11 + 7];
+    const float zc = coarse_depth(near, far, s, S, lindisp);
+    float out = zc;
+    if (perturb) {
+      const float zl = coarse_depth(near, far, s > 0 ? s - 1 : 0, S, lindisp);
+      const float zu = coarse_depth(near, far, s < S - 1 ? s + 1 : S - 1, S, lindisp);
+      const float lower = (s > 0) ? fmul(0.5f, fadd(zc, zl)) : zc;
+      const float upper = (s < S - 1) ? fmul(0.5f, fadd(zu, zc)) : zc;
+      float u;
+      if (t_rand) {
+        u = t_rand[i];
+      } else {
+        uint32_t o[4];
+        philox4x32((uint32_t)i, (uint32_t)(i >> 32), 0x636f6172u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        u = u01(o[0]);
+      }
+      out = fadd(lower, fmul(fsub(upper, lower), u));
+    }
+    z[i] = out;
+  }
+}
+
+__global__ void posenc_kernel(int64_t n, int L, const float* __restrict__ x, float* __restrict__ out) {
+  const int C = 3 + 6 * L;
+  const int64_t total = n * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / C;
+    const int c = (int)(i % C);
+    float v;
+    if (c < 3) {
+      v = x[p * 3 + c];
+    } else {
+      const int j = c - 3, k = j / 6, t = j % 6;
+      const float a = fmul(x[p * 3 + (t % 3)], (float)(1 << k));
+      v = (t < 3) ? sinf(a) : cosf(a);
+    }
+    out[i] = v;
+  }
+}
+
+static inline int grid_for(int64_t n, int block = 256) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+extern "C" int fastnerf_gen_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host,
+                                 float* rays_o, float* rays_d, fn_stream_t stream) {
+  FN_CHECK_ARG(H > 0 && W > 0 && c2w_host && rays_o && rays_d, "H,W>0 and non-null pointers");
+  Cam cam;
+  for (int i = 0; i < 12; ++i) cam.r[i] = c2w_host[i];
+  hipLaunchKernelGGL(gen_rays_kernel, dim3(grid_for((int64_t)H * W)), dim3(256), 0, fn::S(stream), H, W, fx, fy, cx,
+                     cy, cam, rays_o, rays_d);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fastnerf_gen_rays_pixels(int64_t n, const int32_t* pix, const float* poses, float fx, float fy,
+                                        float cx, float cy, float* rays_o, float* rays_d, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && (n == 0 || (pix && poses && rays_o && rays_d)), "null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gen_rays_pixels_kernel, dim3(grid_for(n)), dim3(256), 0, fn::S(stream), n, pix, poses, fx, fy,
+                     cx, cy, rays_o, rays_d);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+// -1./(W/(2.*focal)) is evaluated in double by Python and then applied as an fp32 scalar
+static inline float ndc_scale(int dim, double focal) { return (float)(-1.0 / ((double)dim / (2.0 * focal))); }
+
+extern "C" int fastnerf_ndc_rays(int64_t n, int H, int W, double focal, float near, const float* rays_o,
+                                 const float* rays_d, float* out_o, float* out_d, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && (n == 0 || (rays_o && rays_d && out_o && out_d)), "null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ndc_kernel, dim3(grid_for(n)), dim3(256), 0, fn::S(stream), n, ndc_scale(W, focal), ndc_scale(H, focal),
+                     near, rays_o, rays_d, out_o, out_d);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fastnerf_pack_rays(int64_t n, const float* rays_o, const float* rays_d, float near, float far, int ndc,
+                                  int H, int W, double focal, float* rays11, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && (n == 0 || (rays_o && rays_d && rays11)), "null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(pack_rays_kernel, dim3(grid_for(n)), dim3(256), 0, fn::S(stream), n, rays_o, rays_d, near, far,
+                     ndc, ndc ? ndc_scale(W, focal) : 0.f, ndc ? ndc_scale(H, focal) : 0.f, rays11);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fastnerf_sample_coarse(int64_t n, int S, const float* rays11, int lindisp, int perturb,
+                                      const float* t_rand, uint64_t seed, float* z, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 1 && (n == 0 || (rays11 && z)), "n>=0, S>=1, non-null pointers");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sample_coarse_kernel, dim3(grid_for(n * S)), dim3(256), 0, fn::S(stream), n, S, rays11, lindisp,
+                     perturb, t_rand, seed, z);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fastnerf_posenc(int64_t n, int L, const float* x, float* out, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && L >= 0 && L <= 16 && (n == 0 || (x && out)), "n>=0, 0<=L<=16, non-null pointers");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(n * (3 + 6 * L))), dim3(256), 0, fn::S(stream), n, L, x, out);
+  FN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,190 @@
+"""Thin tensor-level wrappers over the C ABI (one per entry point).
+
+PyTorch is plumbing here: it owns device memory and the stream; every op calls
+straight into libfastnerf.so with raw pointers.  No op has a CPU fallback."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, require_gpu, stream
+
+NET_PARAMS = 595844
+PACKED_FWD = 593920
+PACKED_BWD = 557056
+ACT_FLOATS = 2528
+DACT_FLOATS = 2432
+
+
+def _f32(t):
+    return t.contiguous().float()
+
+
+def gen_rays(H, W, K, c2w):
+    """get_rays (run_nerf_helpers.py:68-78) for every pixel of one camera -> ([H,W,3], [H,W,3])."""
+    c2w_t = torch.as_tensor(c2w, dtype=torch.float32)
+    dev = c2w_t.device if c2w_t.is_cuda else torch.device('cuda')
+    host = np.ascontiguousarray(c2w_t.detach().cpu().numpy()[:3, :4], dtype=np.float32)
+    ro = torch.empty(H, W, 3, device=dev, dtype=torch.float32)
+    rd = torch.empty(H, W, 3, device=dev, dtype=torch.float32)
+    check(lib().fastnerf_gen_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
+                                  host.ctypes.data, ptr(ro), ptr(rd), stream()), 'fastnerf_gen_rays')
+    return ro, rd
+
+
+def gen_rays_pixels(pix, poses, K):
+    """Rays for selected (image,row,col) pixels; pix [n,3] int32 cuda, poses [n_img,3,4] cuda."""
+    require_gpu(pix, poses)
+    n = pix.shape[0]
+    ro = torch.empty(n, 3, device=pix.device, dtype=torch.float32)
+    rd = torch.empty(n, 3, device=pix.device, dtype=torch.float32)
+    check(lib().fastnerf_gen_rays_pixels(n, ptr(pix.contiguous().int()), ptr(_f32(poses)), float(K[0][0]),
+                                         float(K[1][1]), float(K[0][2]), float(K[1][2]), ptr(ro), ptr(rd), stream()),
+          'fastnerf_gen_rays_pixels')
+    return ro, rd
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    require_gpu(rays_o, rays_d)
+    sh = rays_o.shape
+    ro, rd = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+    oo, od = torch.empty_like(ro), torch.empty_like(rd)
+    check(lib().fastnerf_ndc_rays(ro.shape[0], H, W, float(focal), float(near), ptr(ro), ptr(rd), ptr(oo), ptr(od),
+                                  stream()), 'fastnerf_ndc_rays')
+    return oo.reshape(sh), od.reshape(sh)
+
+
+def pack_rays(rays_o, rays_d, near, far, ndc=False, H=0, W=0, focal=1.0):
+    require_gpu(rays_o, rays_d)
+    ro, rd = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+    out = torch.empty(ro.shape[0], 11, device=ro.device, dtype=torch.float32)
+    check(lib().fastnerf_pack_rays(ro.shape[0], ptr(ro), ptr(rd), float(near), float(far), int(bool(ndc)), int(H),
+                                   int(W), float(focal), ptr(out), stream()), 'fastnerf_pack_rays')
+    return out
+
+
+def sample_coarse(rays11, S, lindisp=False, perturb=False, t_rand=None, seed=0):
+    require_gpu(rays11, t_rand)
+    n = rays11.shape[0]
+    z = torch.empty(n, S, device=rays11.device, dtype=torch.float32)
+    if t_rand is not None:
+        t_rand = _f32(t_rand)
+        assert t_rand.shape == (n, S)
+    check(lib().fastnerf_sample_coarse(n, S, ptr(rays11), int(bool(lindisp)), int(bool(perturb) or t_rand is not None),
+                                       ptr(t_rand), int(seed), ptr(z), stream()), 'fastnerf_sample_coarse')
+    return z
+
+
+def posenc(x, L):
+    require_gpu(x)
+    sh = x.shape
+    xf = _f32(x).reshape(-1, 3)
+    out = torch.empty(xf.shape[0], 3 + 6 * L, device=x.device, dtype=torch.float32)
+    check(lib().fastnerf_posenc(xf.shape[0], L, ptr(xf), ptr(out), stream()), 'fastnerf_posenc')
+    return out.reshape(list(sh[:-1]) + [3 + 6 * L])
+
+
+def mlp_pack(params, packed_fwd=None, packed_bwd=None):
+    require_gpu(params)
+    assert params.numel() == NET_PARAMS and params.is_contiguous()
+    if packed_fwd is None:
+        packed_fwd = torch.empty(PACKED_FWD, device=params.device, dtype=torch.float32)
+    if packed_bwd is None:
+        packed_bwd = torch.empty(PACKED_BWD, device=params.device, dtype=torch.float32)
+    check(lib().fastnerf_mlp_pack(ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()), 'fastnerf_mlp_pack')
+    return packed_fwd, packed_bwd
+
+
+def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None):
+    require_gpu(rays11, z, params, packed_fwd)
+    n, S = z.shape
+    if raw is None:
+        raw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
+    if act is not None:
+        assert act.numel() >= n * S * ACT_FLOATS
+    check(lib().fastnerf_mlp_fwd(n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw), ptr(act), stream()),
+          'fastnerf_mlp_fwd')
+    return raw
+
+
+def mlp_bwd_partial_floats():
+    return int(lib().fastnerf_mlp_bwd_partial_floats())
+
+
+def mlp_bwd(draw, act, params, packed_bwd, dact, partial, grads):
+    require_gpu(draw, act, params, packed_bwd, dact, partial, grads)
+    n, S = draw.shape[0], draw.shape[1]
+    assert dact.numel() >= n * S * DACT_FLOATS and grads.numel() == NET_PARAMS
+    check(lib().fastnerf_mlp_bwd(n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact), ptr(partial),
+                                 ptr(grads), stream()), 'fastnerf_mlp_bwd')
+    return grads
+
+
+def raw2outputs_fwd(raw, z, rays11, noise=None, white_bkgd=False):
+    require_gpu(raw, z, rays11, noise)
+    n, S = z.shape
+    dev = z.device
+    rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    disp = torch.empty(n, device=dev, dtype=torch.float32)
+    acc = torch.empty(n, device=dev, dtype=torch.float32)
+    weights = torch.empty(n, S, device=dev, dtype=torch.float32)
+    depth = torch.empty(n, device=dev, dtype=torch.float32)
+    check(lib().fastnerf_raw2outputs_fwd(n, S, ptr(raw), ptr(z), ptr(rays11), ptr(noise), int(bool(white_bkgd)),
+                                         ptr(rgb), ptr(disp), ptr(acc), ptr(weights), ptr(depth), stream()),
+          'fastnerf_raw2outputs_fwd')
+    return rgb, disp, acc, weights, depth
+
+
+def raw2outputs_bwd(raw, z, rays11, g_rgb, noise=None, white_bkgd=False, draw=None):
+    require_gpu(raw, z, rays11, g_rgb, noise)
+    n, S = z.shape
+    if draw is None:
+        draw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
+    check(lib().fastnerf_raw2outputs_bwd(n, S, ptr(raw), ptr(z), ptr(rays11), ptr(noise), int(bool(white_bkgd)),
+                                         ptr(_f32(g_rgb)), ptr(draw), stream()), 'fastnerf_raw2outputs_bwd')
+    return draw
+
+
+def sample_pdf_merge(z, weights, Ni, det=False, u=None, seed=0, want_samples=True):
+    require_gpu(z, weights, u)
+    n, S = z.shape
+    dev = z.device
+    z_out = torch.empty(n, S + Ni, device=dev, dtype=torch.float32)
+    z_samples = torch.empty(n, Ni, device=dev, dtype=torch.float32) if want_samples else None
+    z_std = torch.empty(n, device=dev, dtype=torch.float32)
+    if u is not None:
+        u = _f32(u)
+        assert u.shape == (n, Ni)
+    check(lib().fastnerf_sample_pdf_merge(n, S, Ni, ptr(z), ptr(weights), int(bool(det)), ptr(u), int(seed),
+                                          ptr(z_out), ptr(z_samples), ptr(z_std), stream()),
+          'fastnerf_sample_pdf_merge')
+    return z_out, z_samples, z_std
+
+
+def sample_pdf(bins, weights, Ni, det=False, u=None, seed=0):
+    require_gpu(bins, weights, u)
+    n, M = bins.shape
+    out = torch.empty(n, Ni, device=bins.device, dtype=torch.float32)
+    if u is not None:
+        u = _f32(u)
+    check(lib().fastnerf_sample_pdf(n, M, Ni, ptr(_f32(bins)), ptr(_f32(weights)), int(bool(det)), ptr(u), int(seed),
+                                    ptr(out), stream()), 'fastnerf_sample_pdf')
+    return out
+
+
+def mse_leafmax(rgb, rgb0, target, grad_scale=1.0, want_grads=True, leaf_tag=None, max_leaves=0, table=None):
+    require_gpu(rgb, rgb0, target, leaf_tag, table)
+    n = rgb.shape[0]
+    dev = rgb.device
+    g = torch.empty(n, 3, device=dev, dtype=torch.float32) if want_grads else None
+    g0 = torch.empty(n, 3, device=dev, dtype=torch.float32) if (want_grads and rgb0 is not None) else None
+    loss2 = torch.empty(2, device=dev, dtype=torch.float32)
+    check(lib().fastnerf_mse_leafmax(n, ptr(rgb), ptr(rgb0), ptr(target), float(grad_scale), ptr(g), ptr(g0),
+                                     ptr(loss2), ptr(leaf_tag), int(max_leaves), ptr(table), stream()),
+          'fastnerf_mse_leafmax')
+    return loss2, g, g0
+
+
+def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    require_gpu(params, grads, m, v)
+    check(lib().fastnerf_adam_step(params.numel(), ptr(params), ptr(grads), ptr(m), ptr(v), float(lr), float(beta1),
+                                   float(beta2), float(eps), int(step), stream()), 'fastnerf_adam_step')

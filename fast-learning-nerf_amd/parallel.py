@@ -1,0 +1,63 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL ("nccl" backend on
+ROCm) across xGMI; gloo on CPU for the world_size-2 tests.
+
+The reference's only multi-GPU strategy is single-process nn.DataParallel around the MLP
+(run_nerf.py:82,90).  Here every rank renders its shard of the ray batch end to end
+and the ONLY exchange per optimiser step is one all-reduce(SUM) of the flat gradient buffer
+(2 x 595,844 fp32 = 4.77 MB: latency-bound on xGMI, so one fused buffer instead of 48 tensors),
+plus one all-reduce(MAX) of the per-(image, leaf) error table per subdivide epoch (max is
+associative, so the result is bit-identical to the single-GPU table)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type=None):
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rk = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        use_cuda = torch.cuda.is_available() if device_type is None else device_type == 'cuda'
+        if use_cuda:
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend='nccl' if use_cuda else 'gloo', rank=rk, world_size=world)
+    return rk, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def all_reduce_sum(flat):
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def all_reduce_max_int(table_i32):
+    """MAX over ranks of the leaf-error table stored as the int32 bit patterns of non-negative
+    floats (monotone in the float value) -> exact and order independent."""
+    if world_size() > 1:
+        dist.all_reduce(table_i32, op=dist.ReduceOp.MAX)
+    return table_i32
+
+
+def shard(n, rk=None, world=None):
+    """Interleaved shard rows rk::world of a batch of n rays."""
+    rk = rank() if rk is None else rk
+    world = world_size() if world is None else world
+    return slice(rk, n, world)
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,275 @@
+"""Volumetric renderer -- mirror of nerf-ours/render.py on the HIP kernels.
+
+Same call surface: render (render.py:26-91), batchify_rays (:12-24), render_rays (:195-305),
+raw2outputs (:149-192), render_path (:94-146).  `render_rays` runs the fused device pipeline
+
+    sample_coarse -> mlp_fwd(coarse) -> raw2outputs -> sample_pdf_merge -> mlp_fwd(fine) -> raw2outputs
+
+and, when autograd is recording, registers ONE autograd node whose backward runs
+raw2outputs_bwd + mlp_bwd for both nets and hands the flat gradients to the NeRF parameters,
+so the reference's `loss.backward(); optimizer.step()` loop works unchanged.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .model import NeRF, param_slices
+from .run_nerf_helpers import get_rays, to8b
+
+_SEED_GEN = torch.Generator()
+
+
+def _next_seed():
+    # device-side Philox streams are keyed from torch's global CPU RNG so torch.manual_seed governs them
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _pytest_rand(shape, device):
+    np.random.seed(0)
+    return torch.Tensor(np.random.rand(*shape)).to(device)
+
+
+class _Workspace:
+    """Per-device scratch for the backward pass (activations are allocated per call; the
+    split-K partial buffer and the dact scratch are reused)."""
+    _cache = {}
+
+    @classmethod
+    def partial(cls, device):
+        key = ('partial', str(device))
+        if key not in cls._cache:
+            cls._cache[key] = torch.empty(ops.mlp_bwd_partial_floats(), device=device, dtype=torch.float32)
+        return cls._cache[key]
+
+    @classmethod
+    def dact(cls, device, floats):
+        key = ('dact', str(device))
+        t = cls._cache.get(key)
+        if t is None or t.numel() < floats:
+            cls._cache[key] = t = torch.empty(floats, device=device, dtype=torch.float32)
+        return t
+
+
+def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, perturb, white_bkgd, t_rand, u, noise0,
+                  noise1, save, packed_c=None, packed_f=None):
+    """The fused forward.  Returns (outputs dict, saved-for-backward dict)."""
+    n = rays11.shape[0]
+    dev = rays11.device
+    pc = packed_c if packed_c is not None else net_c.packed()
+    z0 = ops.sample_coarse(rays11, N_samples, lindisp=lindisp, perturb=perturb, t_rand=t_rand,
+                           seed=_next_seed() if (perturb and t_rand is None) else 0)
+    act0 = torch.empty(n * N_samples * ops.ACT_FLOATS, device=dev, dtype=torch.float32) if save else None
+    raw0 = ops.mlp_fwd(rays11, z0, net_c.flat, pc[0], act=act0)
+    rgb0, disp0, acc0, w0, depth0 = ops.raw2outputs_fwd(raw0, z0, rays11, noise0, white_bkgd)
+    out = {}
+    saved = {'rays11': rays11, 'z0': z0, 'raw0': raw0, 'act0': act0, 'noise0': noise0, 'white': white_bkgd,
+             'net_c': net_c, 'net_f': None, 'pc': pc}
+    if N_importance > 0:
+        fine = net_f if net_f is not None else net_c
+        pf = packed_f if packed_f is not None else (fine.packed() if fine is not net_c else pc)
+        z1, z_samples, z_std = ops.sample_pdf_merge(z0, w0, N_importance, det=(perturb == 0.), u=u,
+                                                    seed=_next_seed() if (perturb and u is None) else 0)
+        S1 = N_samples + N_importance
+        act1 = torch.empty(n * S1 * ops.ACT_FLOATS, device=dev, dtype=torch.float32) if save else None
+        raw1 = ops.mlp_fwd(rays11, z1, fine.flat, pf[0], act=act1)
+        rgb1, disp1, acc1, w1, depth1 = ops.raw2outputs_fwd(raw1, z1, rays11, noise1, white_bkgd)
+        out.update(rgb_map=rgb1, disp_map=disp1, acc_map=acc1, raw=raw1, rgb0=rgb0, disp0=disp0, acc0=acc0,
+                   z_std=z_std, weights=w1, z_vals=z1, depth_map=depth1, z_samples=z_samples, weights0=w0, z0=z0)
+        saved.update(z1=z1, raw1=raw1, act1=act1, noise1=noise1, net_f=fine, pf=pf)
+    else:
+        out.update(rgb_map=rgb0, disp_map=disp0, acc_map=acc0, raw=raw0, weights=w0, z_vals=z0, depth_map=depth0)
+    return out, saved
+
+
+def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None):
+    """Writes d(loss)/d(params) of the coarse (and fine) net, given d(loss)/d(rgb maps), into
+    out_c / out_f (flat, parameter order; default: the nets' flat_grad buffers)."""
+    rays11 = saved['rays11']
+    dev = rays11.device
+    partial = _Workspace.partial(dev)
+    net_c, net_f = saved['net_c'], saved['net_f']
+    out_c = out_c if out_c is not None else net_c.flat_grad
+    if net_f is not None and net_f is not net_c:
+        out_f = out_f if out_f is not None else net_f.flat_grad
+    if net_f is not None:
+        n, S1 = saved['z1'].shape
+        if g_rgb is None:
+            g_rgb = torch.zeros(n, 3, device=dev)
+        draw1 = ops.raw2outputs_bwd(saved['raw1'], saved['z1'], rays11, g_rgb, saved['noise1'], saved['white'])
+        dact = _Workspace.dact(dev, n * S1 * ops.DACT_FLOATS)
+        if net_f is net_c:
+            gtmp = torch.empty_like(out_c)
+            ops.mlp_bwd(draw1, saved['act1'], net_f.flat, saved['pf'][1], dact, partial, gtmp)
+        else:
+            ops.mlp_bwd(draw1, saved['act1'], net_f.flat, saved['pf'][1], dact, partial, out_f)
+            gtmp = None
+        g_c = g_rgb0
+    else:
+        g_c, gtmp = g_rgb, None
+    n, S0 = saved['z0'].shape
+    if g_c is None:
+        g_c = torch.zeros(n, 3, device=dev)
+    draw0 = ops.raw2outputs_bwd(saved['raw0'], saved['z0'], rays11, g_c, saved['noise0'], saved['white'])
+    dact = _Workspace.dact(dev, n * S0 * ops.DACT_FLOATS)
+    ops.mlp_bwd(draw0, saved['act0'], net_c.flat, saved['pc'][1], dact, partial, out_c)
+    if gtmp is not None:
+        out_c.add_(gtmp)
+
+
+def _grad_views(flat):
+    return [flat[off:off + int(np.prod(shape))].view(shape) for _, off, shape in param_slices()]
+
+
+class _RenderRaysFn(torch.autograd.Function):
+    """One autograd node for the whole fused render_rays; inputs are the NeRF parameters so that
+    autograd routes the flat gradients to them."""
+
+    @staticmethod
+    def forward(ctx, cfg, *params):
+        out, saved = _forward_core(save=True, **cfg)
+        ctx.saved = saved
+        ctx.n_params = len(params)
+        keys = ['rgb_map', 'disp_map', 'acc_map', 'raw'] + (['rgb0', 'disp0', 'acc0', 'z_std'] if 'rgb0' in out else [])
+        ctx.keys = keys
+        outs = tuple(out[k] for k in keys)
+        ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if k not in ('rgb_map', 'rgb0')])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        g = dict(zip(ctx.keys, gouts))
+        saved = ctx.saved
+        # fresh buffers: autograd accumulates the returned tensors into the parameters' .grad
+        # (which may alias the nets' flat_grad), so the kernels must not write there directly
+        two = saved['net_f'] is not None and saved['net_f'] is not saved['net_c']
+        out_c = torch.empty_like(saved['net_c'].flat)
+        out_f = torch.empty_like(saved['net_f'].flat) if two else None
+        _backward_core(saved, g.get('rgb_map'), g.get('rgb0'), out_c, out_f)
+        grads = list(_grad_views(out_c)) + (list(_grad_views(out_f)) if two else [])
+        assert len(grads) == ctx.n_params
+        return (None,) + tuple(grads)
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """render.py:149-192 -> (rgb_map, disp_map, acc_map, weights, depth_map).  Forward only."""
+    n, S = z_vals.shape
+    rays11 = torch.zeros(n, 11, device=z_vals.device, dtype=torch.float32)
+    rays11[:, 3:6] = rays_d
+    noise = None
+    if raw_noise_std > 0.:
+        noise = torch.randn(n, S, device=z_vals.device) * raw_noise_std
+        if pytest:
+            noise = _pytest_rand((n, S), z_vals.device) * raw_noise_std
+    return ops.raw2outputs_fwd(raw.contiguous().float(), z_vals.contiguous().float(), rays11, noise, white_bkgd)
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False):
+    """render.py:195-305.  `network_query_fn` is accepted for signature compatibility; positional
+    encoding + MLP run fused inside the HIP kernels, so `network_fn`/`network_fine` must be
+    fastnerf NeRF modules (anything else raises -- there is no fallback path)."""
+    net_c = getattr(network_fn, 'module', network_fn)
+    net_f = getattr(network_fine, 'module', network_fine) if network_fine is not None else None
+    if not isinstance(net_c, NeRF) or (net_f is not None and not isinstance(net_f, NeRF)):
+        raise TypeError('render_rays needs fastnerf NeRF modules (the HIP path has no generic fallback)')
+    if ray_batch.shape[-1] != 11:
+        raise NotImplementedError('the HIP renderer implements use_viewdirs=True ray batches [N,11]')
+    ops.require_gpu(ray_batch)
+    rays11 = ray_batch.contiguous().float()
+    n = rays11.shape[0]
+    dev = rays11.device
+    t_rand = u = noise0 = noise1 = None
+    if perturb > 0. and pytest:
+        t_rand = _pytest_rand((n, N_samples), dev)
+        if N_importance > 0:
+            u = _pytest_rand((n, N_importance), dev)
+    if raw_noise_std > 0.:
+        if pytest:
+            noise0 = _pytest_rand((n, N_samples), dev) * raw_noise_std
+            noise1 = _pytest_rand((n, N_samples + N_importance), dev) * raw_noise_std
+        else:
+            noise0 = torch.randn(n, N_samples, device=dev) * raw_noise_std
+            noise1 = torch.randn(n, N_samples + N_importance, device=dev) * raw_noise_std
+    cfg = dict(rays11=rays11, net_c=net_c, net_f=net_f, N_samples=N_samples, N_importance=N_importance,
+               lindisp=lindisp, perturb=perturb, white_bkgd=white_bkgd, t_rand=t_rand, u=u, noise0=noise0,
+               noise1=noise1)
+    params = list(net_c.parameters()) + (list(net_f.parameters()) if (net_f is not None and net_f is not net_c) else [])
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        outs = _RenderRaysFn.apply(cfg, *params)
+        keys = ['rgb_map', 'disp_map', 'acc_map', 'raw'] + (['rgb0', 'disp0', 'acc0', 'z_std'] if N_importance > 0 else [])
+        out = dict(zip(keys, outs))
+    else:
+        out, _ = _forward_core(save=False, **cfg)
+    ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
+    if retraw:
+        ret['raw'] = out['raw']
+    if N_importance > 0:
+        ret['rgb0'], ret['disp0'], ret['acc0'], ret['z_std'] = out['rgb0'], out['disp0'], out['acc0'], out['z_std']
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """render.py:12-24."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """render.py:26-91 -> [rgb_map, disp_map, acc_map, extras]."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+    if not use_viewdirs:
+        raise NotImplementedError('the HIP renderer implements use_viewdirs=True (all nerf-ours configs)')
+    ops.require_gpu(rays_o, rays_d)
+    view_o, view_d = rays_o, rays_d
+    if c2w_staticcam is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+    sh = rays_d.shape
+    if c2w_staticcam is None:
+        rays11 = ops.pack_rays(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=float(K[0][0]))
+    else:
+        # viewdirs come from the moving camera, origins/directions from the static one (render.py:59-66)
+        rays11 = ops.pack_rays(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=float(K[0][0]))
+        rays11[:, 8:11] = ops.pack_rays(view_o, view_d, near, far)[:, 8:11]
+    all_ret = batchify_rays(rays11, chunk, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """render.py:94-146 without the LPIPS dependency (external, optional in the reference env):
+    renders every pose, reports PSNR when ground truth is given, writes PNGs when imageio exists."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    rgbs, disps, psnrs = [], [], []
+    with torch.no_grad():
+        for i, c2w in enumerate(render_poses):
+            rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=torch.as_tensor(c2w)[:3, :4], **render_kwargs)
+            rgbs.append(rgb.cpu().numpy())
+            disps.append(disp.cpu().numpy())
+            if gt_imgs is not None and render_factor == 0:
+                gt = gt_imgs[i].cpu().numpy() if torch.is_tensor(gt_imgs[i]) else np.asarray(gt_imgs[i])
+                psnrs.append(-10. * np.log10(np.mean(np.square(rgbs[-1] - gt))))
+            if savedir is not None:
+                try:
+                    import imageio
+                    imageio.imwrite(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
+                except ImportError:
+                    np.save(os.path.join(savedir, '{:03d}.npy'.format(i)), to8b(rgbs[-1]))
+    if psnrs and savedir is not None:
+        with open(os.path.join(savedir, 'results.txt'), 'w') as f:
+            f.write('mean PSNR: {}\n'.format(np.mean(psnrs)))
+    render_path.last_psnrs = psnrs
+    return np.stack(rgbs, 0), np.stack(disps, 0)

@@ -1,0 +1,279 @@
+"""Training driver surface -- mirror of nerf-ours/run_nerf.py for the hot path.
+
+create_nerf (run_nerf.py:67-153) returns the same 6-tuple and the same render_kwargs keys;
+batchify / run_network (:40-64) keep their signatures.  `Trainer` is the fused,
+autograd-free optimisation step (render + 2xMSE + backward + all-reduce + Adam + LR decay,
+run_nerf.py:479-508) that the benchmark and `train()` use; the autograd-compatible route
+(`render(...)`, `loss.backward()`, `optimizer.step()`) stays available through render.py.
+Dataset readers / CLI parsing are out of scope; `train()` takes
+in-memory images + poses.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops, parallel
+from .model import NeRF
+from .render import _backward_core, _forward_core, render, render_path  # noqa: F401
+from .run_nerf_helpers import get_embedder, img2mse, mse2psnr
+from .tree import QuadTreeManager
+
+
+def batchify(fn, chunk):
+    """run_nerf.py:40-47."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64):
+    """run_nerf.py:50-64: PE + MLP on explicit points [N,S,3] with per-ray viewdirs [N,3].
+    Runs the fused HIP forward by expressing every point as a ray with o=pt, d=0."""
+    net = getattr(fn, 'module', fn)
+    if not isinstance(net, NeRF):
+        raise TypeError('run_network needs a fastnerf NeRF module')
+    ops.require_gpu(inputs, viewdirs)
+    sh = inputs.shape
+    pts = inputs.reshape(-1, 3).float()
+    P = pts.shape[0]
+    rays11 = torch.zeros(P, 11, device=pts.device, dtype=torch.float32)
+    rays11[:, 0:3] = pts
+    rays11[:, 8:11] = viewdirs[:, None].expand(sh).reshape(-1, 3)
+    z = torch.zeros(P, 1, device=pts.device, dtype=torch.float32)
+    raw = ops.mlp_fwd(rays11, z, net.flat, net.packed()[0])
+    return raw.reshape(list(sh[:-1]) + [4])
+
+
+class _Args:
+    """Defaults of argument_parser.py:4-123 for the flags the hot path reads."""
+    netdepth = 8; netwidth = 256; netdepth_fine = 8; netwidth_fine = 256
+    N_rand = 32 * 32 * 4; lrate = 5e-4; lrate_decay = 250; chunk = 1024 * 32; netchunk = 1024 * 64
+    no_batching = True; no_reload = False; ft_path = None
+    N_samples = 64; N_importance = 0; perturb = 1.; use_viewdirs = True; i_embed = 0
+    multires = 10; multires_views = 4; raw_noise_std = 0.
+    dataset_type = 'blender'; white_bkgd = False; no_ndc = False; lindisp = False
+    n_epoch = 12; init_level = 3; rays_downscale = 1; subdivide_every = 1; subdivide_thres = 0.015
+    randSamp_perc = 0.5; basedir = './logs'; expname = 'fastnerf'
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def make_args(**kw):
+    return _Args(**kw)
+
+
+def create_nerf(args, device='cuda'):
+    """run_nerf.py:67-153 -> (render_kwargs_train, render_kwargs_test, start_epoch, start_iter,
+    grad_vars, optimizer).  Both nets live in ONE flat parameter / gradient buffer (coarse first,
+    as in `grad_vars`), which is what the fused Trainer and the RCCL all-reduce operate on."""
+    if not args.use_viewdirs or args.multires != 10 or args.multires_views != 4 or args.i_embed != 0:
+        raise NotImplementedError('HIP path implements use_viewdirs with multires=10, multires_views=4')
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    two = args.N_importance > 0
+    n_nets = 2 if two else 1
+    dev = torch.device(device)
+    flat_all = torch.empty(n_nets * ops.NET_PARAMS, device=dev, dtype=torch.float32)
+    grad_all = torch.zeros(n_nets * ops.NET_PARAMS, device=dev, dtype=torch.float32)
+    N = ops.NET_PARAMS
+    output_ch = 5 if two else 4
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=[4],
+                 input_ch_views=input_ch_views, use_viewdirs=True, device=dev, flat=flat_all[:N], flat_grad=grad_all[:N])
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if two:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=[4], input_ch_views=input_ch_views, use_viewdirs=True, device=dev,
+                          flat=flat_all[N:], flat_grad=grad_all[N:])
+        grad_vars += list(model_fine.parameters())
+    network_query_fn = lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn,
+                                                                        embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                                                                        netchunk=args.netchunk)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start_epoch, start_iter = 0, 0
+    # checkpoints: same file layout as run_nerf.py:109-127 / 532-539
+    ckpts = []
+    if args.ft_path is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(args.basedir, args.expname)
+        if os.path.isdir(d):
+            ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f]
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt = torch.load(ckpts[-1], map_location=dev, weights_only=False)
+        start_epoch, start_iter = ckpt['global_epoch'], ckpt['global_iter']
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        model.load_state_dict(ckpt['network_fn_state_dict'])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
+        'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
+        'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    create_nerf.flat_all, create_nerf.grad_all = flat_all, grad_all
+    model._flat_all, model._grad_all = flat_all, grad_all
+    return render_kwargs_train, render_kwargs_test, start_epoch, start_iter, grad_vars, optimizer
+
+
+class Trainer:
+    """Fused optimisation step over rays sharded across ranks (one process per GPU).
+
+    step(): render (perturbed, hierarchical) -> loss = mse(fine) + mse(coarse) -> analytic backward
+    -> RCCL all-reduce(SUM) of the flat gradient (grads are pre-scaled by n_local/N_global, so the
+    sum is the gradient of the global-batch mean) -> Adam over both nets in one launch -> LR decay
+    with the reference's pre-increment rule (run_nerf.py:498-508)."""
+
+    def __init__(self, render_kwargs_train, H, W, K, near, far, lrate=5e-4, lrate_decay=250, decay=True,
+                 beta1=0.9, beta2=0.999, eps=1e-8):
+        kw = render_kwargs_train
+        self.net_c = kw['network_fn']
+        self.net_f = kw['network_fine']
+        self.N_samples, self.N_importance = kw['N_samples'], kw['N_importance']
+        self.perturb, self.white_bkgd = kw['perturb'], kw['white_bkgd']
+        self.raw_noise_std = kw.get('raw_noise_std', 0.)
+        self.ndc, self.lindisp = kw.get('ndc', True), kw.get('lindisp', False)
+        self.H, self.W, self.K, self.near, self.far = H, W, K, near, far
+        self.flat = self.net_c._flat_all
+        self.grad = self.net_c._grad_all
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.lrate, self.lrate_decay, self.decay = lrate, lrate_decay, decay
+        self.lr = lrate
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self.adam_t = 0
+        self.global_iter = 0
+        self.world = parallel.world_size()
+        self.repack()
+
+    def repack(self):
+        self.pc = self.net_c.packed(refresh=True)
+        self.pf = self.net_f.packed(refresh=True) if self.net_f is not None else None
+
+    def forward_backward(self, rays_o, rays_d, target, leaf_tag=None, table=None, max_leaves=0, t_rand=None, u=None,
+                         n_global=None):
+        n = rays_o.shape[0]
+        dev = rays_o.device
+        rays11 = ops.pack_rays(rays_o, rays_d, self.near, self.far, ndc=self.ndc, H=self.H, W=self.W,
+                               focal=float(self.K[0][0]))
+        noise0 = noise1 = None
+        if self.raw_noise_std > 0.:
+            noise0 = torch.randn(n, self.N_samples, device=dev) * self.raw_noise_std
+            noise1 = torch.randn(n, self.N_samples + self.N_importance, device=dev) * self.raw_noise_std
+        out, saved = _forward_core(rays11, self.net_c, self.net_f, self.N_samples, self.N_importance, self.lindisp,
+                                   self.perturb, self.white_bkgd, t_rand, u, noise0, noise1, save=True,
+                                   packed_c=self.pc, packed_f=self.pf)
+        scale = 1.0 if n_global is None else float(n) / float(n_global)
+        loss2, g, g0 = ops.mse_leafmax(out['rgb_map'], out.get('rgb0'), target, grad_scale=scale, leaf_tag=leaf_tag,
+                                       max_leaves=max_leaves, table=table)
+        _backward_core(saved, g, g0)
+        return loss2, out
+
+    def step(self, rays_o, rays_d, target, leaf_tag=None, table=None, max_leaves=0, t_rand=None, u=None,
+             n_global=None, decay=None):
+        loss2, out = self.forward_backward(rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global)
+        if self.world > 1:
+            parallel.all_reduce_sum(self.grad)
+        self.adam_t += 1
+        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.adam_t, self.beta1, self.beta2, self.eps)
+        self.repack()
+        if (self.decay if decay is None else decay):
+            self.lr = self.lrate * (0.1 ** (self.global_iter / (self.lrate_decay * 1000)))
+            self.global_iter += 1
+        return loss2, out
+
+    def state_dict(self):
+        return {'m': self.m, 'v': self.v, 'adam_t': self.adam_t, 'global_iter': self.global_iter, 'lr': self.lr}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd['m']); self.v.copy_(sd['v'])
+        self.adam_t, self.global_iter, self.lr = sd['adam_t'], sd['global_iter'], sd['lr']
+
+
+def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=print, max_iters_per_epoch=None,
+          compat_rng=False):
+    """Epoch loop of run_nerf.py:train() (:337-546) on in-memory data: center-crop warm-up, per-epoch
+    quadtree ray generation, fused steps with the on-device leaf-loss table, tree adjustment every
+    `subdivide_every` epochs, checkpoints in the reference's file format.  images [n,H,W,3] (CPU or
+    GPU tensor), poses [n,3,4]."""
+    dev = torch.device(device)
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    kw_train, kw_test, start_epoch, global_iter, grad_vars, optimizer = create_nerf(args, device=dev)
+    trainer = Trainer(kw_train, H, W, K, near, far, lrate=args.lrate, lrate_decay=args.lrate_decay)
+    trainer.global_iter = global_iter
+    images = torch.as_tensor(images, dtype=torch.float32)
+    poses = torch.as_tensor(poses, dtype=torch.float32)[:, :3, :4]
+    mgr = QuadTreeManager(H, W, K, images, poses, mseThres=0.0, max_depth=args.init_level, device=dev)
+    N_rand = args.N_rand
+    rank, world = parallel.rank(), parallel.world_size()
+    history = []
+
+    def run_batches(rays_o, rays_d, tgt, tags, decay, table, max_leaves):
+        n_total = rays_o.shape[0]
+        it = 0
+        for b0 in range(0, n_total, N_rand):
+            b1 = min(b0 + N_rand, n_total)
+            sl = slice(b0 + rank, b1, world) if world > 1 else slice(b0, b1)
+            loss2, _ = trainer.step(rays_o[sl], rays_d[sl], tgt[sl], leaf_tag=None if tags is None else tags[sl],
+                                    table=table, max_leaves=max_leaves, n_global=(b1 - b0) if world > 1 else None,
+                                    decay=decay)
+            it += 1
+            if max_iters_per_epoch is not None and it >= max_iters_per_epoch:
+                break
+        return loss2, it
+
+    if start_epoch == 0:
+        # center-crop warm-up (run_nerf.py:367-423): one coordinate set shared by all images, no LR decay
+        dH, dW = H // 4, W // 4
+        rows = torch.arange(H // 2 - dH, H // 2 + dH)
+        cols = torch.arange(W // 2 - dW, W // 2 + dW)
+        coords = torch.stack(torch.meshgrid(rows, cols, indexing='ij'), -1).reshape(-1, 2)
+        randNum = min(int(N_rand * 500 / mgr.n_images), coords.shape[0])
+        sel = coords[np.random.choice(coords.shape[0], size=[randNum], replace=False)]
+        pix = torch.cat([torch.cat([torch.full((randNum, 1), i, dtype=torch.int64), sel], 1)
+                         for i in range(mgr.n_images)], 0)
+        ro, rd, tgt = mgr.gather(pix)
+        loss2, it = run_batches(ro, rd, tgt, None, False, None, 0)
+        log('warm-up: {} iters, fine/coarse mse {}'.format(it, loss2.tolist()))
+
+    for epoch_id in range(start_epoch + 1, args.n_epoch + 1):
+        t0 = time.time()
+        last = epoch_id == args.n_epoch
+        if last:
+            mgr.epoch_size = mgr.n_images * mgr.h * mgr.w
+        ro, rd, tgt = mgr.gen_rays_v3_multiThread(down_scale=1, prob=False, randSamp_proc=args.randSamp_perc,
+                                                  last_epoch=last, compat_rng=compat_rng)
+        tags = mgr.result_leaf_tag
+        max_leaves = mgr.max_leaves()
+        table = torch.zeros(mgr.n_images * max_leaves, device=dev, dtype=torch.int32)
+        loss2, it = run_batches(ro, rd, tgt, tags, True, table, max_leaves)
+        psnr = mse2psnr(loss2[:1].cpu())
+        history.append((epoch_id, it, float(loss2[0]), float(psnr[0]), time.time() - t0))
+        log('epoch {}: {} iters, fine mse {:.5f} psnr {:.2f}, {:.1f}s'.format(*history[-1]))
+        if args.subdivide_every > 0 and epoch_id % args.subdivide_every == 0 and epoch_id < args.n_epoch - 1:
+            if world > 1:
+                parallel.all_reduce_max_int(table)
+            mgr.adjust_tree_from_table(table.view(mgr.n_images, max_leaves), thres=args.subdivide_thres)
+        if rank == 0 and getattr(args, 'save_ckpt', False):
+            d = os.path.join(args.basedir, args.expname)
+            os.makedirs(d, exist_ok=True)
+            torch.save({'global_epoch': epoch_id, 'global_iter': trainer.global_iter,
+                        'network_fn_state_dict': kw_train['network_fn'].state_dict(),
+                        'network_fine_state_dict': kw_train['network_fine'].state_dict(),
+                        'fused_optimizer_state': trainer.state_dict(),
+                        'tree_leaves': mgr.export_leaves()}, os.path.join(d, '{:03d}.tar'.format(epoch_id)))
+    return kw_train, kw_test, trainer, mgr, history

@@ -1,0 +1,191 @@
+"""Quadtree ray selection -- mirror of nerf-ours/tree.py's QuadTreeManager on a native backend.
+
+The reference keeps a Python object graph per image and scans every ray of the epoch once per leaf
+on the CPU (tree.py:629-652).  Here the trees are DFS leaf arrays in libfastnerf.so (host C++), the
+per-(image, leaf) max |gt-pred| is reduced on the device while training runs
+(fastnerf_mse_leafmax), and rays are generated on the fly from (image,row,col) picks instead of
+gathering from [n,H,W,3] host arrays.  Leaf enumeration, per-leaf ray counts, pixel ranges and the
+split rule are bit-exact with the reference (tests/test_tree_*.py).
+
+API kept: QuadTreeManager(H, W, K, images, poses, mseThres, max_depth) (tree.py:161),
+gen_rays_v3_multiThread (:377-428), adjust_tree_multiThread (:533-557), attributes h, w, n_images,
+images, epoch_size, cur_level, result_leaf_id, childrens, origins, dirs.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+
+class QuadTreeManager:
+    def __init__(self, H, W, K, images, poses, mseThres=0.1, max_depth=5, device='cuda'):
+        if mseThres != 0.0:
+            raise NotImplementedError('variance-gated initial subdivision (mseThres>0) is never used by the '
+                                      'reference driver (run_nerf.py:337 passes 0.0)')
+        self.h, self.w = int(H), int(W)
+        self.K = np.asarray(K, dtype=np.float64)
+        self.n_images = int(poses.shape[0])
+        self.device = torch.device(device)
+        self.images = torch.as_tensor(images, dtype=torch.float32)
+        self.poses = torch.as_tensor(poses, dtype=torch.float32)[:, :3, :4].contiguous()
+        self.epoch_size = self.n_images * self.h * self.w
+        self.cur_level = max_depth
+        self._t = lib().fastnerf_tree_create(self.h, self.w, self.n_images, int(max_depth))
+        if not self._t:
+            raise RuntimeError('fastnerf_tree_create failed')
+        self.result_leaf_id = None   # [N,2] float32 (image, leaf), as the reference stores it
+        self.result_leaf_tag = None  # [N,2] int32 on the device (what the kernels consume)
+        self._dev_images = None
+        self._dev_poses = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_t', None):
+                lib().fastnerf_tree_destroy(self._t)
+                self._t = None
+        except Exception:
+            pass
+
+    # ---- tree state ---------------------------------------------------------------------------
+    def num_leaves(self, i):
+        return check(lib().fastnerf_tree_num_leaves(self._t, i), 'fastnerf_tree_num_leaves')
+
+    def max_leaves(self):
+        return check(lib().fastnerf_tree_max_leaves(self._t), 'fastnerf_tree_max_leaves')
+
+    def min_area(self, i):
+        return float(lib().fastnerf_tree_min_area(self._t, i))
+
+    def leaves(self, i):
+        """[n_leaves,4] float64 (x0,y0,x1,y1) in the reference's get_children() order."""
+        n = self.num_leaves(i)
+        out = np.empty((n, 4), dtype=np.float64)
+        check(lib().fastnerf_tree_get_leaves(self._t, i, out.ctypes.data), 'fastnerf_tree_get_leaves')
+        return out
+
+    @property
+    def childrens(self):
+        return [self.leaves(i) for i in range(self.n_images)]
+
+    def export_leaves(self):
+        return [(self.leaves(i), self.min_area(i)) for i in range(self.n_images)]
+
+    def import_leaves(self, state):
+        for i, (boxes, min_area) in enumerate(state):
+            b = np.ascontiguousarray(boxes, dtype=np.float64)
+            check(lib().fastnerf_tree_set_leaves(self._t, i, b.shape[0], b.ctypes.data, float(min_area)),
+                  'fastnerf_tree_set_leaves')
+
+    def leaf_plan(self, i, ray_num_per_pixel, last_epoch=False):
+        """[n,5] int32: ray count, row_lo, row_hi, col_lo, col_hi (tree.py:578-581,598-599)."""
+        n = 1 if last_epoch else self.num_leaves(i)
+        out = np.empty((n, 5), dtype=np.int32)
+        check(lib().fastnerf_tree_leaf_plan(self._t, i, float(ray_num_per_pixel), int(bool(last_epoch)),
+                                            out.ctypes.data), 'fastnerf_tree_leaf_plan')
+        return out
+
+    # ---- rays ---------------------------------------------------------------------------------
+    def _dev(self):
+        if self._dev_images is None:
+            self._dev_images = self.images.to(self.device)
+            self._dev_poses = self.poses.to(self.device)
+        return self._dev_images, self._dev_poses
+
+    @property
+    def origins(self):
+        return torch.stack([ops.gen_rays(self.h, self.w, self.K, self.poses[i])[0] for i in range(self.n_images)], 0)
+
+    @property
+    def dirs(self):
+        return torch.stack([ops.gen_rays(self.h, self.w, self.K, self.poses[i])[1] for i in range(self.n_images)], 0)
+
+    def gather(self, pix):
+        """pix [N,3] int64/int32 (image,row,col) -> rays_o, rays_d, rgb on the device."""
+        imgs, poses = self._dev()
+        p = pix.to(self.device)
+        ro, rd = ops.gen_rays_pixels(p.int().contiguous(), poses, self.K)
+        rgb = imgs[p[:, 0].long(), p[:, 1].long(), p[:, 2].long()]
+        return ro, rd, rgb.contiguous()
+
+    def gen_pixels(self, down_scale=1, last_epoch=False, compat_rng=True):
+        """Pixel picks + leaf tags of one epoch (host side of tree.py:377-428 / 569-626).
+        Returns pix [N,3] int64 (image,row,col), already shuffled; sets result_leaf_id."""
+        ray_num_per_image = self.epoch_size / self.n_images / down_scale
+        ray_num_per_pixel = ray_num_per_image / self.h / self.w
+        plans = [self.leaf_plan(i, ray_num_per_pixel, last_epoch) for i in range(self.n_images)]
+        if compat_rng:
+            pix, tags = [], []
+            for ti, plan in enumerate(plans):
+                for li in range(plan.shape[0]):
+                    n, r0, r1, c0, c1 = (int(v) for v in plan[li])
+                    xs = torch.randint(r0, r1, (n,))
+                    ys = torch.randint(c0, c1, (n,))
+                    pix.append(torch.stack([torch.full((n,), ti, dtype=torch.int64), xs, ys], 1))
+                    tags.append(torch.tensor([[ti, li]], dtype=torch.float32).repeat([n, 1]))
+            pix = torch.cat(pix, 0)
+            tags = torch.cat(tags, 0)
+            perm = torch.randperm(pix.shape[0])
+            pix, tags = pix[perm], tags[perm]
+            self.result_leaf_id = tags
+            self._tags_i32 = tags.to(torch.int32)
+        else:
+            dev = self.device
+            allp = torch.from_numpy(np.concatenate(plans, 0)).to(dev).long()           # [L,5]
+            img = torch.from_numpy(np.concatenate([np.full(p.shape[0], i) for i, p in enumerate(plans)])).to(dev)
+            leaf = torch.from_numpy(np.concatenate([np.arange(p.shape[0]) for p in plans])).to(dev)
+            idx = torch.repeat_interleave(torch.arange(allp.shape[0], device=dev), allp[:, 0])
+            n = idx.shape[0]
+            lo_r, hi_r, lo_c, hi_c = allp[idx, 1], allp[idx, 2], allp[idx, 3], allp[idx, 4]
+            xs = lo_r + torch.floor(torch.rand(n, device=dev, dtype=torch.float64) * (hi_r - lo_r)).long()
+            ys = lo_c + torch.floor(torch.rand(n, device=dev, dtype=torch.float64) * (hi_c - lo_c)).long()
+            pix = torch.stack([img[idx], xs, ys], 1)
+            tags = torch.stack([img[idx], leaf[idx]], 1)
+            perm = torch.randperm(n, device=dev)
+            pix, tags = pix[perm], tags[perm]
+            self._tags_i32 = tags.to(torch.int32)
+            self.result_leaf_id = self._tags_i32.float()
+        self.result_pix = pix
+        return pix
+
+    def gen_rays_v3_multiThread(self, down_scale=16, prob=True, randSamp_proc=0.95, debug=False, last_epoch=False,
+                                compat_rng=True):
+        """tree.py:377-428.  compat_rng=True draws pixels with torch's global CPU generator in the
+        reference's exact call order (per image, per leaf: randint rows, randint cols; then one
+        randperm), so a seeded run selects identical pixels; compat_rng=False draws the same
+        distribution vectorised on the device.  Returns (origins, dirs, rgb) on the device."""
+        if prob:
+            raise NotImplementedError('prob=True (variance-weighted picks) is not on the nerf-ours path '
+                                      '(run_nerf.py:440,452 pass prob=False); see SURVEY 8(f) f2')
+        pix = self.gen_pixels(down_scale, last_epoch, compat_rng)
+        self.result_leaf_tag = self._tags_i32.to(self.device).contiguous()
+        return self.gather(pix)
+
+    # ---- adjustment -----------------------------------------------------------------------------
+    def adjust_tree_from_table(self, table, thres=0.001):
+        """Split rule of tree.py:629-652 driven by the reduced per-(image, leaf) table.
+        table: [n_images, max_leaves] float32 values or their int32 bit patterns."""
+        t = table
+        if t.dtype in (torch.int32, torch.uint32):
+            t = t.view(torch.float32)
+        t = t.detach().float().cpu().contiguous()
+        assert t.shape[0] == self.n_images
+        tot = check(lib().fastnerf_tree_adjust(self._t, t.data_ptr(), int(t.shape[1]), float(thres)),
+                    'fastnerf_tree_adjust')
+        self.cur_level += 1
+        return int(tot)
+
+    def adjust_tree_multiThread(self, rgb_gt, rgb_pred, thres=0.001, debug=False):
+        """tree.py:533-557 with the reference's arguments: the epoch's gt / predicted colours in
+        the order of self.result_leaf_id.  The segmented max runs on the device."""
+        dev = self.device
+        gt = torch.as_tensor(rgb_gt, dtype=torch.float32).to(dev).contiguous()
+        pred = torch.as_tensor(rgb_pred, dtype=torch.float32).to(dev).contiguous()
+        ml = self.max_leaves()
+        table = torch.zeros(self.n_images * ml, device=dev, dtype=torch.int32)
+        ops.mse_leafmax(pred, None, gt, want_grads=False, leaf_tag=self.result_leaf_tag, max_leaves=ml, table=table)
+        tot = self.adjust_tree_from_table(table.view(self.n_images, ml), thres)
+        print('After sudivide, there are {} child nodes'.format(tot))
+        return tot

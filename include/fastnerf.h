@@ -1,0 +1,144 @@
+/* fastnerf.h -- C ABI of the MI355X-native NeRF training inner loop.
+ *
+ * Drop-in boundary for the renderer / quadtree path of
+ * wen-yuan-zhang/Fast-Learning-NeRF (nerf-ours).  The reference has no FFI: the
+ * path sits behind Python functions.  Every entry point below names the
+ * reference function (file:line, relative to nerf-ours/) whose work it
+ * replaces; INTEGRATION.md shows the ctypes stub a maintainer adds to call it.
+ *
+ * Conventions
+ *   - all `float*`/`int*` arguments are DEVICE pointers unless the name ends in
+ *     `_host`; buffers are owned by the caller (PyTorch's allocator); nothing
+ *     is retained past return.
+ *   - fp32, contiguous row-major.  rays are [N,11] = o(3) d(3) near far
+ *     viewdir(3) (render.py:74-80).
+ *   - every call enqueues work on `stream` (a hipStream_t) and returns without
+ *     synchronising.
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 HIP error);
+ *     fastnerf_last_error() returns a thread-local message.  Never aborts.
+ */
+#ifndef FASTNERF_H
+#define FASTNERF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fn_stream_t; /* hipStream_t */
+
+int fastnerf_version(void);
+const char* fastnerf_last_error(void);
+/* device properties used by bench/tests: returns CU count (or <0) */
+int fastnerf_device_cus(void);
+
+/* ---- rays ------------------------------------------------------------- */
+/* get_rays (run_nerf_helpers.py:68-78): all H*W pixels of one camera.
+ * c2w_host: 12 floats (3x4 row-major).  rays_o/rays_d: [H,W,3]. */
+int fastnerf_gen_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host,
+                      float* rays_o, float* rays_d, fn_stream_t stream);
+/* rays for selected pixels of many cameras (tree.py:617-619 gather restated as
+ * on-the-fly generation): pix [n,3] int32 (image, row, col); poses [n_img,3,4]. */
+int fastnerf_gen_rays_pixels(int64_t n, const int32_t* pix, const float* poses, float fx, float fy, float cx,
+                             float cy, float* rays_o, float* rays_d, fn_stream_t stream);
+/* ndc_rays (run_nerf_helpers.py:91-108), in -> out [n,3] each. */
+int fastnerf_ndc_rays(int64_t n, int H, int W, double focal, float near, const float* rays_o, const float* rays_d,
+                      float* out_o, float* out_d, fn_stream_t stream);
+/* render() prologue (render.py:59-80): viewdirs = d/|d| (before ndc), optional
+ * ndc warp, pack [n,11]. */
+int fastnerf_pack_rays(int64_t n, const float* rays_o, const float* rays_d, float near, float far, int ndc, int H,
+                       int W, double focal, float* rays11, fn_stream_t stream);
+/* coarse depths (render.py:244-266).  t_rand: [n,S] injected U[0,1) jitter, or
+ * NULL; when NULL and perturb!=0 a Philox stream keyed by (seed, ray, sample)
+ * is used.  z: [n,S]. */
+int fastnerf_sample_coarse(int64_t n, int S, const float* rays11, int lindisp, int perturb, const float* t_rand,
+                           uint64_t seed, float* z, fn_stream_t stream);
+/* Embedder.embed (run_nerf_helpers.py:15-63): x [n,3] -> out [n, 3+6L]. */
+int fastnerf_posenc(int64_t n, int L, const float* x, float* out, fn_stream_t stream);
+
+/* ---- MLP (model.py:8-63, D=8 W=256 skip@4 use_viewdirs) ---------------- */
+#define FASTNERF_NET_PARAMS 595844      /* floats per net, model.parameters() order */
+#define FASTNERF_PACKED_FWD 593920      /* floats: fragment-ordered forward weights  */
+#define FASTNERF_PACKED_BWD 557056      /* floats: fragment-ordered transposed weights */
+/* per-point saved activations (floats): pe64 + 8*h256 + feat256 + vpe32 + hv128 */
+#define FASTNERF_ACT_FLOATS 2528
+/* per-point pre-activation gradients (floats): 8*dY256 + dfeat256 + dYv128 */
+#define FASTNERF_DACT_FLOATS 2432
+
+/* re-layout of one net's flat parameters into the MFMA fragment order used by
+ * mlp_fwd (packed_fwd) and mlp_bwd_dx (packed_bwd). */
+int fastnerf_mlp_pack(const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream);
+/* run_network (run_nerf.py:50-64) + NeRF.forward: points are generated on the
+ * fly from rays11 [n,11] and z [n,S] (pts = o + d*z, render.py:268), encoded
+ * (L=10 / L=4) and pushed through the MLP.  raw: [n,S,4] (rgb logits, sigma).
+ * act: NULL (inference) or a buffer of n*S*FASTNERF_ACT_FLOATS floats that
+ * receives the activations backward needs. */
+int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const float* z, const float* params,
+                     const float* packed_fwd, float* raw, float* act, fn_stream_t stream);
+/* backward of the above w.r.t. the parameters: draw [n,S,4] -> grads (same
+ * layout as params, OVERWRITTEN).  dact: scratch n*S*FASTNERF_DACT_FLOATS;
+ * partial: scratch of fastnerf_mlp_bwd_partial_floats() floats. */
+int64_t fastnerf_mlp_bwd_partial_floats(void);
+int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float* act, const float* params,
+                     const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
+
+/* ---- compositing / hierarchical sampling ------------------------------ */
+/* raw2outputs (render.py:149-192).  noise: [n,S] scaled sigma noise or NULL.
+ * outputs: rgb_map [n,3], disp [n], acc [n], weights [n,S], depth [n]. */
+int fastnerf_raw2outputs_fwd(int64_t n, int S, const float* raw, const float* z, const float* rays11,
+                             const float* noise, int white_bkgd, float* rgb_map, float* disp, float* acc,
+                             float* weights, float* depth, fn_stream_t stream);
+/* d(rgb_map)/d(raw): g_rgb [n,3] -> draw [n,S,4]. */
+int fastnerf_raw2outputs_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays11,
+                             const float* noise, int white_bkgd, const float* g_rgb, float* draw,
+                             fn_stream_t stream);
+/* sample_pdf (run_nerf_helpers.py:112-155) on bins = mid(z), weights[1:-1],
+ * followed by sort(cat[z, z_samples]) (render.py:279-283).  u: [n,Ni] injected
+ * uniforms or NULL; det!=0 -> linspace(0,1,Ni); else Philox(seed).
+ * z_out: [n,S+Ni] sorted; z_samples: [n,Ni] (may be NULL); z_std [n] (may be NULL). */
+int fastnerf_sample_pdf_merge(int64_t n, int S, int Ni, const float* z, const float* weights, int det,
+                              const float* u, uint64_t seed, float* z_out, float* z_samples, float* z_std,
+                              fn_stream_t stream);
+
+/* stand-alone sample_pdf(bins [n,M], weights [n,M-1]) -> samples [n,Ni]
+ * (run_nerf_helpers.py:112-155 as called by third parties, e.g. tests). */
+int fastnerf_sample_pdf(int64_t n, int M, int Ni, const float* bins, const float* weights, int det, const float* u,
+                        uint64_t seed, float* samples, fn_stream_t stream);
+
+/* ---- loss / optimiser / quadtree loss map ------------------------------ */
+/* img2mse (run_nerf_helpers.py:9) for fine and coarse maps + their gradients
+ * + the per-(image, leaf) max |gt - pred| table (tree.py:538, 632-642).
+ * loss2: 2 floats (fine mse, coarse mse), accumulated from zero by the call.
+ * leaf_tag: [n,2] int32 (image, leaf) or NULL; table: [n_img*max_leaves] uint32
+ * bit patterns of non-negative floats (atomicMax), or NULL.
+ * grad_scale multiplies 2/(3n) (data-parallel: n_local/n_global). */
+int fastnerf_mse_leafmax(int64_t n, const float* rgb, const float* rgb0, const float* target, float grad_scale,
+                         float* g_rgb, float* g_rgb0, float* loss2, const int32_t* leaf_tag, int max_leaves,
+                         uint32_t* table, fn_stream_t stream);
+/* torch.optim.Adam step (run_nerf.py:99,494) over a flat buffer. */
+int fastnerf_adam_step(int64_t n, float* params, const float* grads, float* m, float* v, double lr, double beta1,
+                       double beta2, double eps, int step, fn_stream_t stream);
+
+/* ---- host quadtree (tree.py), no device work --------------------------- */
+typedef struct fn_tree fn_tree; /* opaque: per-image DFS leaf lists */
+fn_tree* fastnerf_tree_create(int H, int W, int n_images, int max_depth);
+void fastnerf_tree_destroy(fn_tree* t);
+int fastnerf_tree_num_leaves(const fn_tree* t, int image);
+int fastnerf_tree_max_leaves(const fn_tree* t);
+double fastnerf_tree_min_area(const fn_tree* t, int image);
+/* leaves of one image in DFS enumeration order: out [n_leaves,4] doubles x0,y0,x1,y1 */
+int fastnerf_tree_get_leaves(const fn_tree* t, int image, double* out_host);
+int fastnerf_tree_set_leaves(fn_tree* t, int image, int n_leaves, const double* boxes_host, double min_area);
+/* per-leaf ray count + integer pixel ranges (tree.py:578-581, 598-599):
+ * out [n_leaves,5] int32: count, row_lo, row_hi, col_lo, col_hi (hi exclusive).
+ * last_epoch!=0 evaluates a fresh depth-1 tree (tree.py:390-400). */
+int fastnerf_tree_leaf_plan(const fn_tree* t, int image, double ray_num_per_pixel, int last_epoch,
+                            int32_t* out_host);
+/* adjust_tree_multiThread (tree.py:533-557, 629-652) driven by the reduced
+ * table: table_host [n_images, max_leaves] floats (max |gt-pred| per leaf,
+ * negative = leaf had no ray).  Returns total leaves after the split, <0 on error. */
+int64_t fastnerf_tree_adjust(fn_tree* t, const float* table_host, int max_leaves, double thres);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

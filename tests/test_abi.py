@@ -1,0 +1,37 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/fastnerf.h
+declares (no compute calls here)."""
+import os
+import re
+
+import fastnerf
+from fastnerf import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'fastnerf.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(fastnerf_\w+)\s*\(', src)))
+
+
+def test_header_symbols_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    lib = _lib.lib()
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in fastnerf.h but not exported'
+        assert s in _lib.SIGNATURES, f'{s} has no ctypes signature'
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.fastnerf_version() == 1
+
+
+def test_missing_gpu_fails_loudly():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError):
+        fastnerf.ops.posenc(torch.zeros(4, 3), 10)
+    with pytest.raises((RuntimeError, AssertionError)):
+        fastnerf.model.NeRF()
