@@ -244,31 +244,41 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(int64_t n, int S,
       __builtin_amdgcn_wave_barrier();
       for (int k = lane; k < M; k += WAVE) bins[k] = fmul(0.5f, fadd(zs[k + 1], zs[k]));
     }
-    // pdf / cdf : lane owns weights k in [lane*CW, lane*CW+CW)
+    // pdf / cdf : lane owns weights k in [lane*CW, lane*CW+CW).  The sum and the running cdf are
+    // accumulated in fp64 and rounded once per entry (torch's CPU cumsum accumulates float in
+    // double as well), which keeps the cdf within 1 ulp of the reference's.
     float wl[MAXC];
-    float csum = 0.f;
+    double csum = 0.0;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
       const int k = lane * CW + j;
       wl[j] = (j < CW && k < NW) ? fadd(bins_mode ? weights[r * NW + k] : weights[r * S + k + 1], 1e-5f) : 0.f;
-      csum += wl[j];
+      csum += (double)wl[j];
     }
-    const float tot = wave_sum(csum);
-    float run = 0.f;
+    double totd = csum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) totd += __shfl_xor(totd, o, WAVE);
+    const float tot = (float)totd;
+    double run = 0.0;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
       wl[j] = wl[j] / tot;
-      run += wl[j];
+      run += (double)wl[j];
     }
-    const float incl = wave_scan_add(run, lane);
-    float base = incl - run;  // exclusive prefix of this lane's chunk
+    double incl = run;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const double t = __shfl_up(incl, o, WAVE);
+      if (lane >= o) incl += t;
+    }
+    double base = incl - run;  // exclusive prefix of this lane's chunk
     if (lane == 0) cdf[0] = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
       const int k = lane * CW + j;
       if (j < CW && k < NW) {
-        base += wl[j];
-        cdf[k + 1] = base;
+        base += (double)wl[j];
+        cdf[k + 1] = (float)base;
       }
     }
     __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,217 @@
+"""End-to-end parity: render() vs the reference's outputs (G7), one full training step vs the
+reference (G8) through both the fused Trainer and the autograd-compatible route, and
+size-independent properties at the BASELINE size (4096 rays, 64+128 samples)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_RGB = 1e-4   # north_star: rendered RGB within 1e-4 of the reference on identical inputs
+
+
+@pytest.fixture(scope='module')
+def fn():
+    import fastnerf
+    return fastnerf
+
+
+def build(fn, golden_dir, **over):
+    kw = dict(N_importance=128, N_samples=64, perturb=1.0, white_bkgd=True, use_viewdirs=True, no_reload=True,
+              lrate=5e-4, lrate_decay=500)
+    kw.update(over)
+    args = fn.run_nerf.make_args(**kw)
+    ktr, kte, _, _, grad_vars, optim = fn.run_nerf.create_nerf(args)
+    g = np.load(os.path.join(golden_dir, 'g7_weights.npz'))
+    ktr['network_fn'].load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('c.')})
+    if ktr['network_fine'] is not None:
+        ktr['network_fine'].load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('f.')})
+    return ktr, kte, grad_vars, optim
+
+
+def test_render_g7(fn, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g7_render.npz'))
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    ktr, kte, _, _ = build(fn, golden_dir)
+    rays = torch.stack([torch.from_numpy(g['ro']), torch.from_numpy(g['rd'])], 0).cuda()
+    with torch.no_grad():
+        for tag, kw, extra in (('a', kte, {}), ('b', ktr, {'pytest': True}),
+                               ('c', kte, {'N_samples': 32, 'N_importance': 0})):
+            kk = dict(kw); kk.update(extra)
+            rgb, disp, acc, ex = fn.render.render(800, 800, K, chunk=32768, rays=rays, retraw=True, near=2.0, far=6.0, **kk)
+            res = {'rgb': rgb, 'disp': disp, 'acc': acc}; res.update(ex)
+            for k in ('rgb', 'acc', 'rgb0', 'acc0', 'raw', 'z_std', 'disp', 'disp0'):
+                if f'{tag}.{k}' not in g.files:
+                    continue
+                ref = g[f'{tag}.{k}']
+                err = np.abs(res[k].cpu().numpy() - ref)
+                # rgb/acc: the north_star bound.  raw at the FINE samples is input-sensitivity bound:
+                # a 1e-6 shift of a sample position moves sin(2^9 x) by 5e-4, so per-sample logits
+                # agree to ~1e-3 while the composited colour agrees to ~1e-5.
+                tol = TOL_RGB if k in ('rgb', 'rgb0', 'acc', 'acc0') else 5e-2 * max(1e-3, np.abs(ref).max())
+                assert err.max() < tol, (tag, k, err.max())
+    assert set(ex.keys()) == {'raw'} and rgb.shape == (64, 3)
+
+
+def test_train_step_g8_fused(fn, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    ktr, _, _, _ = build(fn, golden_dir)
+    tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+    ro, rd, tgt = (torch.from_numpy(g[k]).cuda() for k in ('ro', 'rd', 'target'))
+    loss2, out = tr.forward_backward(ro, rd, tgt, t_rand=torch.from_numpy(g['t_rand']).cuda(),
+                                     u=torch.from_numpy(g['u']).cuda())
+    assert abs(float(loss2[0]) - float(g['loss'])) < 1e-5 and abs(float(loss2[1]) - float(g['loss0'])) < 1e-5
+    assert np.abs(out['rgb_map'].cpu().numpy() - g['rgb']).max() < TOL_RGB
+    assert np.abs(out['rgb0'].cpu().numpy() - g['rgb0']).max() < TOL_RGB
+    grad = tr.grad.cpu()
+    names = ['c.' + n for n, _ in O.nerf_param_shapes()] + ['f.' + n for n, _ in O.nerf_param_shapes()]
+    shapes = [s for _, s in O.nerf_param_shapes()] * 2
+    # (1) vs the reference's gradients.  Bound: 3e-2 of each tensor's max -- dominated by the
+    # sensitivity of the fine pass to 1-ulp differences in the inverse-CDF sample positions (the
+    # same kernels agree to 5e-5 with the oracle evaluated at identical positions, see (2)).
+    off = 0
+    for n, shp in zip(names, shapes):
+        ref = g['grad.' + n]
+        k = ref.size
+        got = grad[off:off + k].view(shp).numpy()
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(got - ref).max() < 3e-2 * scale, (n, np.abs(got - ref).max(), scale)
+        off += k
+    # (2) kernel exactness: oracle autograd evaluated at the device's own sample positions.  The
+    # remaining differences are single ReLU-mask flips (a pre-activation within 1e-7 of zero takes
+    # the other branch: ~1 per 1e7 activations, tools/dbg2.py), each worth one sample's contribution
+    # to a small-gradient tensor -> bound 1e-2 of the tensor max, and 1e-3 in relative L2.
+    wts = np.load(os.path.join(golden_dir, 'g7_weights.npz'))
+    rb = O.make_ray_batch(ro.cpu(), rd.cpu(), 2.0, 6.0)
+    for pre, zkey, lo in (('c.', 'z0', 0), ('f.', 'z_vals', fn.ops.NET_PARAMS)):
+        sd = {k[2:]: torch.from_numpy(wts[k]).clone().requires_grad_(True) for k in wts.files if k.startswith(pre)}
+        zz = out[zkey].cpu()
+        pts = rb[:, None, 0:3] + rb[:, None, 3:6] * zz[..., None]
+        raw = O.run_network(sd, pts, rb[:, 8:11])
+        rgbm = O.raw2outputs(raw, zz, rb[:, 3:6], None, True)[0]
+        gr = torch.autograd.grad(O.img2mse(rgbm, tgt.cpu()), list(sd.values()))
+        off = lo
+        for (n, shp), gg in zip(O.nerf_param_shapes(), gr):
+            k = gg.numel()
+            got = grad[off:off + k].view(shp)
+            assert (got - gg).abs().max() < 1e-2 * max(gg.abs().max().item(), 1e-7), (pre + n)
+            assert (got - gg).norm() < 2e-3 * gg.norm() + 1e-12, (pre + n, float((got - gg).norm() / gg.norm()))
+            off += k
+    # optimiser: feed the REFERENCE's gradients to the Adam kernel -> the reference's post-step
+    # weights (identical inputs => tight bound; on the device's own gradients Adam's first step
+    # lr*g/(|g|+1e-8) amplifies 1e-9 absolute noise on |g|~1e-8 entries to O(lr))
+    gold = torch.cat([torch.from_numpy(g['grad.' + n]).reshape(-1) for n in names]).cuda()
+    before = tr.flat.clone()
+    tr.grad.copy_(gold)
+    fn.ops.adam_step(tr.flat, tr.grad, tr.m, tr.v, 5e-4, 1)
+    flat = tr.flat.cpu()
+    sl = {}
+    off = 0
+    for n, shp in zip(names, shapes):
+        k = int(np.prod(shp)); sl[n] = flat[off:off + k].view(shp).numpy(); off += k
+    n_checked = 0
+    for key in g.files:
+        if key.startswith('post.'):
+            assert np.abs(sl[key[5:]] - g[key]).max() < 2e-7, key
+            n_checked += 1
+    assert n_checked > 20
+    # full fused step (own gradients): bounded update, LR rule with the pre-increment iteration
+    tr.flat.copy_(before); tr.m.zero_(); tr.v.zero_(); tr.repack()
+    loss2, _ = tr.step(ro, rd, tgt, t_rand=torch.from_numpy(g['t_rand']).cuda(), u=torch.from_numpy(g['u']).cuda())
+    upd = (tr.flat - before).abs()
+    assert float(upd.max()) <= 5e-4 * 1.001 and float((upd > 4.9e-4).float().mean()) > 0.5
+    assert abs(tr.lr - float(g['new_lr'])) < 1e-12 and tr.global_iter == 1 and tr.adam_t == 1
+
+
+def test_train_step_g8_autograd_route(fn, golden_dir):
+    """The reference's own loop shape: render(...); loss.backward(); optimizer.step()."""
+    g = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    ktr, _, grad_vars, optim = build(fn, golden_dir)
+    H = fn.run_nerf_helpers
+    rays = torch.stack([torch.from_numpy(g['ro']), torch.from_numpy(g['rd'])], 0).cuda()
+    tgt = torch.from_numpy(g['target']).cuda()
+    rgb, disp, acc, extras = fn.render.render(800, 800, K, chunk=32768, rays=rays, retraw=True, near=2.0, far=6.0,
+                                              pytest=True, **ktr)
+    optim.zero_grad()
+    img_loss = H.img2mse(rgb, tgt)
+    loss = img_loss + H.img2mse(extras['rgb0'], tgt)
+    psnr = H.mse2psnr(img_loss.cpu())
+    loss.backward()
+    assert abs(float(img_loss) - float(g['loss'])) < 1e-5 and abs(float(psnr[0]) - float(g['psnr'])) < 1e-3
+    names = ['c.' + n for n, _ in O.nerf_param_shapes()] + ['f.' + n for n, _ in O.nerf_param_shapes()]
+    for n, p in zip(names, grad_vars):
+        ref = g['grad.' + n]
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(p.grad.cpu().numpy() - ref).max() < 3e-2 * scale, n
+    optim.step()
+    w = dict(zip(names, grad_vars))
+    bad = tot = 0
+    for key in g.files:
+        if key.startswith('post.'):
+            d = np.abs(w[key[5:]].detach().cpu().numpy() - g[key]); bad += int((d > 5e-6).sum()); tot += d.size
+    # torch.optim.Adam on the device's own gradients: entries with |g| ~ 1e-8 are noise-amplified
+    # (see the fused test); the bulk must agree
+    assert bad <= tot * 0.15, (bad, tot)
+
+
+def test_properties_at_baseline_size(fn, golden_dir):
+    """4096 rays, 64+128 samples (BASELINE config 2): properties that need no oracle run."""
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    ktr, kte, _, _ = build(fn, golden_dir)
+    c2w = O.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    ro, rd = fn.run_nerf_helpers.get_rays(800, 800, K, c2w)
+    gen = torch.Generator().manual_seed(0)
+    sel = torch.randint(0, 640000, (4096,), generator=gen).cuda()
+    ro, rd = ro.reshape(-1, 3)[sel].contiguous(), rd.reshape(-1, 3)[sel].contiguous()
+    rays = torch.stack([ro, rd], 0)
+    with torch.no_grad():
+        rgb, disp, acc, ex = fn.render.render(800, 800, K, chunk=32768, rays=rays, retraw=True, near=2.0, far=6.0, **kte)
+        # chunking does not change results (render.py:31-32) -- identical kernels per ray
+        rgb2, _, acc2, _ = fn.render.render(800, 800, K, chunk=1000, rays=rays, near=2.0, far=6.0, **kte)
+    assert torch.equal(rgb, rgb2) and torch.equal(acc, acc2)
+    assert torch.isfinite(rgb).all() and (acc >= 0).all() and (acc <= 1 + 1e-5).all()
+    assert ex['raw'].shape == (4096, 192, 4)
+    # permutation equivariance over rays
+    perm = torch.randperm(4096, generator=gen).cuda()
+    with torch.no_grad():
+        rgb3, _, _, _ = fn.render.render(800, 800, K, chunk=32768, rays=rays[:, perm], near=2.0, far=6.0, **kte)
+    assert torch.equal(rgb3, rgb[perm])
+    # a training step at full size decreases the loss on a fixed batch
+    tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0)
+    tgt = torch.rand(4096, 3, generator=gen).cuda()
+    first = None
+    for it in range(6):
+        loss2, _ = tr.step(ro, rd, tgt)
+        first = first if first is not None else float(loss2[0])
+    assert torch.isfinite(loss2).all() and float(loss2[0]) < first
+
+
+def test_quadtree_device_table(fn, golden_dir):
+    """Leaf tags + on-device table from a real step == oracle's segmented max; tree adjusts."""
+    from oracle import tree_oracle as TO
+    K = np.array([[50.0, 0, 32.0], [0, 50.0, 32.0], [0, 0, 1]])
+    gen = torch.Generator().manual_seed(4)
+    imgs = torch.rand(2, 64, 64, 3, generator=gen)
+    poses = torch.stack([O.pose_spherical(40.0 * i, -30.0, 4.0)[:3, :4] for i in range(2)], 0)
+    mgr = fn.tree.QuadTreeManager(64, 64, K, imgs, poses, 0.0, 2)
+    torch.manual_seed(100)
+    ro, rd, rgb = mgr.gen_rays_v3_multiThread(down_scale=1, prob=False)
+    omgr = TO.Manager(64, 64, 2, 2)
+    torch.manual_seed(100)
+    pix = omgr.gen_pixels()
+    assert torch.equal(mgr.result_leaf_id, omgr.result_leaf_id) and torch.equal(mgr.result_pix, pix)
+    o_ref, d_ref = O.get_rays(64, 64, K, poses[0])
+    sel = (pix[:, 0] == 0)
+    assert (rd.cpu()[sel] - d_ref[pix[sel, 1], pix[sel, 2]]).abs().max() < 1e-6
+    assert torch.equal(rgb.cpu(), imgs[pix[:, 0], pix[:, 1], pix[:, 2]])
+    pred = (rgb + (torch.rand(rgb.shape, generator=gen).cuda() - 0.5) * 0.1).clamp(0, 1)
+    mgr.adjust_tree_multiThread(rgb, pred, thres=0.04)
+    omgr.adjust(rgb.cpu(), pred.cpu(), 0.04)
+    for i in range(2):
+        assert np.array_equal(mgr.leaves(i), omgr.leaf_array(i))
