@@ -130,7 +130,7 @@ def main():
         rays11 = ops.pack_rays(ro, rd, 2.0, 6.0)
         z = torch.sort(torch.rand(N_RAYS, N_SAMPLES + N_IMPORTANCE, device=dev) * 4 + 2, -1).values
         P = N_RAYS * (N_SAMPLES + N_IMPORTANCE)
-        act = torch.empty(P * ops.ACT_FLOATS, device=dev)
+        act = torch.empty(ops.act_floats(P), device=dev)
         raw = torch.empty(N_RAYS, N_SAMPLES + N_IMPORTANCE, 4, device=dev)
         for _ in range(2):
             ops.mlp_fwd(rays11, z, tr.net_f.flat, tr.pf[0], act=act, raw=raw)

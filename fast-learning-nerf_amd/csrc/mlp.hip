@@ -208,12 +208,17 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
 // C layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// forward epilogue: + bias, optional ReLU, write H (LDS) and optionally the saved activation
+// forward epilogue: + bias, optional ReLU, write H (LDS) and optionally the saved activation.
+// When `mask_out` is given (training, ReLU layers) the sign pattern of every accumulator register
+// is recorded as one 64-bit ballot; ballot i = (nt*2+mt)*16 + r is kept by lane i and the wave
+// stores its 64 words with one coalesced 512-byte access.  mlp_bwd_dx (same wave->tile mapping)
+// reads the words back instead of re-reading 1 KB/point/layer of activations.
 template <int NT, bool RELU>
 __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const float* __restrict__ bias, float* Hs,
                                              int wm, int wn, int lane, float* __restrict__ save, int ldsave,
-                                             int valid) {
+                                             int valid, unsigned long long* __restrict__ mask_out = nullptr) {
   asm volatile("" : "+v"(lane));
+  unsigned long long mymask = 0ull;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (wn * NT + nt) * 32 + (lane & 31);
@@ -224,12 +229,21 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
       for (int r = 0; r < 16; ++r) {
         const int m = wm * 64 + mt * 32 + crow(r, lane);
         float v = acc[mt][nt][r] + bv;
+        if (RELU && NT == 2) {
+          if (mask_out != nullptr) {
+            const unsigned long long bm = __ballot(v > 0.f);
+            if (lane == (nt * 2 + mt) * 16 + r) mymask = bm;
+          }
+        }
         if (RELU) v = fmaxf(v, 0.f);
         Hs[hidx(m, n)] = v;
         if (save != nullptr && m < valid) save[(unsigned)(m * ldsave + n)] = v;
       }
       __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
     }
+  }
+  if (RELU && NT == 2) {
+    if (mask_out != nullptr) mask_out[lane] = mymask;
   }
 }
 
@@ -254,6 +268,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
+    unsigned long long* maskw =
+        SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(P)) + tile * MASK_WORDS_PER_TILE : nullptr;
     // ---- phase A: points + positional encoding -> Es ---------------------------------
     const int pm = tid >> 2, pq = tid & 3;
     int64_t pp = p0 + pm;
@@ -290,7 +306,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     // ---- L0 : pe64 -> 256 -------------------------------------------------------------
     zero_acc<2>(acc);
     gemm_seg<2, true>(acc, Es, 0, 8, pk + PF_OFF(0) / 4, 8, 0, wn * 2, wm, lane);
-    epilogue_fwd<2, true>(acc, params + L_B(0), Hs, wm, wn, lane, SAVE ? act + act_h(P, 0) + p0 * 256 : nullptr, 256, valid);
+    epilogue_fwd<2, true>(acc, params + L_B(0), Hs, wm, wn, lane, SAVE ? act + act_h(P, 0) + p0 * 256 : nullptr, 256, valid,
+                          SAVE ? maskw + (0 * 8 + wave) * 64 : nullptr);
     __syncthreads();
     // ---- L1..L7 -----------------------------------------------------------------------
 #pragma unroll 1
@@ -318,7 +335,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       }
       __syncthreads();  // every wave has finished reading H
       epilogue_fwd<2, true>(acc, params + boff, Hs, wm, wn, lane,
-                            SAVE ? act + act_h(P, l) + p0 * 256 : nullptr, 256, valid);
+                            SAVE ? act + act_h(P, l) + p0 * 256 : nullptr, 256, valid,
+                            SAVE ? maskw + (l * 8 + wave) * 64 : nullptr);
       __syncthreads();
     }
     // ---- alpha head (VALU) + view-direction encoding -> Es ---------------------------
@@ -432,13 +450,20 @@ extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const flo
 // =========================================================================================
 // backward: dX chain
 // =========================================================================================
-// epilogue: optional rank-1 term (dalpha x wa), ReLU mask from the saved activation, write H
+// epilogue: optional rank-1 term (dalpha x wa), ReLU mask from the forward's ballot words, write H
 // and the pre-activation gradient buffer.
 template <bool MASK, bool RANK1>
 __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs, const float* Es_dalpha,
-                                            const float* __restrict__ wa, const float* __restrict__ hmask,
+                                            const float* __restrict__ wa,
+                                            const unsigned long long* __restrict__ maskw,
                                             float* __restrict__ dsave, int wm, int wn, int lane, int valid) {
   asm volatile("" : "+v"(lane));
+  unsigned mlo = 0u, mhi = 0u;
+  if (MASK) {
+    const unsigned long long w = maskw[lane];
+    mlo = (unsigned)w;
+    mhi = (unsigned)(w >> 32);
+  }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = (wn * 2 + nt) * 32 + (lane & 31);
@@ -450,13 +475,15 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
         const int m = wm * 64 + mt * 32 + crow(r, lane);
         float v = acc[mt][nt][r];
         if (RANK1) v = fmaf(Es_dalpha[m], wan, v);
-        const bool ok = m < valid;
         if (MASK) {
-          const float h = ok ? hmask[(unsigned)(m * 256 + n)] : 0.f;
-          v = (h > 0.f) ? v : 0.f;
+          const int idx = (nt * 2 + mt) * 16 + r;
+          const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)mlo, idx);
+          const unsigned bhi = (unsigned)__builtin_amdgcn_readlane((int)mhi, idx);
+          const unsigned word = (lane & 32) ? bhi : blo;
+          v = ((word >> (lane & 31)) & 1u) ? v : 0.f;
         }
         Hs[hidx(m, n)] = v;
-        if (ok) dsave[(unsigned)(m * 256 + n)] = v;
+        if (m < valid) dsave[(unsigned)(m * 256 + n)] = v;
       }
       __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
     }
@@ -479,6 +506,8 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
+    const unsigned long long* maskw =
+        reinterpret_cast<const unsigned long long*>(act + act_mask(P)) + tile * MASK_WORDS_PER_TILE;
     // ---- phase A: dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] --------------------------
     {
       const int pm = tid >> 2, pq = tid & 3;
@@ -518,7 +547,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     zero_acc<2>(acc);
     gemm_seg<2, false>(acc, Hs, 0, 32, pk + PB_OFF(1) / 4, 32, 0, wn * 2, wm, lane);
     __syncthreads();
-    epilogue_dx<true, true>(acc, Hs, Es, params + A_W, act + act_h(P, 7) + p0 * 256,
+    epilogue_dx<true, true>(acc, Hs, Es, params + A_W, maskw + (7 * 8 + wave) * 64,
                             dact + dact_y(P, 7) + p0 * 256, wm, wn, lane, valid);
     __syncthreads();
     // ---- dY_{l-1} = (dY_l . W_l) * [h_{l-1} > 0],  l = 7..1 ------------------------------
@@ -533,7 +562,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       zero_acc<2>(acc);
       gemm_seg<2, false>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane);
       __syncthreads();
-      epilogue_dx<true, false>(acc, Hs, Es, nullptr, act + act_h(P, l - 1) + p0 * 256,
+      epilogue_dx<true, false>(acc, Hs, Es, nullptr, maskw + ((l - 1) * 8 + wave) * 64,
                                dact + dact_y(P, l - 1) + p0 * 256, wm, wn, lane, valid);
       __syncthreads();
     }
@@ -677,7 +706,22 @@ __global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float*
   int64_t pb = pa + per;
   if (pb > P) pb = P;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, sb = 0.f;
-  for (int64_t p = pa; p < pb; ++p) {
+  int64_t p = pa;
+  for (; p + 4 <= pb; p += 4) {  // 4 independent points in flight
+    float4 d[4];
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      d[i] = *reinterpret_cast<const float4*>(draw + (p + i) * 4);
+      h[i] = hv[(p + i) * 128 + k];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0 = fmaf(d[i].x, h[i], s0); s1 = fmaf(d[i].y, h[i], s1); s2 = fmaf(d[i].z, h[i], s2);
+      if (k < 4) sb += (k == 0) ? d[i].x : (k == 1) ? d[i].y : (k == 2) ? d[i].z : d[i].w;
+    }
+  }
+  for (; p < pb; ++p) {
     const float4 d = *reinterpret_cast<const float4*>(draw + p * 4);
     const float h = hv[p * 128 + k];
     s0 = fmaf(d.x, h, s0); s1 = fmaf(d.y, h, s1); s2 = fmaf(d.z, h, s2);
@@ -688,27 +732,65 @@ __global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float*
   if (k < 4) o[384 + k] = sb;
 }
 
-// dst[r*ld + c] = sum_wg partial[wg][r][c]
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, int nwg,
-                                                               int64_t wg_stride, int rows, int cols,
-                                                               float* __restrict__ dst, int ld, int valid_cols) {
-  const int64_t total = (int64_t)rows * cols;
+// ---- one launch reduces every job's per-workgroup partials into the flat gradient ------------
+struct RedSeg {
+  int64_t src;        // offset into the partial buffer
+  int64_t wg_stride;  // floats between consecutive workgroups' partials
+  int64_t dst;        // offset into the flat gradient
+  int nwg, rows, cols, ld, valid_cols;
+};
+#define MAX_SEGS 32
+struct RedTable {
+  RedSeg s[MAX_SEGS];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) reduce_all_kernel(RedTable tab, const float* __restrict__ partial,
+                                                          float* __restrict__ grads) {
+  const RedSeg sg = tab.s[blockIdx.y];
+  const int64_t total = (int64_t)sg.rows * sg.cols;
+  const float* src = partial + sg.src;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(e / cols), c = (int)(e % cols);
-    if (c >= valid_cols) continue;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += partial[(int64_t)w * wg_stride + e];
-    dst[(int64_t)r * ld + c] = s;
+    const int r = (int)(e / sg.cols), c = (int)(e % sg.cols);
+    if (c >= sg.valid_cols) continue;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 8 <= sg.nwg; w += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
+    }
+    for (; w < sg.nwg; ++w) a[0] += src[(int64_t)w * sg.wg_stride + e];
+    grads[sg.dst + (int64_t)r * sg.ld + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
 }
 
-static const int64_t DW_PARTIAL_W = 256 * 256;  // floats per workgroup, largest job
+// dW jobs of one net: id, NO, KI, bias?, rank1?
+struct DwJobDesc { int NO, KI, bias, rank1; };
+static const DwJobDesc DW_JOBS[12] = {
+    {256, 64, 1, 0},                                                                      // 0: L0 (pe)
+    {256, 256, 1, 0}, {256, 256, 1, 0}, {256, 256, 1, 0}, {256, 256, 1, 0},               // 1..4: L1..L4
+    {256, 256, 1, 0}, {256, 256, 1, 0}, {256, 256, 1, 0},                                 // 5..7: L5(h)..L7
+    {256, 64, 0, 0},                                                                      // 8: L5 (pe)
+    {256, 256, 1, 1},                                                                     // 9: feature (+alpha row)
+    {128, 256, 1, 0},                                                                     // 10: views (feat part)
+    {128, 32, 0, 0},                                                                      // 11: views (vpe part)
+};
+#define HEAD_MAX_WG 1024
+static int64_t dw_job_floats(int j) {
+  return (int64_t)DW_JOBS[j].NO * DW_JOBS[j].KI + (DW_JOBS[j].bias ? DW_JOBS[j].NO : 0) +
+         (DW_JOBS[j].rank1 ? DW_JOBS[j].KI : 0);
+}
+static int64_t dw_job_base(int j, int ncu) {
+  int64_t o = 0;
+  for (int i = 0; i < j; ++i) o += dw_job_floats(i) * ncu;
+  return o;
+}
 extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
-  return (int64_t)num_cus() * (DW_PARTIAL_W + 256 + 256);
+  return dw_job_base(12, num_cus()) + (int64_t)HEAD_MAX_WG * 388;
 }
 
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
-static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* partial,
+static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* base,
                      int nwg, hipStream_t st) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
@@ -719,23 +801,19 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
     FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  float* pw = partial;
-  float* pb = partial + (int64_t)nwg * DW_PARTIAL_W;
-  float* pr = pb + (int64_t)nwg * 256;
+  float* pw = base;
+  float* pb = base + (int64_t)nwg * NO * KI;
+  float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr);
   FN_LAUNCH_CHECK();
   return 0;
 }
 
-static int launch_reduce(const float* partial, int nwg, int rows, int cols, float* dst, int ld, int valid_cols,
-                         hipStream_t st) {
-  const int64_t total = (int64_t)rows * cols;
-  int g = (int)((total + 255) / 256);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(g), dim3(256), 0, st, partial, nwg, total, rows, cols, dst, ld,
-                     valid_cols);
-  FN_LAUNCH_CHECK();
-  return 0;
+static void add_seg(RedTable& T, int64_t src, int64_t wg_stride, int nwg, int rows, int cols, int64_t dst, int ld,
+                    int valid_cols) {
+  RedSeg& s = T.s[T.n++];
+  s.src = src; s.wg_stride = wg_stride; s.nwg = nwg; s.rows = rows; s.cols = cols; s.dst = dst; s.ld = ld;
+  s.valid_cols = valid_cols;
 }
 
 extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float* act, const float* params,
@@ -746,7 +824,8 @@ extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float
   hipStream_t st = fn::S(stream);
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
-  int grid = num_cus();
+  const int ncu = num_cus();
+  int grid = ncu;
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {
@@ -757,57 +836,56 @@ extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float
   hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact);
   FN_LAUNCH_CHECK();
 
-  // ---- dW jobs -----------------------------------------------------------------------------
+  // ---- dW jobs: every job writes per-workgroup partials into its own region ------------------
   const int64_t nt32 = (P + DW_MT - 1) / DW_MT;
-  int nwg = num_cus();
+  int nwg = ncu;
   if (nt32 < nwg) nwg = (int)nt32;
-  const float* pw = partial;
-  const float* pb = partial + (int64_t)nwg * DW_PARTIAL_W;
-  const float* pr = pb + (int64_t)nwg * 256;
+  RedTable T;
+  T.n = 0;
   int rc;
   const float* a_pe = act + act_pe(P);
-  // L0: dY0^T pe64  -> [256][63] (+bias)
-  if ((rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, partial, nwg, st))) return rc;
-  if ((rc = launch_reduce(pw, nwg, 256, 64, grads + L_W(0), 63, 63, st))) return rc;
-  if ((rc = launch_reduce(pb, nwg, 1, 256, grads + L_B(0), 256, 256, st))) return rc;
-  // L1..L7 (h part) (+bias); L5 also has the pe part
+  auto region = [&](int j) { return partial + dw_job_base(j, ncu); };
+  auto segs = [&](int j, int64_t dstW, int ld, int validc, int64_t dstB, int64_t dstR) {
+    const DwJobDesc& d = DW_JOBS[j];
+    const int64_t b = dw_job_base(j, ncu);
+    add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc);
+    int64_t o = b + (int64_t)nwg * d.NO * d.KI;
+    if (d.bias) { add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO); o += (int64_t)nwg * d.NO; }
+    if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
+  };
+  // L0
+  if ((rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st))) return rc;
+  segs(0, L_W(0), 63, 63, L_B(0), 0);
+  // L1..L7 (h part)
+  const int64_t woffs[8] = {L_W(0), L_W(1), L_W(2), L_W(3), L_W(4), L_W(5), L_W(6), L_W(7)};
+  const int64_t boffs[8] = {L_B(0), L_B(1), L_B(2), L_B(3), L_B(4), L_B(5), L_B(6), L_B(7)};
   for (int l = 1; l < 8; ++l) {
-    const int64_t woff = (l == 1) ? L_W(1) : (l == 2) ? L_W(2) : (l == 3) ? L_W(3) : (l == 4) ? L_W(4)
-                        : (l == 5) ? L_W(5) : (l == 6) ? L_W(6) : L_W(7);
-    const int64_t boff = (l == 1) ? L_B(1) : (l == 2) ? L_B(2) : (l == 3) ? L_B(3) : (l == 4) ? L_B(4)
-                        : (l == 5) ? L_B(5) : (l == 6) ? L_B(6) : L_B(7);
-    const int ld = (l == 5) ? 319 : 256;
-    const int c0 = (l == 5) ? 63 : 0;
-    if ((rc = launch_dw<2, 2, 4, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, l - 1), 256, nullptr, partial, nwg, st))) return rc;
-    if ((rc = launch_reduce(pw, nwg, 256, 256, grads + woff + c0, ld, 256, st))) return rc;
-    if ((rc = launch_reduce(pb, nwg, 1, 256, grads + boff, 256, 256, st))) return rc;
-    if (l == 5) {
-      if ((rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, partial, nwg, st))) return rc;
-      if ((rc = launch_reduce(pw, nwg, 256, 64, grads + L_W(5), 319, 63, st))) return rc;
-    }
+    if ((rc = launch_dw<2, 2, 4, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, l - 1), 256, nullptr, region(l), nwg, st))) return rc;
+    segs(l, woffs[l] + (l == 5 ? 63 : 0), l == 5 ? 319 : 256, 256, boffs[l], 0);
   }
-  // feature layer: dfeat^T h7 (+bias) and the alpha head as a rank-1 row: dWa = sum dalpha * h7
-  if ((rc = launch_dw<2, 2, 4, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, 7), 256, draw, partial, nwg, st))) return rc;
-  if ((rc = launch_reduce(pw, nwg, 256, 256, grads + F_W, 256, 256, st))) return rc;
-  if ((rc = launch_reduce(pb, nwg, 1, 256, grads + F_B, 256, 256, st))) return rc;
-  if ((rc = launch_reduce(pr, nwg, 1, 256, grads + A_W, 256, 256, st))) return rc;
-  // view layer: dYv^T [feat | vpe] (+bias)
-  if ((rc = launch_dw<2, 2, 2, 4, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P), 256, nullptr, partial, nwg, st))) return rc;
-  if ((rc = launch_reduce(pw, nwg, 128, 256, grads + V_W, 283, 256, st))) return rc;
-  if ((rc = launch_reduce(pb, nwg, 1, 128, grads + V_B, 128, 128, st))) return rc;
-  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P), 32, nullptr, partial, nwg, st))) return rc;
-  if ((rc = launch_reduce(pw, nwg, 128, 32, grads + V_W + 256, 283, 27, st))) return rc;
+  // L5 pe part
+  if ((rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st))) return rc;
+  segs(8, L_W(5), 319, 63, 0, 0);
+  // feature layer (+bias) with the alpha head as a rank-1 row
+  if ((rc = launch_dw<2, 2, 4, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, 7), 256, draw, region(9), nwg, st))) return rc;
+  segs(9, F_W, 256, 256, F_B, A_W);
+  // view layer
+  if ((rc = launch_dw<2, 2, 2, 4, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P), 256, nullptr, region(10), nwg, st))) return rc;
+  segs(10, V_W, 283, 256, V_B, 0);
+  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P), 32, nullptr, region(11), nwg, st))) return rc;
+  segs(11, V_W + 256, 283, 27, 0, 0);
   // rgb head + alpha bias
   {
-    int hg = num_cus();
-    if (P < hg) hg = (int)P;
-    hipLaunchKernelGGL(head_grads_kernel, dim3(hg), dim3(128), 0, st, P, draw, act + act_hv(P), partial);
+    int64_t hg64 = (P + 255) / 256;
+    int hg = (int)(hg64 > HEAD_MAX_WG ? HEAD_MAX_WG : hg64);
+    if (hg < 1) hg = 1;
+    const int64_t hb = dw_job_base(12, ncu);
+    hipLaunchKernelGGL(head_grads_kernel, dim3(hg), dim3(128), 0, st, P, draw, act + act_hv(P), partial + hb);
     FN_LAUNCH_CHECK();
-    if ((rc = launch_reduce(partial, hg, 1, 388, grads + R_W, 388, 387, st))) return rc;  // dWr (384) + dbr (3)
-    // dba is element 387 of each partial row -> grads[A_B]
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partial + 387, hg, (int64_t)388, 1, 1,
-                       grads + A_B, 1, 1);
-    FN_LAUNCH_CHECK();
+    add_seg(T, hb, 388, hg, 1, 388, R_W, 388, 387);   // dWr (384) + dbr (3), contiguous in the flat layout
+    add_seg(T, hb + 387, 388, hg, 1, 1, A_B, 1, 1);   // dba
   }
+  hipLaunchKernelGGL(reduce_all_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
+  FN_LAUNCH_CHECK();
   return 0;
 }

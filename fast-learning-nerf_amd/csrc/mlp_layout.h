@@ -50,13 +50,17 @@ constexpr int64_t PB_TOTAL = PB_OFF(9);
 static_assert(PB_TOTAL == 557056, "packed bwd size");
 
 // ---- saved activations, SoA over P points ----
-constexpr int ACT_FLOATS = 64 + 8 * 256 + 256 + 32 + 128;
-static_assert(ACT_FLOATS == 2528, "act floats");
+constexpr int ACT_DENSE = 64 + 8 * 256 + 256 + 32 + 128;   // floats per point
+static_assert(ACT_DENSE == 2528, "act floats");
+// + per 128-point tile: 8 layers x 8 waves x 64 ballot words (uint64) of the ReLU masks
+constexpr int MASK_WORDS_PER_TILE = 8 * 8 * 64;
+constexpr int ACT_FLOATS = ACT_DENSE + 64;                   // 2592 per point (+ one tile of slack)
 inline __host__ __device__ int64_t act_pe(int64_t P) { return 0; }
 inline __host__ __device__ int64_t act_h(int64_t P, int l) { return P * 64 + (int64_t)l * P * 256; }
 inline __host__ __device__ int64_t act_feat(int64_t P) { return P * (64 + 2048); }
 inline __host__ __device__ int64_t act_vpe(int64_t P) { return P * (64 + 2048 + 256); }
 inline __host__ __device__ int64_t act_hv(int64_t P) { return P * (64 + 2048 + 256 + 32); }
+inline __host__ __device__ int64_t act_mask(int64_t P) { return P * ACT_DENSE; }  // uint64 words from here
 // ---- pre-activation gradients, SoA ----
 constexpr int DACT_FLOATS = 8 * 256 + 256 + 128;
 inline __host__ __device__ int64_t dact_y(int64_t P, int l) { return (int64_t)l * P * 256; }

@@ -11,8 +11,14 @@ from ._lib import check, lib, ptr, require_gpu, stream
 NET_PARAMS = 595844
 PACKED_FWD = 593920
 PACKED_BWD = 557056
-ACT_FLOATS = 2528
+ACT_FLOATS = 2592
+ACT_SLACK = 8192
 DACT_FLOATS = 2432
+
+
+def act_floats(P):
+    """Size (floats) of the saved-activation buffer for P points."""
+    return P * ACT_FLOATS + ACT_SLACK
 
 
 def _f32(t):
@@ -100,7 +106,7 @@ def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None):
     if raw is None:
         raw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
     if act is not None:
-        assert act.numel() >= n * S * ACT_FLOATS
+        assert act.numel() >= act_floats(n * S)
     check(lib().fastnerf_mlp_fwd(n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw), ptr(act), stream()),
           'fastnerf_mlp_fwd')
     return raw

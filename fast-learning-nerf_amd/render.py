@@ -60,7 +60,7 @@ def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, pertur
     pc = packed_c if packed_c is not None else net_c.packed()
     z0 = ops.sample_coarse(rays11, N_samples, lindisp=lindisp, perturb=perturb, t_rand=t_rand,
                            seed=_next_seed() if (perturb and t_rand is None) else 0)
-    act0 = torch.empty(n * N_samples * ops.ACT_FLOATS, device=dev, dtype=torch.float32) if save else None
+    act0 = torch.empty(ops.act_floats(n * N_samples), device=dev, dtype=torch.float32) if save else None
     raw0 = ops.mlp_fwd(rays11, z0, net_c.flat, pc[0], act=act0)
     rgb0, disp0, acc0, w0, depth0 = ops.raw2outputs_fwd(raw0, z0, rays11, noise0, white_bkgd)
     out = {}
@@ -72,7 +72,7 @@ def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, pertur
         z1, z_samples, z_std = ops.sample_pdf_merge(z0, w0, N_importance, det=(perturb == 0.), u=u,
                                                     seed=_next_seed() if (perturb and u is None) else 0)
         S1 = N_samples + N_importance
-        act1 = torch.empty(n * S1 * ops.ACT_FLOATS, device=dev, dtype=torch.float32) if save else None
+        act1 = torch.empty(ops.act_floats(n * S1), device=dev, dtype=torch.float32) if save else None
         raw1 = ops.mlp_fwd(rays11, z1, fine.flat, pf[0], act=act1)
         rgb1, disp1, acc1, w1, depth1 = ops.raw2outputs_fwd(raw1, z1, rays11, noise1, white_bkgd)
         out.update(rgb_map=rgb1, disp_map=disp1, acc_map=acc1, raw=raw1, rgb0=rgb0, disp0=disp0, acc0=acc0,

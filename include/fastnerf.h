@@ -59,8 +59,10 @@ int fastnerf_posenc(int64_t n, int L, const float* x, float* out, fn_stream_t st
 #define FASTNERF_NET_PARAMS 595844      /* floats per net, model.parameters() order */
 #define FASTNERF_PACKED_FWD 593920      /* floats: fragment-ordered forward weights  */
 #define FASTNERF_PACKED_BWD 557056      /* floats: fragment-ordered transposed weights */
-/* per-point saved activations (floats): pe64 + 8*h256 + feat256 + vpe32 + hv128 */
-#define FASTNERF_ACT_FLOATS 2528
+/* saved activations: n*S*FASTNERF_ACT_FLOATS + FASTNERF_ACT_SLACK floats
+ * (per point pe64 + 8*h256 + feat256 + vpe32 + hv128 + 64 floats of ReLU ballot masks) */
+#define FASTNERF_ACT_FLOATS 2592
+#define FASTNERF_ACT_SLACK 8192
 /* per-point pre-activation gradients (floats): 8*dY256 + dfeat256 + dYv128 */
 #define FASTNERF_DACT_FLOATS 2432
 
@@ -70,7 +72,7 @@ int fastnerf_mlp_pack(const float* params, float* packed_fwd, float* packed_bwd,
 /* run_network (run_nerf.py:50-64) + NeRF.forward: points are generated on the
  * fly from rays11 [n,11] and z [n,S] (pts = o + d*z, render.py:268), encoded
  * (L=10 / L=4) and pushed through the MLP.  raw: [n,S,4] (rgb logits, sigma).
- * act: NULL (inference) or a buffer of n*S*FASTNERF_ACT_FLOATS floats that
+ * act: NULL (inference) or a buffer of n*S*FASTNERF_ACT_FLOATS + FASTNERF_ACT_SLACK floats that
  * receives the activations backward needs. */
 int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const float* z, const float* params,
                      const float* packed_fwd, float* raw, float* act, fn_stream_t stream);

@@ -70,7 +70,7 @@ def test_mlp_forward_points(fn, weights, P):
     err = (raw.cpu() - ref).abs().max().item()
     assert err < 2e-5, err   # logits are O(0.1..1); fp32 accumulation-order differences only
     # training variant writes the same raw and consistent activations
-    act = torch.empty(P * fn.ops.ACT_FLOATS).cuda()
+    act = torch.empty(fn.ops.act_floats(P)).cuda()
     raw2 = fn.ops.mlp_fwd(rays, torch.zeros(P, 1).cuda(), flat, pf, act=act)[:, 0]
     assert torch.equal(raw, raw2)
     pe = act[:P * 64].view(P, 64).cpu()
@@ -93,7 +93,7 @@ def test_mlp_backward_vs_autograd(fn, weights):
     flat = flat_of(weights).cuda()
     pf, pb = fn.ops.mlp_pack(flat)
     P = n * S
-    act = torch.empty(P * fn.ops.ACT_FLOATS).cuda()
+    act = torch.empty(fn.ops.act_floats(P)).cuda()
     raw = fn.ops.mlp_fwd(rb.cuda(), z.cuda(), flat, pf, act=act)
     assert (raw.cpu() - out.detach()).abs().max() < 2e-5
     dact = torch.empty(P * fn.ops.DACT_FLOATS).cuda()
