@@ -1,0 +1,96 @@
+"""world_size-2 data-parallel logic on CPU (gloo): ray sharding + one all-reduce(SUM) of the
+flat gradient (pre-scaled by n_local/N_global) reproduces the full-batch gradient; the leaf table
+all-reduce(MAX) on float bit patterns reproduces the full table exactly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import fastnerf
+    from fastnerf import parallel
+    from oracle import nerf_oracle as O
+    rk, ws, _ = parallel.init_from_env('cpu')
+    assert (rk, ws) == (rank, world) and parallel.world_size() == world and parallel.rank() == rank
+    gen = torch.Generator().manual_seed(0)          # same data on every rank
+    sdc, sdf = O.init_nerf_params(gen), O.init_nerf_params(gen)
+    N, S, Ni = 12, 8, 8
+    ro = torch.randn(N, 3, generator=gen) * 0.3
+    rd = torch.randn(N, 3, generator=gen)
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0)
+    tgt = torch.rand(N, 3, generator=gen)
+    t_rand, u = torch.rand(N, S, generator=gen), torch.rand(N, Ni, generator=gen)
+    tag = torch.stack([torch.randint(0, 2, (N,), generator=gen), torch.randint(0, 5, (N,), generator=gen)], 1)
+
+    def grads_of(sl, scale):
+        params = list(sdc.values()) + list(sdf.values())
+        for p in params:
+            p.requires_grad_(True)
+        ret = O.render_rays(rb[sl], sdc, sdf, S, Ni, white_bkgd=True, t_rand=t_rand[sl], u=u[sl])
+        loss = (O.img2mse(ret['rgb_map'], tgt[sl]) + O.img2mse(ret['rgb0'], tgt[sl])) * scale
+        g = torch.autograd.grad(loss, params)
+        for p in params:
+            p.requires_grad_(False)
+        return torch.cat([x.reshape(-1) for x in g]), ret['rgb_map'].detach()
+
+    full, rgb_full = grads_of(slice(0, N), 1.0)
+    sl = parallel.shard(N)
+    n_local = len(range(N)[sl])
+    local, rgb_local = grads_of(sl, n_local / N)     # what mse_leafmax's grad_scale does on the device
+    parallel.all_reduce_sum(local)
+    err = (local - full).abs().max().item() / full.abs().max().item()
+    # leaf table: per-rank segmented max -> all-reduce(MAX) on the int32 bit patterns
+    tab = O.leaf_loss_max(tgt[sl], rgb_local, tag[sl], 2, 5).view(-1).view(torch.int32).clone()
+    parallel.all_reduce_max_int(tab)
+    tab_full = O.leaf_loss_max(tgt, rgb_full, tag, 2, 5).view(-1)
+    same = torch.equal(tab.view(torch.float32), tab_full)
+    parallel.barrier()
+    q.put((rank, err, bool(same), n_local))
+    torch.distributed.destroy_process_group()
+
+
+def test_world2_gradient_allreduce_and_table_max():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    for rank, err, same, n_local in res:
+        assert err < 1e-5, (rank, err)      # summation order only
+        assert same, rank
+        assert n_local == 6
+
+
+def test_shard_covers_batch():
+    sys.path.insert(0, ROOT)
+    from fastnerf import parallel
+    for n in (1, 7, 4096, 4097):
+        for world in (1, 2, 8):
+            idx = sorted(i for r in range(world) for i in range(n)[parallel.shard(n, r, world)])
+            assert idx == list(range(n))
