@@ -26,13 +26,14 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    extra = os.environ.get('FASTNERF_CFLAGS', '').split()   # tuning experiments, e.g. -DTM=128
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, 'build', src + '.o')
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -19,14 +19,19 @@
 // every 8-wide k-step) which is legal because a dot product does not care about summation
 // order beyond rounding; parity with the reference is therefore "fp32 rounding class"
 // (<=1e-6 relative), not bitwise.
+#include <stdlib.h>
 #include "common.h"
 #include "mlp_layout.h"
 
 using namespace fnl;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define TM 128         // points per tile (fwd / dx)
-#define NTHR 512       // threads per workgroup (fwd / dx)
+#ifndef TM
+#define TM 64          // points per tile (fwd / dx)
+#endif
+#define NTHR (TM * 4)  // threads per workgroup: (TM/64) x 4 waves, each a 64x64 output block
+#define NWAVES (NTHR / 64)
+#define WG_PER_CU (128 / TM)  // two 80 KiB workgroups share a CU's 160 KiB LDS when TM == 64
 #define LDS_H (TM * 256)
 #define LDS_E (TM * 64)
 #define LDS_BYTES ((LDS_H + LDS_E) * 4)
@@ -139,15 +144,29 @@ extern "C" int fastnerf_mlp_pack(const float* params, float* packed_fwd, float* 
 __device__ __forceinline__ int hidx(int m, int k) { return m * 256 + ((((k >> 2) ^ (m & 15)) << 2) | (k & 3)); }
 __device__ __forceinline__ int eidx(int m, int k) { return m * 64 + ((((k >> 2) ^ (m & 15)) << 2) | (k & 3)); }
 
+// streaming (non-temporal) 16-byte store: saved activations are written once and read much later,
+// they must not displace the 2.4 MB of weights every CU re-reads from its XCD's 4 MB L2
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt(float* p, const float4& v) {
+  f32x4v t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p));
+}
+
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
 // accumulate `nks` k-steps (8 wide) of A (LDS, rows wm*64.., E or H layout, first k-step
 // a_ks0) times packed B (global, this layer's k-steps b_ks0.., KS k-steps per n-tile).
+// Side job (save_dst != nullptr, H layout only, nks == 32): while the MFMAs of this k-loop run, the
+// tile's activations -- which this very loop reads from LDS -- are also streamed to HBM as whole
+// 1 KiB rows (one ds_read_b128 + one global_store_dwordx4 per lane per two k-steps), instead of 64
+// dword stores per wave in the epilogue that produced them.
 template <int NT, bool A_IS_E>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks,
-                                         const float4* __restrict__ Bp, int KS, int b_ks0, int nt0, int wm, int lane) {
+                                         const float4* __restrict__ Bp, int KS, int b_ks0, int nt0, int wm, int lane,
+                                         int dbg = 0, float* __restrict__ save_dst = nullptr, int save_valid = 0,
+                                         int wave = 0) {
   asm volatile("" : "+v"(lane));  // keep per-call address math inside the call (no cross-layer hoisting)
   const int lrow = lane & 31, lhalf = lane >> 5;
   const float* arow[2];
@@ -190,7 +209,21 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __re
   for (int ks = 0; ks < nks; ks += 2) {  // nks is even for every layer
     load_ab(a1, b1, ks + 1);
     mfma16(a0, b0);
-    if (ks + 2 < nks) load_ab(a0, b0, ks + 2);
+    if (ks + 2 < nks) {
+      load_ab(a0, b0, ks + 2);
+    } else if (!A_IS_E && save_dst != nullptr) {
+      // last iteration, every load of this loop already issued: stream the tile's rows out in one
+      // burst.  (vmcnt retires in order, so a store issued earlier in the loop would sit in front
+      // of later weight loads and stall their waits for a full HBM write round trip.)
+#pragma unroll 4
+      for (int i = 0; i < TM / NWAVES; ++i) {
+        const int m = i * NWAVES + wave;
+        if (m < save_valid) {
+          const float4 v = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
+          store_nt(save_dst + (unsigned)(m * 256 + ((lane ^ (m & 15)) << 2)), v);
+        }
+      }
+    }
     mfma16(a1, b1);
   }
 }
@@ -213,8 +246,16 @@ __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >
 // is recorded as one 64-bit ballot; ballot i = (nt*2+mt)*16 + r is kept by lane i and the wave
 // stores its 64 words with one coalesced 512-byte access.  mlp_bwd_dx (same wave->tile mapping)
 // reads the words back instead of re-reading 1 KB/point/layer of activations.
+template <int NT>
+__device__ __forceinline__ void load_bias(float (&bv)[NT], const float* __restrict__ bias, int wn, int lane) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = bias[(wn * NT + nt) * 32 + (lane & 31)];
+}
+
+// bias values are loaded by the caller BEFORE the k-loop (load_bias) so that no global load waits
+// behind the activation stores issued at the end of the loop
 template <int NT, bool RELU>
-__device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const float* __restrict__ bias, float* Hs,
+__device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const float (&bias_v)[NT], float* Hs,
                                              int wm, int wn, int lane, float* __restrict__ save, int ldsave,
                                              int valid, unsigned long long* __restrict__ mask_out = nullptr) {
   asm volatile("" : "+v"(lane));
@@ -222,7 +263,7 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (wn * NT + nt) * 32 + (lane & 31);
-    const float bv = bias[n];
+    const float bv = bias_v[nt];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -247,14 +288,27 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
   }
 }
 
+
+// Two workgroups share every CU (two waves per SIMD share one MFMA pipe).  Launched together on
+// identical work they run in lockstep -- both in their k-loops (pipe shared) and then both in
+// their epilogues (pipe idle).  A one-off pseudo-random start delay (0..15 x 1024 cycles, larger
+// than an epilogue) de-phases them so that one workgroup's epilogue / barrier / PE phase overlaps
+// the other's MFMAs (measured: profiles/r01_summary.md).
+__device__ __forceinline__ void stagger_start() {
+#if TM == 64
+  const unsigned h = ((unsigned)blockIdx.x * 2654435761u) >> 28;  // 0..15
+  for (unsigned i = 0; i < h; ++i) __builtin_amdgcn_s_sleep(16);    // 16 x 64 cycles
+#endif
+}
+
 // =========================================================================================
 // forward
 // =========================================================================================
 template <bool SAVE>
-__global__ void __launch_bounds__(NTHR, 2)
+__global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                const float* __restrict__ params, const float* __restrict__ packed, float* __restrict__ raw,
-               float* __restrict__ act) {
+               float* __restrict__ act, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;
   float* Es = smem + LDS_H;
@@ -264,12 +318,13 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
   const int wm = wave >> 2, wn = wave & 3;
   const float4* pk = reinterpret_cast<const float4*>(packed);
   const int64_t ntiles = (P + TM - 1) / TM;
+  stagger_start();
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     unsigned long long* maskw =
-        SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(P)) + tile * MASK_WORDS_PER_TILE : nullptr;
+        SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(P)) + tile * (8 * NWAVES * 64) : nullptr;
     // ---- phase A: points + positional encoding -> Es ---------------------------------
     const int pm = tid >> 2, pq = tid & 3;
     int64_t pp = p0 + pm;
@@ -298,45 +353,41 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       for (int i = tid; i < TM * 16; i += NTHR) {
         const int m = i >> 4, sl = i & 15;
         if (m < valid)
-          *reinterpret_cast<float4*>(ape + m * 64 + sl * 4) =
-              *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2));
+          store_nt(ape + m * 64 + sl * 4, *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2)));
       }
     }
     f32x16 acc[2][2];
     // ---- L0 : pe64 -> 256 -------------------------------------------------------------
     zero_acc<2>(acc);
-    gemm_seg<2, true>(acc, Es, 0, 8, pk + PF_OFF(0) / 4, 8, 0, wn * 2, wm, lane);
-    epilogue_fwd<2, true>(acc, params + L_B(0), Hs, wm, wn, lane, SAVE ? act + act_h(P, 0) + p0 * 256 : nullptr, 256, valid,
-                          SAVE ? maskw + (0 * 8 + wave) * 64 : nullptr);
+    float bv2[2];
+    load_bias<2>(bv2, params + L_B(0), wn, lane);
+    gemm_seg<2, true>(acc, Es, 0, 8, pk + PF_OFF(0) / 4, 8, 0, wn * 2, wm, lane, dbg);
+    epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
+                          SAVE ? maskw + (0 * NWAVES + wave) * 64 : nullptr);
     __syncthreads();
     // ---- L1..L7 -----------------------------------------------------------------------
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
       zero_acc<2>(acc);
-      const float4* B = pk + PF_OFF(0) / 4;  // placeholder, set below
-      int64_t off;
+      int64_t off, boff;
       switch (l) {
-        case 1: off = PF_OFF(1); break; case 2: off = PF_OFF(2); break; case 3: off = PF_OFF(3); break;
-        case 4: off = PF_OFF(4); break; case 5: off = PF_OFF(5); break; case 6: off = PF_OFF(6); break;
-        default: off = PF_OFF(7); break;
+        case 1: off = PF_OFF(1); boff = L_B(1); break; case 2: off = PF_OFF(2); boff = L_B(2); break;
+        case 3: off = PF_OFF(3); boff = L_B(3); break; case 4: off = PF_OFF(4); boff = L_B(4); break;
+        case 5: off = PF_OFF(5); boff = L_B(5); break; case 6: off = PF_OFF(6); boff = L_B(6); break;
+        default: off = PF_OFF(7); boff = L_B(7); break;
       }
-      B = pk + off / 4;
+      const float4* B = pk + off / 4;
+      load_bias<2>(bv2, params + boff, wn, lane);
+      float* sv = SAVE ? act + act_h(P, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
       if (l == 5) {
-        gemm_seg<2, true>(acc, Es, 0, 8, B, 40, 0, wn * 2, wm, lane);
-        gemm_seg<2, false>(acc, Hs, 0, 32, B, 40, 8, wn * 2, wm, lane);
+        gemm_seg<2, true>(acc, Es, 0, 8, B, 40, 0, wn * 2, wm, lane, dbg);
+        gemm_seg<2, false>(acc, Hs, 0, 32, B, 40, 8, wn * 2, wm, lane, dbg, sv, valid, wave);
       } else {
-        gemm_seg<2, false>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane);
-      }
-      int64_t boff;
-      switch (l) {
-        case 1: boff = L_B(1); break; case 2: boff = L_B(2); break; case 3: boff = L_B(3); break;
-        case 4: boff = L_B(4); break; case 5: boff = L_B(5); break; case 6: boff = L_B(6); break;
-        default: boff = L_B(7); break;
+        gemm_seg<2, false>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
       }
       __syncthreads();  // every wave has finished reading H
-      epilogue_fwd<2, true>(acc, params + boff, Hs, wm, wn, lane,
-                            SAVE ? act + act_h(P, l) + p0 * 256 : nullptr, 256, valid,
-                            SAVE ? maskw + (l * 8 + wave) * 64 : nullptr);
+      epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
+                            SAVE ? maskw + (l * NWAVES + wave) * 64 : nullptr);
       __syncthreads();
     }
     // ---- alpha head (VALU) + view-direction encoding -> Es ---------------------------
@@ -369,28 +420,40 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     }
     // ---- feature layer (no ReLU) ------------------------------------------------------
     zero_acc<2>(acc);
-    gemm_seg<2, false>(acc, Hs, 0, 32, pk + PF_OFF(8) / 4, 32, 0, wn * 2, wm, lane);
+    load_bias<2>(bv2, params + F_B, wn, lane);
+    gemm_seg<2, false>(acc, Hs, 0, 32, pk + PF_OFF(8) / 4, 32, 0, wn * 2, wm, lane, dbg,
+                       SAVE ? act + act_h(P, 7) + p0 * 256 : nullptr, valid, wave);
     __syncthreads();
-    epilogue_fwd<2, false>(acc, params + F_B, Hs, wm, wn, lane, SAVE ? act + act_feat(P) + p0 * 256 : nullptr, 256, valid);
+    epilogue_fwd<2, false>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
     __syncthreads();
     if (SAVE) {
       float* avp = act + act_vpe(P) + p0 * 32;
       for (int i = tid; i < TM * 8; i += NTHR) {
         const int m = i >> 3, sl = i & 7;
         if (m < valid)
-          *reinterpret_cast<float4*>(avp + m * 32 + sl * 4) =
-              *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2));
+          store_nt(avp + m * 32 + sl * 4, *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2)));
       }
     }
     // ---- view layer: [feat | vpe32] -> 128, ReLU ---------------------------------------
     {
       f32x16 av[2][1];
       zero_acc<1>(av);
-      gemm_seg<1, false>(av, Hs, 0, 32, pk + PF_OFF(9) / 4, 36, 0, wn, wm, lane);
-      gemm_seg<1, true>(av, Es, 0, 4, pk + PF_OFF(9) / 4, 36, 32, wn, wm, lane);
+      float bv1[1];
+      load_bias<1>(bv1, params + V_B, wn, lane);
+      gemm_seg<1, false>(av, Hs, 0, 32, pk + PF_OFF(9) / 4, 36, 0, wn, wm, lane, dbg,
+                         SAVE ? act + act_feat(P) + p0 * 256 : nullptr, valid, wave);
+      gemm_seg<1, true>(av, Es, 0, 4, pk + PF_OFF(9) / 4, 36, 32, wn, wm, lane, dbg);
       __syncthreads();
-      epilogue_fwd<1, true>(av, params + V_B, Hs, wm, wn, lane, SAVE ? act + act_hv(P) + p0 * 128 : nullptr, 128, valid);
+      epilogue_fwd<1, true>(av, bv1, Hs, wm, wn, lane, nullptr, 128, valid);
       __syncthreads();
+      if (SAVE) {   // hv: 32 slots per row, whole 512-byte rows per half wave
+        float* ahv = act + act_hv(P) + p0 * 128;
+        for (int i = tid; i < TM * 32; i += NTHR) {
+          const int m = i >> 5, sl = i & 31;
+          if (m < valid)
+            store_nt(ahv + m * 128 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
+        }
+      }
     }
     // ---- rgb head (VALU) + output -------------------------------------------------------
     {
@@ -427,7 +490,7 @@ extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const flo
   if (n == 0) return 0;
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
-  int grid = num_cus();
+  int grid = num_cus() * WG_PER_CU;
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {
@@ -437,12 +500,17 @@ extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const flo
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done = true;
   }
+  static int dbg = -1;
+  if (dbg < 0) {
+    const char* e = getenv("FASTNERF_DBG");   // profiling ablations only; 0 in production
+    dbg = e ? atoi(e) : 0;
+  }
   if (act)
     hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, fn::S(stream), P, S, rays11, z, params,
-                       packed_fwd, raw, act);
+                       packed_fwd, raw, act, dbg);
   else
     hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, fn::S(stream), P, S, rays11, z,
-                       params, packed_fwd, raw, act);
+                       params, packed_fwd, raw, act, dbg);
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -452,22 +520,38 @@ extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const flo
 // =========================================================================================
 // epilogue: optional rank-1 term (dalpha x wa), ReLU mask from the forward's ballot words, write H
 // and the pre-activation gradient buffer.
+struct DxPre {  // loaded before the k-loop (see load_bias)
+  unsigned mlo, mhi;
+  float wan[2];
+};
 template <bool MASK, bool RANK1>
-__device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs, const float* Es_dalpha,
-                                            const float* __restrict__ wa,
-                                            const unsigned long long* __restrict__ maskw,
-                                            float* __restrict__ dsave, int wm, int wn, int lane, int valid) {
-  asm volatile("" : "+v"(lane));
-  unsigned mlo = 0u, mhi = 0u;
+__device__ __forceinline__ DxPre dx_preload(const unsigned long long* __restrict__ maskw, const float* __restrict__ wa,
+                                            int wn, int lane) {
+  DxPre p;
+  p.mlo = p.mhi = 0u;
+  p.wan[0] = p.wan[1] = 0.f;
   if (MASK) {
     const unsigned long long w = maskw[lane];
-    mlo = (unsigned)w;
-    mhi = (unsigned)(w >> 32);
+    p.mlo = (unsigned)w;
+    p.mhi = (unsigned)(w >> 32);
   }
+  if (RANK1) {
+    p.wan[0] = wa[(wn * 2 + 0) * 32 + (lane & 31)];
+    p.wan[1] = wa[(wn * 2 + 1) * 32 + (lane & 31)];
+  }
+  return p;
+}
+
+template <bool MASK, bool RANK1>
+__device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs, const float* Es_dalpha,
+                                            const DxPre& pre, float* __restrict__ dsave, int wm, int wn, int lane,
+                                            int valid) {
+  asm volatile("" : "+v"(lane));
+  const unsigned mlo = pre.mlo, mhi = pre.mhi;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = (wn * 2 + nt) * 32 + (lane & 31);
-    const float wan = RANK1 ? wa[n] : 0.f;
+    const float wan = pre.wan[nt];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -483,14 +567,14 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
           v = ((word >> (lane & 31)) & 1u) ? v : 0.f;
         }
         Hs[hidx(m, n)] = v;
-        if (m < valid) dsave[(unsigned)(m * 256 + n)] = v;
+        if (dsave != nullptr && m < valid) dsave[(unsigned)(m * 256 + n)] = v;
       }
       __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
     }
   }
 }
 
-__global__ void __launch_bounds__(NTHR, 2)
+__global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __restrict__ act,
                   const float* __restrict__ params, const float* __restrict__ packed_t, float* __restrict__ dact) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -502,12 +586,13 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
   const int wm = wave >> 2, wn = wave & 3;
   const float4* pk = reinterpret_cast<const float4*>(packed_t);
   const int64_t ntiles = (P + TM - 1) / TM;
+  stagger_start();
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     const unsigned long long* maskw =
-        reinterpret_cast<const unsigned long long*>(act + act_mask(P)) + tile * MASK_WORDS_PER_TILE;
+        reinterpret_cast<const unsigned long long*>(act + act_mask(P)) + tile * (8 * NWAVES * 64);
     // ---- phase A: dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] --------------------------
     {
       const int pm = tid >> 2, pq = tid & 3;
@@ -532,7 +617,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
         o.w = (h.w > 0.f) ? fmaf(dr.z, w2.w, fmaf(dr.y, w1.w, dr.x * w0.w)) : 0.f;
         if (!ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = o;
-        if (ok) *reinterpret_cast<float4*>(dyv + k) = o;
+        if (ok) store_nt(dyv + k, o);
       }
     }
     __syncthreads();
@@ -541,14 +626,18 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     zero_acc<2>(acc);
     gemm_seg<2, false>(acc, Hs, 0, 16, pk + PB_OFF(0) / 4, 16, 0, wn * 2, wm, lane);
     __syncthreads();
-    epilogue_dx<false, false>(acc, Hs, Es, nullptr, nullptr, dact + dact_feat(P) + p0 * 256, wm, wn, lane, valid);
+    epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
+                              valid);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ------------------------------------
     zero_acc<2>(acc);
-    gemm_seg<2, false>(acc, Hs, 0, 32, pk + PB_OFF(1) / 4, 32, 0, wn * 2, wm, lane);
-    __syncthreads();
-    epilogue_dx<true, true>(acc, Hs, Es, params + A_W, maskw + (7 * 8 + wave) * 64,
-                            dact + dact_y(P, 7) + p0 * 256, wm, wn, lane, valid);
+    {
+      const DxPre pre = dx_preload<true, true>(maskw + (7 * NWAVES + wave) * 64, params + A_W, wn, lane);
+      gemm_seg<2, false>(acc, Hs, 0, 32, pk + PB_OFF(1) / 4, 32, 0, wn * 2, wm, lane, 0,
+                         dact + dact_feat(P) + p0 * 256, valid, wave);    // streams dfeat (what it reads) out
+      __syncthreads();
+      epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
+    }
     __syncthreads();
     // ---- dY_{l-1} = (dY_l . W_l) * [h_{l-1} > 0],  l = 7..1 ------------------------------
 #pragma unroll 1
@@ -560,11 +649,21 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
         default: off = PB_OFF(8); break;
       }
       zero_acc<2>(acc);
-      gemm_seg<2, false>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane);
+      const DxPre pre = dx_preload<true, false>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
+      gemm_seg<2, false>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane, 0,
+                         dact + dact_y(P, l) + p0 * 256, valid, wave);    // streams dY_l (what it reads) out
       __syncthreads();
-      epilogue_dx<true, false>(acc, Hs, Es, nullptr, maskw + ((l - 1) * 8 + wave) * 64,
-                               dact + dact_y(P, l - 1) + p0 * 256, wm, wn, lane, valid);
+      epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
       __syncthreads();
+    }
+    {   // dY0 has no consumer loop: copy it out row-wise
+      float* d0 = dact + dact_y(P, 0) + p0 * 256;
+      for (int i = tid; i < TM * 64; i += NTHR) {
+        const int m = i >> 6, sl = i & 63;
+        if (m < valid)
+          store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
+      }
+      __syncthreads();   // H is rewritten by the next tile's phase A
     }
   }
 }
@@ -825,7 +924,7 @@ extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
   const int ncu = num_cus();
-  int grid = ncu;
+  int grid = ncu * WG_PER_CU;
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {

@@ -52,8 +52,8 @@ static_assert(PB_TOTAL == 557056, "packed bwd size");
 // ---- saved activations, SoA over P points ----
 constexpr int ACT_DENSE = 64 + 8 * 256 + 256 + 32 + 128;   // floats per point
 static_assert(ACT_DENSE == 2528, "act floats");
-// + per 128-point tile: 8 layers x 8 waves x 64 ballot words (uint64) of the ReLU masks
-constexpr int MASK_WORDS_PER_TILE = 8 * 8 * 64;
+// + per tile of 64*k points: 8 layers x 4k waves x 64 ballot words (uint64) of the ReLU masks
+// (= 256 bytes per point for either tile size)
 constexpr int ACT_FLOATS = ACT_DENSE + 64;                   // 2592 per point (+ one tile of slack)
 inline __host__ __device__ int64_t act_pe(int64_t P) { return 0; }
 inline __host__ __device__ int64_t act_h(int64_t P, int l) { return P * 64 + (int64_t)l * P * 256; }
