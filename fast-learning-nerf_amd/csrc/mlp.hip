@@ -673,13 +673,16 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
 // =========================================================================================
 #define DW_MT 32  // points per LDS stage
 
-// WO x WI waves (WO*WI == 4), each wave TO x TI MFMA tiles:  NO = WO*TO*32, KI = WI*TI*32
+// WO x WI waves (4 or 8), each wave TO x TI MFMA tiles:  NO = WO*TO*32, KI = WI*TI*32.
+// The 256x256 jobs run 8 waves x 128 accumulator registers (two waves per SIMD) so that one wave's
+// staging / bias work overlaps the other's MFMAs.
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                   const float* __restrict__ draw /*RANK1: dalpha = draw[p*4+3]*/, float* __restrict__ partial_w,
                   float* __restrict__ partial_b, float* __restrict__ partial_r) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  constexpr int NTD = WO * WI * 64;  // threads
   constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;  // floats per LDS stage (+32 dalpha)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -702,9 +705,9 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bsum = 0.f, rsum = 0.f;
 
-  constexpr int YV = DW_MT * NO / 4 / 256;  // float4 per thread for the dY stage
-  constexpr int XV = DW_MT * KI / 4 / 256;  // float4 per thread for the X stage
-  static_assert(DW_MT * NO % 1024 == 0 && DW_MT * KI % 1024 == 0, "stage split");
+  constexpr int YV = (DW_MT * NO / 4 + NTD - 1) / NTD;  // float4 per thread for the dY stage
+  constexpr int XV = (DW_MT * KI / 4 + NTD - 1) / NTD;  // float4 per thread for the X stage
+  static_assert(DW_MT * NO % 4 == 0 && DW_MT * KI % 4 == 0 && NO <= NTD && KI <= NTD, "stage split");
   float4 ry[YV], rx[XV];
   float rda = 0.f;
 
@@ -712,17 +715,19 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
     const int64_t pbase = t * DW_MT;
 #pragma unroll
     for (int i = 0; i < YV; ++i) {
-      const int e = (i * 256 + tid) * 4;
+      const int e = (i * NTD + tid) * 4;
       const int m = e / NO, c = e % NO;
       const int64_t p = pbase + m;
-      ry[i] = (p < P) ? *reinterpret_cast<const float4*>(dY + p * ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ry[i] = (e < DW_MT * NO && p < P) ? *reinterpret_cast<const float4*>(dY + p * ldy + c)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int e = (i * 256 + tid) * 4;
+      const int e = (i * NTD + tid) * 4;
       const int m = e / KI, c = e % KI;
       const int64_t p = pbase + m;
-      rx[i] = (p < P) ? *reinterpret_cast<const float4*>(X + p * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = (e < DW_MT * KI && p < P) ? *reinterpret_cast<const float4*>(X + p * ldx + c)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (RANK1 && tid < DW_MT) {
       const int64_t p = pbase + tid;
@@ -731,9 +736,11 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
   };
   auto store_stage = [&](float* st) {
 #pragma unroll
-    for (int i = 0; i < YV; ++i) *reinterpret_cast<float4*>(st + (i * 256 + tid) * 4) = ry[i];
+    for (int i = 0; i < YV; ++i)
+      if ((i * NTD + tid) * 4 < DW_MT * NO) *reinterpret_cast<float4*>(st + (i * NTD + tid) * 4) = ry[i];
 #pragma unroll
-    for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(st + DW_MT * NO + (i * 256 + tid) * 4) = rx[i];
+    for (int i = 0; i < XV; ++i)
+      if ((i * NTD + tid) * 4 < DW_MT * KI) *reinterpret_cast<float4*>(st + DW_MT * NO + (i * NTD + tid) * 4) = rx[i];
     if (RANK1 && tid < DW_MT) st[DW_MT * (NO + KI) + tid] = rda;
   };
 
@@ -745,22 +752,43 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
   for (int64_t t = t0; t < t1; ++t) {
     float* cur = smem + ((t - t0) & 1) * STAGE;
     float* nxt = smem + (((t - t0) & 1) ^ 1) * STAGE;
+#if !defined(DW_ABL) || DW_ABL != 1
     if (t + 1 < t1) load_stage(t + 1);
+#endif
     const float* Ys = cur;
     const float* Xs = cur + DW_MT * NO;
-    // MFMA over the stage's 32 points, 2 per step
-#pragma unroll 4
-    for (int k2 = 0; k2 < DW_MT / 2; ++k2) {
-      const int m = k2 * 2 + (lane >> 5);
-      float a[TO], b[TI];
+    // MFMA over the stage's 32 points, 2 per step; fragments of the next step are fetched from LDS
+    // before the current step's MFMAs are issued (ping-pong registers): with one wave per SIMD
+    // nothing else hides the ds_read latency.
+    {
+      float fa0[TO], fb0[TI], fa1[TO], fb1[TI];
+      auto ldf = [&](float (&a)[TO], float (&b)[TI], int k2) {
+        const int m = k2 * 2 + (lane >> 5);
 #pragma unroll
-      for (int i = 0; i < TO; ++i) a[i] = Ys[m * NO + (wo * TO + i) * 32 + (lane & 31)];
+        for (int i = 0; i < TO; ++i) a[i] = Ys[m * NO + (wo * TO + i) * 32 + (lane & 31)];
 #pragma unroll
-      for (int j = 0; j < TI; ++j) b[j] = Xs[m * KI + (wi * TI + j) * 32 + (lane & 31)];
+        for (int j = 0; j < TI; ++j) b[j] = Xs[m * KI + (wi * TI + j) * 32 + (lane & 31)];
+      };
+      auto mm = [&](const float (&a)[TO], const float (&b)[TI]) {
 #pragma unroll
-      for (int i = 0; i < TO; ++i)
+        for (int i = 0; i < TO; ++i)
 #pragma unroll
-        for (int j = 0; j < TI; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < TI; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+      };
+      ldf(fa0, fb0, 0);
+#pragma unroll
+      for (int k2 = 0; k2 < DW_MT / 2; k2 += 2) {
+        // sched_barrier: keep the LDS reads AHEAD of the MFMA block (the machine scheduler otherwise
+        // sinks them next to their first use and re-exposes the latency)
+        ldf(fa1, fb1, k2 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k2 + 2 < DW_MT / 2) ldf(fa0, fb0, k2 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (BIAS) {
       if (tid < NO) {
@@ -775,8 +803,10 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
         for (int m = 0; m < DW_MT; ++m) rsum = fmaf(da[m], Xs[m * KI + tid], rsum);
       }
     }
+#if !defined(DW_ABL) || DW_ABL != 2
     if (t + 1 < t1) store_stage(nxt);
     __syncthreads();
+#endif
   }
   // write partials
   float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
@@ -903,7 +933,7 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
   float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr);
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -959,17 +989,17 @@ extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float
   const int64_t woffs[8] = {L_W(0), L_W(1), L_W(2), L_W(3), L_W(4), L_W(5), L_W(6), L_W(7)};
   const int64_t boffs[8] = {L_B(0), L_B(1), L_B(2), L_B(3), L_B(4), L_B(5), L_B(6), L_B(7)};
   for (int l = 1; l < 8; ++l) {
-    if ((rc = launch_dw<2, 2, 4, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, l - 1), 256, nullptr, region(l), nwg, st))) return rc;
+    if ((rc = launch_dw<4, 2, 2, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, l - 1), 256, nullptr, region(l), nwg, st))) return rc;
     segs(l, woffs[l] + (l == 5 ? 63 : 0), l == 5 ? 319 : 256, 256, boffs[l], 0);
   }
   // L5 pe part
   if ((rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st))) return rc;
   segs(8, L_W(5), 319, 63, 0, 0);
   // feature layer (+bias) with the alpha head as a rank-1 row
-  if ((rc = launch_dw<2, 2, 4, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, 7), 256, draw, region(9), nwg, st))) return rc;
+  if ((rc = launch_dw<4, 2, 2, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, 7), 256, draw, region(9), nwg, st))) return rc;
   segs(9, F_W, 256, 256, F_B, A_W);
   // view layer
-  if ((rc = launch_dw<2, 2, 2, 4, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P), 256, nullptr, region(10), nwg, st))) return rc;
+  if ((rc = launch_dw<2, 4, 2, 2, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P), 256, nullptr, region(10), nwg, st))) return rc;
   segs(10, V_W, 283, 256, V_B, 0);
   if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P), 32, nullptr, region(11), nwg, st))) return rc;
   segs(11, V_W + 256, 283, 27, 0, 0);
