@@ -1,0 +1,75 @@
+"""Training-level parity: PSNR at equal iteration count vs the CPU oracle (north_star: within
+0.1 dB), and the epoch driver with the quadtree in the loop."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def fn():
+    import fastnerf
+    return fastnerf
+
+
+def test_psnr_at_equal_iterations(fn):
+    imgs, poses, focal = fn.synthetic.make_dataset(n_images=6, H=24, W=24)
+    H = W = 24
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    torch.manual_seed(0)
+    args = fn.run_nerf.make_args(N_importance=16, N_samples=16, perturb=1.0, white_bkgd=True, no_reload=True,
+                                 lrate=5e-4, lrate_decay=500)
+    ktr, _, _, _, _, _ = fn.run_nerf.create_nerf(args)
+    sdc = {k: v.detach().cpu().clone() for k, v in ktr['network_fn'].state_dict().items()}
+    sdf = {k: v.detach().cpu().clone() for k, v in ktr['network_fine'].state_dict().items()}
+    tr = fn.run_nerf.Trainer(ktr, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+    opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
+    rays = [O.get_rays(H, W, K, poses[i]) for i in range(6)]
+    ro_all = torch.stack([r[0] for r in rays], 0).reshape(-1, 3)
+    rd_all = torch.stack([r[1] for r in rays], 0).reshape(-1, 3)
+    tgt_all = imgs.reshape(-1, 3)
+    gen = torch.Generator().manual_seed(1)
+    n_iters, N = 40, 192
+    lg, lc = [], []
+    for it in range(n_iters):
+        sel = torch.randint(0, ro_all.shape[0], (N,), generator=gen)
+        t_rand, u = torch.rand(N, 16, generator=gen), torch.rand(N, 16, generator=gen)
+        ro, rd, tgt = ro_all[sel], rd_all[sel], tgt_all[sel]
+        loss2, _ = tr.step(ro.cuda(), rd.cuda(), tgt.cuda(), t_rand=t_rand.cuda(), u=u.cuda())
+        lg.append(float(loss2[0]))
+        opt.lr = O.lr_schedule(5e-4, 500, it - 1) if it > 0 else 5e-4   # pre-increment rule (run_nerf.py:498-508)
+        l1, l0, _, _ = O.train_step(sdc, sdf, opt, O.make_ray_batch(ro, rd, 2.0, 6.0), tgt, 16, 16, True,
+                                    t_rand=t_rand, u=u)
+        lc.append(float(l1))
+    psnr_g = -10 * np.log10(np.mean(lg[-5:]))
+    psnr_c = -10 * np.log10(np.mean(lc[-5:]))
+    assert lg[-1] < lg[0] * 0.8                         # it trains
+    assert abs(psnr_g - psnr_c) < 0.1, (psnr_g, psnr_c)  # north_star bound
+    assert abs(lg[0] - lc[0]) < 1e-5
+    assert abs(tr.lr - opt.lr * 0 - O.lr_schedule(5e-4, 500, n_iters - 1)) < 1e-12
+
+
+def test_train_driver_with_quadtree(fn):
+    imgs, poses, focal = fn.synthetic.make_dataset(n_images=4, H=32, W=32)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    args = fn.run_nerf.make_args(N_importance=16, N_samples=16, perturb=1.0, white_bkgd=True, no_reload=True,
+                                 N_rand=256, n_epoch=4, init_level=2, subdivide_every=1, subdivide_thres=0.05,
+                                 lrate=5e-4, lrate_decay=500)
+    logs = []
+    ktr, kte, trainer, mgr, hist = fn.run_nerf.train(imgs, poses, 32, 32, focal, args, log=logs.append,
+                                                     compat_rng=False)
+    assert len(hist) == 4 and all(np.isfinite(h[2]) for h in hist)
+    assert hist[-1][2] < hist[0][2]                       # loss went down over the epochs
+    # trees were refined (epochs 1 and 2 subdivide; the last two do not: run_nerf.py:520)
+    assert mgr.cur_level == 4 and max(mgr.num_leaves(i) for i in range(4)) > 4
+    # last epoch uses every pixel once per image in expectation (tree.py:390-400)
+    assert hist[-1][1] == (4 * 32 * 32 + 255) // 256
+    # evaluation path renders a held-in view close to its target
+    K = np.array([[focal, 0, 16.0], [0, focal, 16.0], [0, 0, 1]])
+    rgbs, disps = fn.render.render_path(poses[:1], (32, 32, focal), K, 4096, dict(kte, near=2.0, far=6.0), gt_imgs=imgs[:1])
+    assert rgbs.shape == (1, 32, 32, 3) and np.isfinite(rgbs).all()
+    assert fn.render.render_path.last_psnrs[0] > 8.0
