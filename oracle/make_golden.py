@@ -284,6 +284,27 @@ def main():
         rec['last_d'] = d.numpy().copy()
         np.savez_compressed(os.path.join(OUT, f'g9_tree_seq_{Hh}x{Ww}.npz'), **rec)
 
+    # ---- G11 LLFF-style forward-facing render: ndc=True (render() default), near 0 / far 1,
+    #      64+64 samples, raw_noise_std=1 through the pytest hook (np.random.rand * std) ----------
+    # the G8 block above has stepped the optimiser: restore the weights saved in g7_weights.npz
+    kw_train['network_fn'].load_state_dict({'module.' + k: torch.from_numpy(v) for k, v in sdc.items()})
+    kw_train['network_fine'].load_state_dict({'module.' + k: torch.from_numpy(v) for k, v in sdf.items()})
+    Hl, Wl, fl = 756, 1008, 815.13
+    Kl = np.array([[fl, 0, 0.5 * Wl], [0, fl, 0.5 * Hl], [0, 0, 1]])
+    c2w_l = torch.tensor([[1.0, 0, 0, 0.05], [0, 1.0, 0, -0.03], [0, 0, 1.0, 0.1]])
+    o_l, d_l = H.get_rays(Hl, Wl, Kl, c2w_l)
+    sel = torch.randint(0, Hl * Wl, (48,), generator=g)
+    rol = o_l.reshape(-1, 3)[sel].contiguous()
+    rdl = d_l.reshape(-1, 3)[sel].contiguous()
+    kl = {k: v for k, v in kw_train.items() if k not in ('ndc', 'lindisp')}
+    kl['raw_noise_std'] = 1.0
+    kl['N_importance'] = 64
+    rgb, disp, acc, ex = R.render(Hl, Wl, Kl, chunk=32768, rays=torch.stack([rol, rdl], 0), retraw=True,
+                                  near=0., far=1., pytest=True, **kl)
+    np.savez(os.path.join(OUT, 'g11_llff_render.npz'), ro=rol.numpy(), rd=rdl.numpy(), K=Kl, H=Hl, W=Wl,
+             rgb=rgb.detach().numpy(), disp=disp.detach().numpy(), acc=acc.detach().numpy(),
+             rgb0=ex['rgb0'].detach().numpy(), acc0=ex['acc0'].detach().numpy(), z_std=ex['z_std'].detach().numpy())
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('wrote goldens to', OUT, 'total bytes', tot)
 

@@ -215,3 +215,20 @@ def test_quadtree_device_table(fn, golden_dir):
     omgr.adjust(rgb.cpu(), pred.cpu(), 0.04)
     for i in range(2):
         assert np.array_equal(mgr.leaves(i), omgr.leaf_array(i))
+
+
+def test_llff_ndc_noise_g11(fn, golden_dir):
+    """Config-4 shape: NDC rays, near 0 / far 1, 64+64 samples, raw_noise_std=1 via the reference's
+    pytest hook; kwargs without 'ndc'/'lindisp' keys => render() defaults ndc=True (run_nerf.py:143-147)."""
+    g = np.load(os.path.join(golden_dir, 'g11_llff_render.npz'))
+    ktr, _, _, _ = build(fn, golden_dir)
+    kl = {k: v for k, v in ktr.items() if k not in ('ndc', 'lindisp')}
+    kl['raw_noise_std'] = 1.0
+    kl['N_importance'] = 64
+    rays = torch.stack([torch.from_numpy(g['ro']), torch.from_numpy(g['rd'])], 0).cuda()
+    with torch.no_grad():
+        rgb, disp, acc, ex = fn.render.render(int(g['H']), int(g['W']), g['K'], chunk=32768, rays=rays, retraw=True,
+                                              near=0., far=1., pytest=True, **kl)
+    for k, got in (('rgb', rgb), ('acc', acc), ('rgb0', ex['rgb0']), ('acc0', ex['acc0'])):
+        assert np.abs(got.cpu().numpy() - g[k]).max() < TOL_RGB, k
+    assert np.abs(ex['z_std'].cpu().numpy() - g['z_std']).max() < 1e-3

@@ -153,3 +153,20 @@ def test_g8_train_step(golden_dir):
     assert n_checked > 20
     assert abs(O.lr_schedule(5e-4, 500, 0) - float(g['new_lr'])) < 1e-12
     assert abs(O.lr_schedule(5e-4, 500, 250000) - 5e-4 * 0.1 ** 0.5) < 1e-12
+
+
+def test_g11_llff_ndc_noise(golden_dir):
+    """Forward-facing config-4 shape: ndc warp (render.py:69-71), near 0 / far 1, sigma noise."""
+    g = L(golden_dir, 'g11_llff_render.npz')
+    wts = L(golden_dir, 'g7_weights.npz')
+    sdc, sdf = load_sd(wts, 'c.'), load_sd(wts, 'f.')
+    rb = O.make_ray_batch(T(g['ro']), T(g['rd']), 0.0, 1.0, H=int(g['H']), W=int(g['W']), focal=float(g['K'][0][0]),
+                          ndc=True)
+    np.random.seed(0); t_rand = torch.Tensor(np.random.rand(48, 64))
+    np.random.seed(0); n0 = torch.Tensor(np.random.rand(48, 64)) * 1.0
+    np.random.seed(0); u = torch.Tensor(np.random.rand(48, 64))
+    np.random.seed(0); n1 = torch.Tensor(np.random.rand(48, 128)) * 1.0
+    with torch.no_grad():
+        r = O.render_rays(rb, sdc, sdf, 64, 64, white_bkgd=True, t_rand=t_rand, u=u, noise0=n0, noise1=n1)
+    for gk, rk in (('rgb', 'rgb_map'), ('acc', 'acc_map'), ('rgb0', 'rgb0'), ('acc0', 'acc0'), ('z_std', 'z_std')):
+        assert np.allclose(r[rk].numpy(), g[gk], rtol=1e-5, atol=2e-6), gk
