@@ -144,9 +144,16 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         flops = P * FWD_FLOP_PER_POINT
         achieved = flops / (ms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            traffic = pmc['kernels']['void mlp_fwd_kernel<true>']['hbm_bytes']
+        except Exception:
+            pass
         roof = {'bound': 'mfma', 'kernel': 'mlp_fwd_kernel<true> (fine pass, 786432 points/launch)',
                 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': ms,
+                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01_pmc_traffic.json)',
+                'avg_launch_ms': ms,
                 'flop_per_launch': flops}
         del act
 
@@ -167,6 +174,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        parallel.barrier()
         torch.distributed.destroy_process_group()
 
 

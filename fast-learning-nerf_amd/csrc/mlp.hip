@@ -181,14 +181,19 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __re
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 64 + lane;
 
-  // ping-pong register sets (no copies: a copy of a just-issued load would force vmcnt(0))
-  float4 a0[2], b0[NT], a1[2], b1[NT];
-  auto load_ab = [&](float4 (&a)[2], float4 (&b)[NT], int ks) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = bptr[nt][ks * 64];
+  // rotating register sets (no copies: a copy of a just-issued load would force vmcnt(0)); the
+  // weight fragments are fetched PF k-steps ahead of their MFMAs
+#ifndef GEMM_PF
+#define GEMM_PF 1
+#endif
+  auto load_a = [&](float4 (&a)[2], int ks) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
       a[mt] = *reinterpret_cast<const float4*>(arow[mt] + ((((a_ks0 + ks) * 2 + lhalf) ^ axor[mt]) << 2));
+  };
+  auto load_b = [&](float4 (&b)[NT], int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = bptr[nt][ks * 64];
   };
   auto mfma16 = [&](const float4 (&a)[2], const float4 (&b)[NT]) {
 #pragma unroll
@@ -204,17 +209,11 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __re
       }
     }
   };
-  load_ab(a0, b0, 0);
-#pragma unroll 1
-  for (int ks = 0; ks < nks; ks += 2) {  // nks is even for every layer
-    load_ab(a1, b1, ks + 1);
-    mfma16(a0, b0);
-    if (ks + 2 < nks) {
-      load_ab(a0, b0, ks + 2);
-    } else if (!A_IS_E && save_dst != nullptr) {
-      // last iteration, every load of this loop already issued: stream the tile's rows out in one
-      // burst.  (vmcnt retires in order, so a store issued earlier in the loop would sit in front
-      // of later weight loads and stall their waits for a full HBM write round trip.)
+  auto side_copy = [&]() {
+    if (!A_IS_E && save_dst != nullptr) {
+      // every load of this loop already issued: stream the tile's rows out in one burst.  (vmcnt
+      // retires in order, so a store issued earlier in the loop would sit in front of later weight
+      // loads and stall their waits for a full HBM write round trip.)
 #pragma unroll 4
       for (int i = 0; i < TM / NWAVES; ++i) {
         const int m = i * NWAVES + wave;
@@ -224,8 +223,34 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __re
         }
       }
     }
+  };
+#if GEMM_PF == 1
+  float4 a0[2], b0[NT], a1[2], b1[NT];
+  load_b(b0, 0); load_a(a0, 0);
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks += 2) {  // nks is even for every layer
+    load_b(b1, ks + 1); load_a(a1, ks + 1);
+    mfma16(a0, b0);
+    if (ks + 2 < nks) { load_b(b0, ks + 2); load_a(a0, ks + 2); } else side_copy();
     mfma16(a1, b1);
   }
+#else
+  // weights two k-steps ahead (3 B sets in flight), activations one ahead; nks % 4 == 0
+  float4 a0[2], a1[2], b0[NT], b1[NT], b2[NT], b3[NT];
+  load_b(b0, 0); load_b(b1, 1); load_a(a0, 0);
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks += 4) {
+    load_b(b2, ks + 2); load_a(a1, ks + 1);
+    mfma16(a0, b0);
+    load_b(b3, ks + 3); load_a(a0, ks + 2);
+    mfma16(a1, b1);
+    if (ks + 4 < nks) load_b(b0, ks + 4);
+    load_a(a1, ks + 3);
+    mfma16(a0, b2);
+    if (ks + 4 < nks) { load_b(b1, ks + 5); load_a(a0, ks + 4); } else side_copy();
+    mfma16(a1, b3);
+  }
+#endif
 }
 
 template <int NT>
