@@ -38,6 +38,16 @@ SIGNATURES = {
     'fastnerf_sample_pdf': (I, [L, I, I, P, P, I, P, U64, P, P]),
     'fastnerf_mse_leafmax': (I, [L, P, P, P, F, P, P, P, P, I, P, P]),
     'fastnerf_adam_step': (I, [L, P, P, P, P, D, D, D, D, I, P]),
+    'fastnerf_net_floats': (L, [I, I]),
+    'fastnerf_mlp_act_floats': (L, [I, L]),
+    'fastnerf_mlp_pack_ex': (I, [I, P, P, P, P]),
+    'fastnerf_mlp_fwd_ex': (I, [I, L, I, P, P, P, P, P, P, P]),
+    'fastnerf_mlp_bwd_ex': (I, [I, L, I, P, P, P, P, P, P, P, P]),
+    'fastnerf_pp_intersect_sphere': (I, [L, P, P, P, P]),
+    'fastnerf_pp_fg_depths': (I, [L, I, F, P, I, P, U64, P, P]),
+    'fastnerf_pp_sample_pdf_merge': (I, [L, I, I, P, P, I, P, U64, P, P, P]),
+    'fastnerf_pp_composite_fwd': (I, [L, I, I, P, P, P, P, P, P, P, P, P]),
+    'fastnerf_pp_composite_bwd': (I, [L, I, I, P, P, P, P, P, P, P, P]),
     'fastnerf_tree_create': (P, [I, I, I, I]),
     'fastnerf_tree_destroy': (None, [P]),
     'fastnerf_tree_num_leaves': (I, [P, I]),

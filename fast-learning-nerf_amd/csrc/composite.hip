@@ -45,11 +45,24 @@ struct SampleVals {
   float c[3];
 };
 
+// Variants of the compositing rule:
+//   nerf-ours raw2outputs (render.py:149-192)      : relu, eps 1e-10, last dist 1e10, dists * |d|
+//   nerf++ foreground (ddp_model.py:97-107)         : abs,  eps 1e-6,  last dist fg_far - z_last, * |d|
+//   nerf++ background (ddp_model.py:118-135)        : abs,  eps 1e-6,  z flipped (1 -> 0), last 1e10, no |d|
+struct CompCfg {
+  int act_abs;    // 0: relu(sigma)   1: |sigma|
+  float eps;      // added to 1 - alpha
+  int last_mode;  // 0: 1e10   1: far[r] - z_last
+  int use_dnorm;  // multiply dists by |rays_d|
+  int flip;       // samples are stored near->far but consumed far->near (z index S-1-s)
+};
+__device__ __forceinline__ CompCfg nerf_cfg() { return CompCfg{0, 1e-10f, 0, 1, 0}; }
+
 // per-lane chunk evaluation shared by forward and backward
 template <bool WITH_RGB>
 __device__ __forceinline__ void eval_chunk(int S, int C, int lane, const float* __restrict__ raw,
                                            const float* __restrict__ z, const float* __restrict__ noise, float dnorm,
-                                           SampleVals v[MAXC], int& cnt) {
+                                           SampleVals v[MAXC], int& cnt, const CompCfg cfg, float far) {
   const int s0 = lane * C;
   cnt = 0;
 #pragma unroll
@@ -58,15 +71,21 @@ __device__ __forceinline__ void eval_chunk(int S, int C, int lane, const float* 
     const int s = s0 + j;
     if (s >= S) break;
     const float4 r = *reinterpret_cast<const float4*>(raw + (int64_t)s * 4);
-    const float zs = z[s];
-    float dist = (s + 1 < S) ? fsub(z[s + 1], zs) : 1e10f;
-    dist = fmul(dist, dnorm);
+    const float zs = cfg.flip ? z[S - 1 - s] : z[s];
+    float dist;
+    if (s + 1 < S) {
+      const float zn = cfg.flip ? z[S - 2 - s] : z[s + 1];
+      dist = cfg.flip ? fsub(zs, zn) : fsub(zn, zs);
+    } else {
+      dist = cfg.last_mode ? fsub(far, zs) : 1e10f;
+    }
+    if (cfg.use_dnorm) dist = fmul(dist, dnorm);
     float sig = r.w;
     if (noise) sig = fadd(sig, noise[s]);
-    const float rs = fmaxf(sig, 0.0f);
+    const float rs = cfg.act_abs ? fabsf(sig) : fmaxf(sig, 0.0f);
     const float alpha = fsub(1.0f, expf(-fmul(rs, dist)));
     v[j].alpha = alpha;
-    v[j].t = fadd(fsub(1.0f, alpha), 1e-10f);
+    v[j].t = fadd(fsub(1.0f, alpha), cfg.eps);
     v[j].dist = dist;
     v[j].z = zs;
     v[j].sig = sig;
@@ -85,7 +104,9 @@ __global__ void __launch_bounds__(256) raw2outputs_fwd_kernel(int64_t n, int S, 
                                                                const float* __restrict__ noise, int white,
                                                                float* __restrict__ rgb_map, float* __restrict__ disp,
                                                                float* __restrict__ acc, float* __restrict__ weights,
-                                                               float* __restrict__ depth) {
+                                                               float* __restrict__ depth, const CompCfg cfg,
+                                                               const float* __restrict__ far,
+                                                               float* __restrict__ lambda) {
   const int lane = threadIdx.x & 63;
   const int C = (S + WAVE - 1) / WAVE;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -95,7 +116,8 @@ __global__ void __launch_bounds__(256) raw2outputs_fwd_kernel(int64_t n, int S, 
     const float dnorm = sqrtf(fadd(fadd(fmul(rr[3], rr[3]), fmul(rr[4], rr[4])), fmul(rr[5], rr[5])));
     SampleVals v[MAXC];
     int cnt;
-    eval_chunk<true>(S, C, lane, raw + r * S * 4, z + r * S, noise ? noise + r * S : nullptr, dnorm, v, cnt);
+    eval_chunk<true>(S, C, lane, raw + r * S * 4, z + r * S, noise ? noise + r * S : nullptr, dnorm, v, cnt, cfg,
+                     far ? far[r] : 0.f);
     float prod = 1.0f;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j)
@@ -103,6 +125,10 @@ __global__ void __launch_bounds__(256) raw2outputs_fwd_kernel(int64_t n, int S, 
     const float incl = wave_scan_mul(prod, lane);
     float T = __shfl_up(incl, 1, WAVE);
     if (lane == 0) T = 1.0f;
+    if (lambda) {   // product over ALL samples (nerf++ bg_lambda, ddp_model.py:103)
+      const float tot = __shfl(incl, WAVE - 1, WAVE);
+      if (lane == 0) lambda[r] = tot;
+    }
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
@@ -136,7 +162,9 @@ __global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(int64_t n, int S, 
                                                                const float* __restrict__ rays,
                                                                const float* __restrict__ noise, int white,
                                                                const float* __restrict__ g_rgb,
-                                                               float* __restrict__ draw) {
+                                                               float* __restrict__ draw, const CompCfg cfg,
+                                                               const float* __restrict__ far,
+                                                               const float* __restrict__ g_lambda) {
   const int lane = threadIdx.x & 63;
   const int C = (S + WAVE - 1) / WAVE;
   const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -148,7 +176,8 @@ __global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(int64_t n, int S, 
     const float gbg = white ? (g0 + g1 + g2) : 0.0f;
     SampleVals v[MAXC];
     int cnt;
-    eval_chunk<true>(S, C, lane, raw + r * S * 4, z + r * S, noise ? noise + r * S : nullptr, dnorm, v, cnt);
+    eval_chunk<true>(S, C, lane, raw + r * S * 4, z + r * S, noise ? noise + r * S : nullptr, dnorm, v, cnt, cfg,
+                     far ? far[r] : 0.f);
     float prod = 1.0f;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j)
@@ -156,6 +185,8 @@ __global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(int64_t n, int S, 
     const float incl = wave_scan_mul(prod, lane);
     float T0 = __shfl_up(incl, 1, WAVE);
     if (lane == 0) T0 = 1.0f;
+    // d(lambda)/d(alpha_i) = -lambda / t_i : folds into the suffix term
+    const float lam_term = g_lambda ? g_lambda[r] * __shfl(incl, WAVE - 1, WAVE) : 0.0f;
     // pass 1: weights, G*w chunk sums
     float w[MAXC], G[MAXC], Tj[MAXC];
     float gw_chunk = 0.f;
@@ -178,8 +209,10 @@ __global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(int64_t n, int S, 
 #pragma unroll
     for (int j = MAXC - 1; j >= 0; --j) {
       if (j < cnt) {
-        const float dalpha = G[j] * Tj[j] - suffix / v[j].t;
-        const float dsig = (v[j].sig > 0.0f) ? dalpha * v[j].dist * (1.0f - v[j].alpha) : 0.0f;
+        const float dalpha = G[j] * Tj[j] - (suffix + lam_term) / v[j].t;
+        const float dact = dalpha * v[j].dist * (1.0f - v[j].alpha);
+        const float dsig = cfg.act_abs ? ((v[j].sig > 0.0f) ? dact : ((v[j].sig < 0.0f) ? -dact : 0.0f))
+                                       : ((v[j].sig > 0.0f) ? dact : 0.0f);
         out[j].x = g0 * w[j] * v[j].c[0] * (1.0f - v[j].c[0]);
         out[j].y = g1 * w[j] * v[j].c[1] * (1.0f - v[j].c[1]);
         out[j].z = g2 * w[j] * v[j].c[2] * (1.0f - v[j].c[2]);
@@ -216,7 +249,9 @@ __device__ __forceinline__ int upper_bound_f(const float* a, int n, float x) {
 
 // LDS per wave: zs[S] | cdf[S] | bins[S] | smp[NP]   (NP = Ni rounded up to a power of two)
 // bins_mode != 0: `z` holds the bins themselves ([n,S-1]) and `weights` is [n,S-2]; no merge.
+// variant 1 = nerf++ sampler (ddp_train_nerf.py:84-133): eps 1e-6, index = #(u >= cdf[:M]), +1e-6 bin width
 __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(int64_t n, int S, int Ni, int NP, int bins_mode,
+                                                                int variant,
                                                                 const float* __restrict__ z,
                                                                 const float* __restrict__ weights, int det,
                                                                 const float* __restrict__ u_in, uint64_t seed,
@@ -252,7 +287,7 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(int64_t n, int S,
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
       const int k = lane * CW + j;
-      wl[j] = (j < CW && k < NW) ? fadd(bins_mode ? weights[r * NW + k] : weights[r * S + k + 1], 1e-5f) : 0.f;
+      wl[j] = (j < CW && k < NW) ? fadd(bins_mode ? weights[r * NW + k] : weights[r * S + k + 1], variant ? 1e-6f : 1e-5f) : 0.f;
       csum += (double)wl[j];
     }
     double totd = csum;
@@ -299,15 +334,15 @@ __global__ void __launch_bounds__(256) sample_pdf_merge_kernel(int64_t n, int S,
           philox4x32((uint32_t)idx, (uint32_t)(idx >> 32), 0x70646673u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
           u = u01(o[0]);
         }
-        const int inds = upper_bound_f(cdf, M, u);  // searchsorted(right=True)
+        const int inds = upper_bound_f(cdf, variant ? NW : M, u);  // searchsorted(right=True) / count(u >= cdf[:M])
         const int below = inds - 1 > 0 ? inds - 1 : 0;
         const int above = inds < M - 1 ? inds : M - 1;
         const float c0 = cdf[below], c1 = cdf[above];
         const float b0 = bins[below], b1 = bins[above];
         float denom = fsub(c1, c0);
-        if (denom < 1e-5f) denom = 1.0f;
+        if (denom < (variant ? 1e-6f : 1e-5f)) denom = 1.0f;
         const float t = fsub(u, c0) / denom;
-        smpl = fadd(b0, fmul(t, fsub(b1, b0)));
+        smpl = variant ? fadd(b0, fmul(t, fadd(fsub(b1, b0), 1e-6f))) : fadd(b0, fmul(t, fsub(b1, b0)));
         if (z_samples) z_samples[r * Ni + i] = smpl;
         lsum += smpl;
       }
@@ -367,7 +402,8 @@ extern "C" int fastnerf_raw2outputs_fwd(int64_t n, int S, const float* raw, cons
   FN_CHECK_ARG(n == 0 || (raw && z && rays11 && rgb_map), "null pointer");
   if (n == 0) return 0;
   hipLaunchKernelGGL(raw2outputs_fwd_kernel, dim3(grid_waves(n)), dim3(256), 0, fn::S(stream), n, S, raw, z, rays11,
-                     noise, white_bkgd, rgb_map, disp, acc, weights, depth);
+                     noise, white_bkgd, rgb_map, disp, acc, weights, depth, CompCfg{0, 1e-10f, 0, 1, 0},
+                     (const float*)nullptr, (float*)nullptr);
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -379,7 +415,8 @@ extern "C" int fastnerf_raw2outputs_bwd(int64_t n, int S, const float* raw, cons
   FN_CHECK_ARG(n == 0 || (raw && z && rays11 && g_rgb && draw), "null pointer");
   if (n == 0) return 0;
   hipLaunchKernelGGL(raw2outputs_bwd_kernel, dim3(grid_waves(n)), dim3(256), 0, fn::S(stream), n, S, raw, z, rays11,
-                     noise, white_bkgd, g_rgb, draw);
+                     noise, white_bkgd, g_rgb, draw, CompCfg{0, 1e-10f, 0, 1, 0}, (const float*)nullptr,
+                     (const float*)nullptr);
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -393,7 +430,7 @@ extern "C" int fastnerf_sample_pdf_merge(int64_t n, int S, int Ni, const float* 
   int NP = 1;
   while (NP < Ni) NP <<= 1;
   const size_t lds = (size_t)4 * (3 * S + NP) * sizeof(float);
-  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid_waves(n)), dim3(256), lds, fn::S(stream), n, S, Ni, NP, 0, z,
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid_waves(n)), dim3(256), lds, fn::S(stream), n, S, Ni, NP, 0, 0, z,
                      weights, det, u, seed, z_out, z_samples, z_std);
   FN_LAUNCH_CHECK();
   return 0;
@@ -408,8 +445,56 @@ extern "C" int fastnerf_sample_pdf(int64_t n, int M, int Ni, const float* bins, 
   while (NP < Ni) NP <<= 1;
   const int S = M + 1;
   const size_t lds = (size_t)4 * (3 * S + NP) * sizeof(float);
-  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid_waves(n)), dim3(256), lds, fn::S(stream), n, S, Ni, NP, 1,
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid_waves(n)), dim3(256), lds, fn::S(stream), n, S, Ni, NP, 1, 0,
                      bins, weights, det, u, seed, (float*)nullptr, samples, (float*)nullptr);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// nerf++ compositing (ddp_model.py:97-135): part 0 = foreground, part 1 = background
+// ---------------------------------------------------------------------------------------
+static inline CompCfg pp_cfg(int part) { return part == 0 ? CompCfg{1, 1e-6f, 1, 1, 0} : CompCfg{1, 1e-6f, 0, 0, 1}; }
+
+extern "C" int fastnerf_pp_composite_fwd(int64_t n, int S, int part, const float* raw, const float* z,
+                                         const float* rays11, const float* fg_far, float* rgb_map, float* weights,
+                                         float* depth, float* lambda, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 2 && S <= WAVE * MAXC && (part == 0 || part == 1), "n>=0, 2<=S<=512, part in {0,1}");
+  FN_CHECK_ARG(n == 0 || (raw && z && rays11 && rgb_map && (part == 1 || fg_far)), "null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(raw2outputs_fwd_kernel, dim3(grid_waves(n)), dim3(256), 0, fn::S(stream), n, S, raw, z, rays11,
+                     (const float*)nullptr, 0, rgb_map, (float*)nullptr, (float*)nullptr, weights, depth, pp_cfg(part),
+                     part == 0 ? fg_far : (const float*)nullptr, part == 0 ? lambda : (float*)nullptr);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fastnerf_pp_composite_bwd(int64_t n, int S, int part, const float* raw, const float* z,
+                                         const float* rays11, const float* fg_far, const float* g_rgb,
+                                         const float* g_lambda, float* draw, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 2 && S <= WAVE * MAXC && (part == 0 || part == 1), "n>=0, 2<=S<=512, part in {0,1}");
+  FN_CHECK_ARG(n == 0 || (raw && z && rays11 && g_rgb && draw && (part == 1 || fg_far)), "null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(raw2outputs_bwd_kernel, dim3(grid_waves(n)), dim3(256), 0, fn::S(stream), n, S, raw, z, rays11,
+                     (const float*)nullptr, 0, g_rgb, draw, pp_cfg(part), part == 0 ? fg_far : (const float*)nullptr,
+                     part == 0 ? g_lambda : (const float*)nullptr);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+// nerf++: sample_pdf on mid(z) / weights[1:-1] + sort(cat) (ddp_train_nerf.py:369-382)
+extern "C" int fastnerf_pp_sample_pdf_merge(int64_t n, int S, int Ni, const float* z, const float* weights, int det,
+                                            const float* u, uint64_t seed, float* z_out, float* z_samples,
+                                            fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 3 && S <= WAVE * MAXC && Ni >= 1 && Ni <= 1024, "n>=0, 3<=S<=512, 1<=Ni<=1024");
+  FN_CHECK_ARG(n == 0 || (z && weights && z_out), "null pointer");
+  if (n == 0) return 0;
+  int NP = 1;
+  while (NP < Ni) NP <<= 1;
+  const size_t lds = (size_t)4 * (3 * S + NP) * sizeof(float);
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid_waves(n)), dim3(256), lds, fn::S(stream), n, S, Ni, NP, 0, 1, z,
+                     weights, det, u, seed, z_out, z_samples, (float*)nullptr);
   FN_LAUNCH_CHECK();
   return 0;
 }

@@ -100,40 +100,63 @@ __global__ void __launch_bounds__(256) pack_kernel(PackTable tab, const float* _
   }
 }
 
-static PackTable make_pack_table() {
+static PackTable make_pack_table(const NetLayout& L) {
   PackTable T;
   int n = 0;
   for (int l = 0; l < 8; ++l) {
     PackDesc d{};
-    d.src_off = L_W(l); d.dst_off = PF_OFF(l); d.ld = L_K(l); d.n_rows = 256; d.n_cols = PF_KP(l);
-    if (l == 0) { d.segA_pad = 64; d.segA_valid = 63; d.segB_valid = 0; }
-    else if (l == 5) { d.segA_pad = 64; d.segA_valid = 63; d.segB_valid = 256; }
+    d.src_off = L.LW[l]; d.dst_off = L.PF[l]; d.n_rows = 256;
+    d.ld = (l == 0) ? L.in_pe : (l == 5 ? 256 + L.in_pe : 256);
+    d.n_cols = (l == 0) ? L.pe_pad : (l == 5 ? L.pe_pad + 256 : 256);
+    if (l == 0) { d.segA_pad = L.pe_pad; d.segA_valid = L.in_pe; d.segB_valid = 0; }
+    else if (l == 5) { d.segA_pad = L.pe_pad; d.segA_valid = L.in_pe; d.segB_valid = 256; }
     else { d.segA_pad = 256; d.segA_valid = 256; d.segB_valid = 0; }
     T.d[n++] = d;
   }
-  { PackDesc d{}; d.src_off = F_W; d.dst_off = PF_OFF(8); d.ld = 256; d.n_rows = 256; d.n_cols = 256;
+  { PackDesc d{}; d.src_off = L.FW; d.dst_off = L.PF[8]; d.ld = 256; d.n_rows = 256; d.n_cols = 256;
     d.segA_pad = 256; d.segA_valid = 256; T.d[n++] = d; }
-  { PackDesc d{}; d.src_off = V_W; d.dst_off = PF_OFF(9); d.ld = 283; d.n_rows = 128; d.n_cols = 288;
+  { PackDesc d{}; d.src_off = L.VW; d.dst_off = L.PF[9]; d.ld = 283; d.n_rows = 128; d.n_cols = 288;
     d.segA_pad = 256; d.segA_valid = 256; d.segB_valid = 27; T.d[n++] = d; }
-  // transposed: views(feat part), feature, pts 7,6,5(h part),4,3,2,1
-  { PackDesc d{}; d.transposed = 1; d.src_off = V_W; d.dst_off = PB_OFF(0); d.ld = 283; d.n_rows = 128; d.n_cols = 256; d.col0 = 0; T.d[n++] = d; }
-  { PackDesc d{}; d.transposed = 1; d.src_off = F_W; d.dst_off = PB_OFF(1); d.ld = 256; d.n_rows = 256; d.n_cols = 256; d.col0 = 0; T.d[n++] = d; }
+  // transposed: views(feat part), feature, trunk 7,6,5(h part),4,3,2,1
+  { PackDesc d{}; d.transposed = 1; d.src_off = L.VW; d.dst_off = L.PB[0]; d.ld = 283; d.n_rows = 128; d.n_cols = 256; d.col0 = 0; T.d[n++] = d; }
+  { PackDesc d{}; d.transposed = 1; d.src_off = L.FW; d.dst_off = L.PB[1]; d.ld = 256; d.n_rows = 256; d.n_cols = 256; d.col0 = 0; T.d[n++] = d; }
   const int order[7] = {7, 6, 5, 4, 3, 2, 1};
   for (int j = 0; j < 7; ++j) {
     const int l = order[j];
-    PackDesc d{}; d.transposed = 1; d.src_off = L_W(l); d.dst_off = PB_OFF(2 + j); d.ld = L_K(l); d.n_rows = 256; d.n_cols = 256;
-    d.col0 = (l == 5) ? 63 : 0;
+    PackDesc d{}; d.transposed = 1; d.src_off = L.LW[l]; d.dst_off = L.PB[2 + j]; d.n_rows = 256; d.n_cols = 256;
+    d.ld = (l == 5) ? 256 + L.in_pe : 256;
+    d.col0 = (l == 5) ? L.in_pe : 0;
     T.d[n++] = d;
   }
   return T;
 }
 
-extern "C" int fastnerf_mlp_pack(const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream) {
-  FN_CHECK_ARG(params && packed_fwd && packed_bwd, "null pointer");
-  static const PackTable T = make_pack_table();
-  hipLaunchKernelGGL(pack_kernel, dim3(64, 19), dim3(256), 0, fn::S(stream), T, params, packed_fwd, packed_bwd);
+static const NetLayout& layout_of(int kind) {
+  static const NetLayout L[3] = {make_layout(0), make_layout(1), make_layout(2)};
+  return L[kind < 0 || kind > 2 ? 0 : kind];
+}
+
+extern "C" int64_t fastnerf_net_floats(int kind, int what) {
+  if (kind < 0 || kind > 2) return -1;
+  const NetLayout& L = layout_of(kind);
+  return what == 0 ? L.n_params : what == 1 ? L.pf_total : what == 2 ? L.pb_total : what == 3 ? L.pe_pad : -1;
+}
+extern "C" int64_t fastnerf_mlp_act_floats(int kind, int64_t P) {
+  if (kind < 0 || kind > 2 || P < 0) return -1;
+  return act_floats(P, layout_of(kind).pe_pad);
+}
+
+extern "C" int fastnerf_mlp_pack_ex(int kind, const float* params, float* packed_fwd, float* packed_bwd,
+                                    fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && params && packed_fwd && packed_bwd, "kind in 0..2, non-null pointers");
+  static const PackTable T[3] = {make_pack_table(layout_of(0)), make_pack_table(layout_of(1)),
+                                 make_pack_table(layout_of(2))};
+  hipLaunchKernelGGL(pack_kernel, dim3(64, 19), dim3(256), 0, fn::S(stream), T[kind], params, packed_fwd, packed_bwd);
   FN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int fastnerf_mlp_pack(const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream) {
+  return fastnerf_mlp_pack_ex(0, params, packed_fwd, packed_bwd, stream);
 }
 
 // =========================================================================================
@@ -162,7 +185,9 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 // tile's activations -- which this very loop reads from LDS -- are also streamed to HBM as whole
 // 1 KiB rows (one ds_read_b128 + one global_store_dwordx4 per lane per two k-steps), instead of 64
 // dword stores per wave in the epilogue that produced them.
-template <int NT, bool A_IS_E>
+// AMODE: 0 = H layout (256 floats/row), 1 = E layout (64 floats/row), 2 = X2 (32 floats/row, the
+// extra PE channels 64..95 of the 4-D background encoding)
+template <int NT, int AMODE>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks,
                                          const float4* __restrict__ Bp, int KS, int b_ks0, int nt0, int wm, int lane,
                                          int dbg = 0, float* __restrict__ save_dst = nullptr, int save_valid = 0,
@@ -174,8 +199,8 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __re
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int m = wm * 64 + mt * 32 + lrow;
-    arow[mt] = As + m * (A_IS_E ? 64 : 256);
-    axor[mt] = m & 15;
+    arow[mt] = As + m * (AMODE == 0 ? 256 : (AMODE == 1 ? 64 : 32));
+    axor[mt] = (AMODE == 2) ? ((m >> 1) & 7) : (m & 15);
   }
   const float4* bptr[NT];
 #pragma unroll
@@ -210,7 +235,7 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __re
     }
   };
   auto side_copy = [&]() {
-    if (!A_IS_E && save_dst != nullptr) {
+    if (AMODE == 0 && save_dst != nullptr) {
       // every load of this loop already issued: stream the tile's rows out in one burst.  (vmcnt
       // retires in order, so a store issued earlier in the loop would sit in front of later weight
       // loads and stall their waits for a full HBM write round trip.)
@@ -329,34 +354,86 @@ __device__ __forceinline__ void stagger_start() {
 // =========================================================================================
 // forward
 // =========================================================================================
-template <bool SAVE>
+// inverted-sphere background point (x', y', z', 1/r) of nerf++ (ddp_model.py:16-45)
+__device__ __forceinline__ void bg_point(const float* __restrict__ o, const float* __restrict__ d, float depth,
+                                         float x[4]) {
+  const float dd = fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2]));
+  const float od = fadd(fadd(fmul(d[0], o[0]), fmul(d[1], o[1])), fmul(d[2], o[2]));
+  const float d1 = -od / dd;
+  float pm_[3], ps[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pm_[c] = fadd(o[c], fmul(d1, d[c]));
+  const float pmn = sqrtf(fadd(fadd(fmul(pm_[0], pm_[0]), fmul(pm_[1], pm_[1])), fmul(pm_[2], pm_[2])));
+  const float dcos = 1.0f / sqrtf(dd);
+  const float d2 = fmul(sqrtf(fsub(1.0f, fmul(pmn, pmn))), dcos);
+  const float d12 = fadd(d1, d2);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ps[c] = fadd(o[c], fmul(d12, d[c]));
+  float ax[3] = {fsub(fmul(o[1], ps[2]), fmul(o[2], ps[1])), fsub(fmul(o[2], ps[0]), fmul(o[0], ps[2])),
+                 fsub(fmul(o[0], ps[1]), fmul(o[1], ps[0]))};
+  const float an = sqrtf(fadd(fadd(fmul(ax[0], ax[0]), fmul(ax[1], ax[1])), fmul(ax[2], ax[2])));
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ax[c] = ax[c] / an;
+  const float ang = fsub(asinf(pmn), asinf(fmul(pmn, depth)));
+  const float ca = cosf(ang), sa = sinf(ang);
+  const float cr[3] = {fsub(fmul(ax[1], ps[2]), fmul(ax[2], ps[1])), fsub(fmul(ax[2], ps[0]), fmul(ax[0], ps[2])),
+                       fsub(fmul(ax[0], ps[1]), fmul(ax[1], ps[0]))};
+  const float dot = fadd(fadd(fmul(ax[0], ps[0]), fmul(ax[1], ps[1])), fmul(ax[2], ps[2]));
+  const float omc = fsub(1.0f, ca);
+  float pn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pn[c] = fadd(fadd(fmul(ps[c], ca), fmul(cr[c], sa)), fmul(fmul(ax[c], dot), omc));
+  const float nn = sqrtf(fadd(fadd(fmul(pn[0], pn[0]), fmul(pn[1], pn[1])), fmul(pn[2], pn[2])));
+  x[0] = pn[0] / nn; x[1] = pn[1] / nn; x[2] = pn[2] / nn; x[3] = depth;
+}
+
+__device__ __forceinline__ int x2idx(int m, int k) { return m * 32 + ((((k >> 2) ^ ((m >> 1) & 7)) << 2) | (k & 3)); }
+
+// BG == false: points o + d*z with the 3-D encoding (63 channels -> E).
+// BG == true : nerf++ background net: inverted-sphere points (4-D), samples in flipped order
+//              (ddp_model.py:118-124), 84 channels = 64 in E + 20 (padded to 32) in the X2 block that
+//              borrows the first 8 KiB of H while H is free (L0) or after it has been consumed (L5).
+template <bool SAVE, bool BG>
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                const float* __restrict__ params, const float* __restrict__ packed, float* __restrict__ raw,
-               float* __restrict__ act, int dbg) {
+               float* __restrict__ act, NetLayout lay) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;
   float* Es = smem + LDS_H;
+  float* X2 = smem;   // [TM][32], aliases the head of H (BG only)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const float4* pk = reinterpret_cast<const float4*>(packed);
   const int64_t ntiles = (P + TM - 1) / TM;
+  const int PEP = BG ? 96 : 64;
+  const int dbg = 0;
   stagger_start();
 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     unsigned long long* maskw =
-        SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(P)) + tile * (8 * NWAVES * 64) : nullptr;
-    // ---- phase A: points + positional encoding -> Es ---------------------------------
+        SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(P, PEP)) + tile * (8 * NWAVES * 64) : nullptr;
+    // ---- phase A: points + positional encoding -> Es (+ X2) ---------------------------
     const int pm = tid >> 2, pq = tid & 3;
     int64_t pp = p0 + pm;
     if (pp >= P) pp = P - 1;
     const int64_t ray = pp / S;
     const float* rr = rays + ray * 11;
-    {
+    float x4[4] = {0.f, 0.f, 0.f, 0.f};   // BG: kept live for the L5 re-encode of channels 64..83
+    auto write_x2 = [&]() {               // channels 64..95 of the 4-D encoding, dimension pq of row pm
+      const float xv = x4[pq];
+      X2[x2idx(pm, 0 + pq)] = cosf(fmul(xv, 128.0f));
+      X2[x2idx(pm, 4 + pq)] = sinf(fmul(xv, 256.0f));
+      X2[x2idx(pm, 8 + pq)] = cosf(fmul(xv, 256.0f));
+      X2[x2idx(pm, 12 + pq)] = sinf(fmul(xv, 512.0f));
+      X2[x2idx(pm, 16 + pq)] = cosf(fmul(xv, 512.0f));
+      X2[x2idx(pm, 20 + pq)] = 0.f; X2[x2idx(pm, 24 + pq)] = 0.f; X2[x2idx(pm, 28 + pq)] = 0.f;
+    };
+    if (!BG) {
       const float zz = zv[pp];
       float x[3];
 #pragma unroll
@@ -371,22 +448,48 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         Es[eidx(pm, 3 + 6 * k + dim)] = sinf(a);
         Es[eidx(pm, 6 + 6 * k + dim)] = cosf(a);
       }
+    } else {
+      const int sidx = (int)(pp - ray * S);
+      const float zz = zv[ray * S + (S - 1 - sidx)];   // flipped sample order
+      bg_point(rr, rr + 3, zz, x4);
+      const float xv = x4[pq];
+      Es[eidx(pm, pq)] = xv;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float a = fmul(xv, (float)(1 << k));
+        Es[eidx(pm, 4 + 8 * k + pq)] = sinf(a);
+        Es[eidx(pm, 8 + 8 * k + pq)] = cosf(a);
+      }
+      Es[eidx(pm, 60 + pq)] = sinf(fmul(xv, 128.0f));
+      write_x2();
     }
     __syncthreads();
     if (SAVE) {
-      float* ape = act + act_pe(P) + p0 * 64;
+      float* ape = act + act_pe(P, PEP) + p0 * PEP;
       for (int i = tid; i < TM * 16; i += NTHR) {
         const int m = i >> 4, sl = i & 15;
         if (m < valid)
-          store_nt(ape + m * 64 + sl * 4, *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2)));
+          store_nt(ape + m * PEP + sl * 4, *reinterpret_cast<const float4*>(Es + m * 64 + ((sl ^ (m & 15)) << 2)));
+      }
+      if (BG) {
+        for (int i = tid; i < TM * 8; i += NTHR) {
+          const int m = i >> 3, sl = i & 7;
+          if (m < valid)
+            store_nt(ape + m * PEP + 64 + sl * 4,
+                     *reinterpret_cast<const float4*>(X2 + m * 32 + ((sl ^ ((m >> 1) & 7)) << 2)));
+        }
       }
     }
     f32x16 acc[2][2];
-    // ---- L0 : pe64 -> 256 -------------------------------------------------------------
+    // ---- L0 : pe -> 256 -----------------------------------------------------------------
     zero_acc<2>(acc);
     float bv2[2];
-    load_bias<2>(bv2, params + L_B(0), wn, lane);
-    gemm_seg<2, true>(acc, Es, 0, 8, pk + PF_OFF(0) / 4, 8, 0, wn * 2, wm, lane, dbg);
+    load_bias<2>(bv2, params + lay.LB[0], wn, lane);
+    gemm_seg<2, 1>(acc, Es, 0, 8, pk + lay.PF[0] / 4, PEP / 8, 0, wn * 2, wm, lane, dbg);
+    if (BG) {
+      gemm_seg<2, 2>(acc, X2, 0, 4, pk + lay.PF[0] / 4, PEP / 8, 8, wn * 2, wm, lane, dbg);
+      __syncthreads();   // X2 lives in H: everyone must be done with it before H is written
+    }
     epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
                           SAVE ? maskw + (0 * NWAVES + wave) * 64 : nullptr);
     __syncthreads();
@@ -394,21 +497,24 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
       zero_acc<2>(acc);
-      int64_t off, boff;
-      switch (l) {
-        case 1: off = PF_OFF(1); boff = L_B(1); break; case 2: off = PF_OFF(2); boff = L_B(2); break;
-        case 3: off = PF_OFF(3); boff = L_B(3); break; case 4: off = PF_OFF(4); boff = L_B(4); break;
-        case 5: off = PF_OFF(5); boff = L_B(5); break; case 6: off = PF_OFF(6); boff = L_B(6); break;
-        default: off = PF_OFF(7); boff = L_B(7); break;
-      }
-      const float4* B = pk + off / 4;
-      load_bias<2>(bv2, params + boff, wn, lane);
-      float* sv = SAVE ? act + act_h(P, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
+      const float4* B = pk + lay.PF[l] / 4;
+      load_bias<2>(bv2, params + lay.LB[l], wn, lane);
+      float* sv = SAVE ? act + act_h(P, PEP, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
       if (l == 5) {
-        gemm_seg<2, true>(acc, Es, 0, 8, B, 40, 0, wn * 2, wm, lane, dbg);
-        gemm_seg<2, false>(acc, Hs, 0, 32, B, 40, 8, wn * 2, wm, lane, dbg, sv, valid, wave);
+        const int KS5 = (PEP + 256) / 8;
+        if (!BG) {
+          gemm_seg<2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
+          gemm_seg<2, 0>(acc, Hs, 0, 32, B, KS5, 8, wn * 2, wm, lane, dbg, sv, valid, wave);
+        } else {
+          gemm_seg<2, 0>(acc, Hs, 0, 32, B, KS5, 12, wn * 2, wm, lane, dbg, sv, valid, wave);
+          __syncthreads();   // h4 consumed: its first 8 KiB become X2 again
+          write_x2();
+          __syncthreads();
+          gemm_seg<2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
+          gemm_seg<2, 2>(acc, X2, 0, 4, B, KS5, 8, wn * 2, wm, lane, dbg);
+        }
       } else {
-        gemm_seg<2, false>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
+        gemm_seg<2, 0>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
       }
       __syncthreads();  // every wave has finished reading H
       epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
@@ -418,7 +524,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     // ---- alpha head (VALU) + view-direction encoding -> Es ---------------------------
     float alpha_val = 0.f;
     {
-      const float* wa = params + A_W;
+      const float* wa = params + lay.AW;
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -429,7 +535,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       }
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
-      alpha_val = s + params[A_B];
+      alpha_val = s + params[lay.AB];
       float v[3] = {rr[8], rr[9], rr[10]};
       if (pq == 0) {
         Es[eidx(pm, 0)] = v[0]; Es[eidx(pm, 1)] = v[1]; Es[eidx(pm, 2)] = v[2];
@@ -445,14 +551,14 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     }
     // ---- feature layer (no ReLU) ------------------------------------------------------
     zero_acc<2>(acc);
-    load_bias<2>(bv2, params + F_B, wn, lane);
-    gemm_seg<2, false>(acc, Hs, 0, 32, pk + PF_OFF(8) / 4, 32, 0, wn * 2, wm, lane, dbg,
-                       SAVE ? act + act_h(P, 7) + p0 * 256 : nullptr, valid, wave);
+    load_bias<2>(bv2, params + lay.FB, wn, lane);
+    gemm_seg<2, 0>(acc, Hs, 0, 32, pk + lay.PF[8] / 4, 32, 0, wn * 2, wm, lane, dbg,
+                   SAVE ? act + act_h(P, PEP, 7) + p0 * 256 : nullptr, valid, wave);
     __syncthreads();
     epilogue_fwd<2, false>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
     __syncthreads();
     if (SAVE) {
-      float* avp = act + act_vpe(P) + p0 * 32;
+      float* avp = act + act_vpe(P, PEP) + p0 * 32;
       for (int i = tid; i < TM * 8; i += NTHR) {
         const int m = i >> 3, sl = i & 7;
         if (m < valid)
@@ -464,15 +570,15 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       f32x16 av[2][1];
       zero_acc<1>(av);
       float bv1[1];
-      load_bias<1>(bv1, params + V_B, wn, lane);
-      gemm_seg<1, false>(av, Hs, 0, 32, pk + PF_OFF(9) / 4, 36, 0, wn, wm, lane, dbg,
-                         SAVE ? act + act_feat(P) + p0 * 256 : nullptr, valid, wave);
-      gemm_seg<1, true>(av, Es, 0, 4, pk + PF_OFF(9) / 4, 36, 32, wn, wm, lane, dbg);
+      load_bias<1>(bv1, params + lay.VB, wn, lane);
+      gemm_seg<1, 0>(av, Hs, 0, 32, pk + lay.PF[9] / 4, 36, 0, wn, wm, lane, dbg,
+                     SAVE ? act + act_feat(P, PEP) + p0 * 256 : nullptr, valid, wave);
+      gemm_seg<1, 1>(av, Es, 0, 4, pk + lay.PF[9] / 4, 36, 32, wn, wm, lane, dbg);
       __syncthreads();
       epilogue_fwd<1, true>(av, bv1, Hs, wm, wn, lane, nullptr, 128, valid);
       __syncthreads();
       if (SAVE) {   // hv: 32 slots per row, whole 512-byte rows per half wave
-        float* ahv = act + act_hv(P) + p0 * 128;
+        float* ahv = act + act_hv(P, PEP) + p0 * 128;
         for (int i = tid; i < TM * 32; i += NTHR) {
           const int m = i >> 5, sl = i & 31;
           if (m < valid)
@@ -482,7 +588,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     }
     // ---- rgb head (VALU) + output -------------------------------------------------------
     {
-      const float* wr = params + R_W;
+      const float* wr = params + lay.RW;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -500,7 +606,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
       if (pq == 0 && pm < valid) {
         float4 o;
-        o.x = s0 + params[R_B]; o.y = s1 + params[R_B + 1]; o.z = s2 + params[R_B + 2]; o.w = alpha_val;
+        o.x = s0 + params[lay.RB]; o.y = s1 + params[lay.RB + 1]; o.z = s2 + params[lay.RB + 2]; o.w = alpha_val;
         *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
       }
     }
@@ -508,36 +614,43 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
   }
 }
 
-extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const float* z, const float* params,
-                                const float* packed_fwd, float* raw, float* act, fn_stream_t stream) {
-  FN_CHECK_ARG(n >= 0 && S >= 1, "n>=0, S>=1");
+extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const float* z,
+                                   const float* params, const float* packed_fwd, float* raw, float* act,
+                                   fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
   FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
   if (n == 0) return 0;
+  const NetLayout& lay = layout_of(kind);
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
   int grid = num_cus() * WG_PER_CU;
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<true>),
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<true, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<false>),
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<false, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done = true;
   }
-  static int dbg = -1;
-  if (dbg < 0) {
-    const char* e = getenv("FASTNERF_DBG");   // profiling ablations only; 0 in production
-    dbg = e ? atoi(e) : 0;
+  hipStream_t st = fn::S(stream);
+  if (kind == 2) {
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
+  } else {
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
   }
-  if (act)
-    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, fn::S(stream), P, S, rays11, z, params,
-                       packed_fwd, raw, act, dbg);
-  else
-    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, fn::S(stream), P, S, rays11, z,
-                       params, packed_fwd, raw, act, dbg);
   FN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const float* z, const float* params,
+                                const float* packed_fwd, float* raw, float* act, fn_stream_t stream) {
+  return fastnerf_mlp_fwd_ex(0, n, S, rays11, z, params, packed_fwd, raw, act, stream);
 }
 
 // =========================================================================================
@@ -601,7 +714,8 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
 
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __restrict__ act,
-                  const float* __restrict__ params, const float* __restrict__ packed_t, float* __restrict__ dact) {
+                  const float* __restrict__ params, const float* __restrict__ packed_t, float* __restrict__ dact,
+                  NetLayout lay) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;
   float* Es = smem + LDS_H;  // Es[0..127] = dalpha of the tile's rows
@@ -617,7 +731,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     const unsigned long long* maskw =
-        reinterpret_cast<const unsigned long long*>(act + act_mask(P)) + tile * (8 * NWAVES * 64);
+        reinterpret_cast<const unsigned long long*>(act + act_mask(P, lay.pe_pad)) + tile * (8 * NWAVES * 64);
     // ---- phase A: dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] --------------------------
     {
       const int pm = tid >> 2, pq = tid & 3;
@@ -625,8 +739,8 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       const int64_t pp = ok ? p0 + pm : P - 1;
       const float4 dr = *reinterpret_cast<const float4*>(draw + pp * 4);
       if (pq == 0) Es[pm] = ok ? dr.w : 0.f;
-      const float* wr = params + R_W;
-      const float* hv = act + act_hv(P) + pp * 128;
+      const float* wr = params + lay.RW;
+      const float* hv = act + act_hv(P, lay.pe_pad) + pp * 128;
       float* dyv = dact + dact_yv(P) + pp * 128;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -649,7 +763,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     f32x16 acc[2][2];
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ------------------------------------------
     zero_acc<2>(acc);
-    gemm_seg<2, false>(acc, Hs, 0, 16, pk + PB_OFF(0) / 4, 16, 0, wn * 2, wm, lane);
+    gemm_seg<2, 0>(acc, Hs, 0, 16, pk + lay.PB[0] / 4, 16, 0, wn * 2, wm, lane);
     __syncthreads();
     epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
                               valid);
@@ -657,8 +771,8 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ------------------------------------
     zero_acc<2>(acc);
     {
-      const DxPre pre = dx_preload<true, true>(maskw + (7 * NWAVES + wave) * 64, params + A_W, wn, lane);
-      gemm_seg<2, false>(acc, Hs, 0, 32, pk + PB_OFF(1) / 4, 32, 0, wn * 2, wm, lane, 0,
+      const DxPre pre = dx_preload<true, true>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
+      gemm_seg<2, 0>(acc, Hs, 0, 32, pk + lay.PB[1] / 4, 32, 0, wn * 2, wm, lane, 0,
                          dact + dact_feat(P) + p0 * 256, valid, wave);    // streams dfeat (what it reads) out
       __syncthreads();
       epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
@@ -667,15 +781,10 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     // ---- dY_{l-1} = (dY_l . W_l) * [h_{l-1} > 0],  l = 7..1 ------------------------------
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
-      int64_t off;
-      switch (l) {
-        case 7: off = PB_OFF(2); break; case 6: off = PB_OFF(3); break; case 5: off = PB_OFF(4); break;
-        case 4: off = PB_OFF(5); break; case 3: off = PB_OFF(6); break; case 2: off = PB_OFF(7); break;
-        default: off = PB_OFF(8); break;
-      }
+      const int64_t off = lay.PB[9 - l];   // PB[2] = L7t ... PB[8] = L1t
       zero_acc<2>(acc);
       const DxPre pre = dx_preload<true, false>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
-      gemm_seg<2, false>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane, 0,
+      gemm_seg<2, 0>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane, 0,
                          dact + dact_y(P, l) + p0 * 256, valid, wave);    // streams dY_l (what it reads) out
       __syncthreads();
       epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
@@ -918,29 +1027,30 @@ __global__ void __launch_bounds__(256) reduce_all_kernel(RedTable tab, const flo
   }
 }
 
-// dW jobs of one net: id, NO, KI, bias?, rank1?
+// dW jobs of one net: NO, KI, bias?, rank1?   (KI of the two pe jobs = the layout's pe_pad)
 struct DwJobDesc { int NO, KI, bias, rank1; };
-static const DwJobDesc DW_JOBS[12] = {
-    {256, 64, 1, 0},                                                                      // 0: L0 (pe)
-    {256, 256, 1, 0}, {256, 256, 1, 0}, {256, 256, 1, 0}, {256, 256, 1, 0},               // 1..4: L1..L4
-    {256, 256, 1, 0}, {256, 256, 1, 0}, {256, 256, 1, 0},                                 // 5..7: L5(h)..L7
-    {256, 64, 0, 0},                                                                      // 8: L5 (pe)
-    {256, 256, 1, 1},                                                                     // 9: feature (+alpha row)
-    {128, 256, 1, 0},                                                                     // 10: views (feat part)
-    {128, 32, 0, 0},                                                                      // 11: views (vpe part)
-};
-#define HEAD_MAX_WG 1024
-static int64_t dw_job_floats(int j) {
-  return (int64_t)DW_JOBS[j].NO * DW_JOBS[j].KI + (DW_JOBS[j].bias ? DW_JOBS[j].NO : 0) +
-         (DW_JOBS[j].rank1 ? DW_JOBS[j].KI : 0);
+static DwJobDesc dw_job(int j, int pe_pad) {
+  switch (j) {
+    case 0: return {256, pe_pad, 1, 0};     // L0 (pe)
+    case 8: return {256, pe_pad, 0, 0};     // L5 (pe part)
+    case 9: return {256, 256, 1, 1};        // feature / remap (+ alpha / sigma row)
+    case 10: return {128, 256, 1, 0};       // view layer (feature part)
+    case 11: return {128, 32, 0, 0};        // view layer (vpe part)
+    default: return {256, 256, 1, 0};       // 1..7: L1..L7 (h part)
+  }
 }
-static int64_t dw_job_base(int j, int ncu) {
+#define HEAD_MAX_WG 1024
+static int64_t dw_job_floats(int j, int pe_pad) {
+  const DwJobDesc d = dw_job(j, pe_pad);
+  return (int64_t)d.NO * d.KI + (d.bias ? d.NO : 0) + (d.rank1 ? d.KI : 0);
+}
+static int64_t dw_job_base(int j, int ncu, int pe_pad) {
   int64_t o = 0;
-  for (int i = 0; i < j; ++i) o += dw_job_floats(i) * ncu;
+  for (int i = 0; i < j; ++i) o += dw_job_floats(i, pe_pad) * ncu;
   return o;
 }
 extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
-  return dw_job_base(12, num_cus()) + (int64_t)HEAD_MAX_WG * 388;
+  return dw_job_base(12, num_cus(), 96) + (int64_t)HEAD_MAX_WG * 388;   // sized for the widest layout
 }
 
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
@@ -970,11 +1080,13 @@ static void add_seg(RedTable& T, int64_t src, int64_t wg_stride, int nwg, int ro
   s.valid_cols = valid_cols;
 }
 
-extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float* act, const float* params,
-                                const float* packed_bwd, float* dact, float* partial, float* grads,
-                                fn_stream_t stream) {
-  FN_CHECK_ARG(n > 0 && S >= 1, "n>0, S>=1");
+extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const float* act,
+                                   const float* params, const float* packed_bwd, float* dact, float* partial,
+                                   float* grads, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads, "null pointer");
+  const NetLayout& L = layout_of(kind);
+  const int PEP = L.pe_pad;
   hipStream_t st = fn::S(stream);
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
@@ -987,7 +1099,7 @@ extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done = true;
   }
-  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact);
+  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L);
   FN_LAUNCH_CHECK();
 
   // ---- dW jobs: every job writes per-workgroup partials into its own region ------------------
@@ -997,49 +1109,56 @@ extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float
   RedTable T;
   T.n = 0;
   int rc;
-  const float* a_pe = act + act_pe(P);
-  auto region = [&](int j) { return partial + dw_job_base(j, ncu); };
+  const float* a_pe = act + act_pe(P, PEP);
+  auto region = [&](int j) { return partial + dw_job_base(j, ncu, PEP); };
   auto segs = [&](int j, int64_t dstW, int ld, int validc, int64_t dstB, int64_t dstR) {
-    const DwJobDesc& d = DW_JOBS[j];
-    const int64_t b = dw_job_base(j, ncu);
+    const DwJobDesc d = dw_job(j, PEP);
+    const int64_t b = dw_job_base(j, ncu, PEP);
     add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc);
     int64_t o = b + (int64_t)nwg * d.NO * d.KI;
     if (d.bias) { add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO); o += (int64_t)nwg * d.NO; }
     if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
   };
   // L0
-  if ((rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st))) return rc;
-  segs(0, L_W(0), 63, 63, L_B(0), 0);
+  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st);
+  else rc = launch_dw<4, 1, 2, 3, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st);
+  if (rc) return rc;
+  segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
   // L1..L7 (h part)
-  const int64_t woffs[8] = {L_W(0), L_W(1), L_W(2), L_W(3), L_W(4), L_W(5), L_W(6), L_W(7)};
-  const int64_t boffs[8] = {L_B(0), L_B(1), L_B(2), L_B(3), L_B(4), L_B(5), L_B(6), L_B(7)};
   for (int l = 1; l < 8; ++l) {
-    if ((rc = launch_dw<4, 2, 2, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, l - 1), 256, nullptr, region(l), nwg, st))) return rc;
-    segs(l, woffs[l] + (l == 5 ? 63 : 0), l == 5 ? 319 : 256, 256, boffs[l], 0);
+    if ((rc = launch_dw<4, 2, 2, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st))) return rc;
+    segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
   }
   // L5 pe part
-  if ((rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st))) return rc;
-  segs(8, L_W(5), 319, 63, 0, 0);
-  // feature layer (+bias) with the alpha head as a rank-1 row
-  if ((rc = launch_dw<4, 2, 2, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, 7), 256, draw, region(9), nwg, st))) return rc;
-  segs(9, F_W, 256, 256, F_B, A_W);
+  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st);
+  else rc = launch_dw<4, 1, 2, 3, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st);
+  if (rc) return rc;
+  segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
+  // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
+  if ((rc = launch_dw<4, 2, 2, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st))) return rc;
+  segs(9, L.FW, 256, 256, L.FB, L.AW);
   // view layer
-  if ((rc = launch_dw<2, 4, 2, 2, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P), 256, nullptr, region(10), nwg, st))) return rc;
-  segs(10, V_W, 283, 256, V_B, 0);
-  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P), 32, nullptr, region(11), nwg, st))) return rc;
-  segs(11, V_W + 256, 283, 27, 0, 0);
+  if ((rc = launch_dw<2, 4, 2, 2, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st))) return rc;
+  segs(10, L.VW, 283, 256, L.VB, 0);
+  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st))) return rc;
+  segs(11, L.VW + 256, 283, 27, 0, 0);
   // rgb head + alpha bias
   {
     int64_t hg64 = (P + 255) / 256;
     int hg = (int)(hg64 > HEAD_MAX_WG ? HEAD_MAX_WG : hg64);
     if (hg < 1) hg = 1;
-    const int64_t hb = dw_job_base(12, ncu);
-    hipLaunchKernelGGL(head_grads_kernel, dim3(hg), dim3(128), 0, st, P, draw, act + act_hv(P), partial + hb);
+    const int64_t hb = dw_job_base(12, ncu, PEP);
+    hipLaunchKernelGGL(head_grads_kernel, dim3(hg), dim3(128), 0, st, P, draw, act + act_hv(P, PEP), partial + hb);
     FN_LAUNCH_CHECK();
-    add_seg(T, hb, 388, hg, 1, 388, R_W, 388, 387);   // dWr (384) + dbr (3), contiguous in the flat layout
-    add_seg(T, hb + 387, 388, hg, 1, 1, A_B, 1, 1);   // dba
+    add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387);   // dWr (384) + dbr (3), contiguous in every layout
+    add_seg(T, hb + 387, 388, hg, 1, 1, L.AB, 1, 1);   // dba
   }
   hipLaunchKernelGGL(reduce_all_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
   FN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float* act, const float* params,
+                                const float* packed_bwd, float* dact, float* partial, float* grads,
+                                fn_stream_t stream) {
+  return fastnerf_mlp_bwd_ex(0, n, S, draw, act, params, packed_bwd, dact, partial, grads, stream);
 }

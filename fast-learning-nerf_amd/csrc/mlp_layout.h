@@ -1,66 +1,64 @@
-// mlp_layout.h -- parameter / packed-weight / activation layouts of the 8x256 NeRF MLP
-// (model.py:8-63 with D=8, W=256, skips=[4], use_viewdirs=True, input_ch=63, input_ch_views=27).
+// mlp_layout.h -- parameter / packed-weight / activation layouts of the 8x256 MLPs on the hot path.
+//
+// kind 0: NeRF            (nerf-ours/model.py:8-63,     input PE 63, parameters() order
+//                          pts_linears.*, views_linears.0, feature_linear, alpha_linear, rgb_linear)
+// kind 1: MLPNet fg       (nerf++-ours/nerf_network.py:70-142, input PE 63, order base_layers.*,
+//                          sigma_layers.0, base_remap_layers.0, rgb_layers.0, rgb_layers.2)
+// kind 2: MLPNet bg       (same, input PE 84 = 4-D inverted-sphere point)
+// All three share the structure  L0..L7 (skip into L5) -> {sigma/alpha, remap/feature} -> view layer -> rgb.
 #pragma once
 #include <stdint.h>
 
 namespace fnl {
-constexpr int W = 256, WH = 128, IN_PE = 63, IN_PEP = 64, IN_V = 27, IN_VP = 32;
+struct NetLayout {
+  int64_t LW[8], LB[8];                    // trunk weights / biases (flat offsets, [out][in] row-major)
+  int64_t VW, VB, FW, FB, AW, AB, RW, RB;  // view layer, feature/remap, alpha/sigma, rgb
+  int64_t PF[10], PB[9];                   // packed (fragment order) offsets: fwd L0..L7,F,V ; bwd Vt,Ft,L7t..L1t
+  int64_t n_params, pf_total, pb_total;
+  int in_pe, pe_pad;                       // 63 -> 64, 84 -> 96
+  int kind;
+};
 
-// ---- flat parameter buffer: model.parameters() order, native [out][in] row-major ----
-constexpr int64_t L_W(int i) {  // pts_linears.i.weight
-  return i == 0 ? 0
-       : i <= 5 ? (int64_t)(IN_PE * W + W) + (int64_t)(i - 1) * (W * W + W)
-                : (int64_t)(IN_PE * W + W) + 4 * (int64_t)(W * W + W) + (int64_t)((W + IN_PE) * W + W) +
-                      (int64_t)(i - 6) * (W * W + W);
-}
-constexpr int L_K(int i) { return i == 0 ? IN_PE : (i == 5 ? W + IN_PE : W); }  // fan-in
-constexpr int64_t L_B(int i) { return L_W(i) + (int64_t)W * L_K(i); }
-constexpr int64_t V_W = L_B(7) + W;                       // views_linears.0.weight [128][283]
-constexpr int64_t V_B = V_W + (int64_t)WH * (W + IN_V);
-constexpr int64_t F_W = V_B + WH;                         // feature_linear.weight [256][256]
-constexpr int64_t F_B = F_W + (int64_t)W * W;
-constexpr int64_t A_W = F_B + W;                          // alpha_linear.weight [1][256]
-constexpr int64_t A_B = A_W + W;
-constexpr int64_t R_W = A_B + 1;                          // rgb_linear.weight [3][128]
-constexpr int64_t R_B = R_W + 3 * WH;
-constexpr int64_t N_PARAMS = R_B + 3;
-static_assert(N_PARAMS == 595844, "parameter count");
-
-// ---- packed forward weights (fragment order; see mlp.hip) ----
-// layer ids: 0..7 = pts_linears, 8 = feature_linear, 9 = views_linears.0
-constexpr int PF_KP(int l) { return l == 0 ? 64 : (l == 5 ? 320 : (l == 9 ? 288 : 256)); }
-constexpr int PF_N(int l) { return l == 9 ? 128 : 256; }
-constexpr int64_t PF_OFF(int l) {
+inline NetLayout make_layout(int kind) {
+  NetLayout L{};
+  L.kind = kind;
+  L.in_pe = (kind == 2) ? 84 : 63;
+  L.pe_pad = (kind == 2) ? 96 : 64;
   int64_t o = 0;
-  for (int i = 0; i < l; ++i) o += (int64_t)PF_KP(i) * PF_N(i);
-  return o;
+  for (int i = 0; i < 8; ++i) {
+    const int fan = (i == 0) ? L.in_pe : (i == 5 ? 256 + L.in_pe : 256);
+    L.LW[i] = o; o += (int64_t)256 * fan;
+    L.LB[i] = o; o += 256;
+  }
+  auto V = [&]() { L.VW = o; o += 128 * 283; L.VB = o; o += 128; };
+  auto F = [&]() { L.FW = o; o += 256 * 256; L.FB = o; o += 256; };
+  auto A = [&]() { L.AW = o; o += 256; L.AB = o; o += 1; };
+  auto R = [&]() { L.RW = o; o += 3 * 128; L.RB = o; o += 3; };
+  if (kind == 0) { V(); F(); A(); R(); } else { A(); F(); V(); R(); }
+  L.n_params = o;
+  int64_t p = 0;
+  for (int l = 0; l < 10; ++l) {
+    L.PF[l] = p;
+    const int kp = (l == 0) ? L.pe_pad : (l == 5 ? L.pe_pad + 256 : (l == 9 ? 288 : 256));
+    p += (int64_t)kp * (l == 9 ? 128 : 256);
+  }
+  L.pf_total = p;
+  p = 0;
+  for (int j = 0; j < 9; ++j) { L.PB[j] = p; p += (int64_t)(j == 0 ? 128 : 256) * 256; }
+  L.pb_total = p;
+  return L;
 }
-constexpr int64_t PF_TOTAL = PF_OFF(10);
-static_assert(PF_TOTAL == 593920, "packed fwd size");
 
-// ---- packed transposed weights for dX (fragment order) ----
-// ids: 0 = views(feat part) K=128; 1 = feature; 2..8 = pts_linears 7,6,5(h part),4,3,2,1
-constexpr int PB_K(int j) { return j == 0 ? 128 : 256; }
-constexpr int64_t PB_OFF(int j) {
-  int64_t o = 0;
-  for (int i = 0; i < j; ++i) o += (int64_t)PB_K(i) * 256;
-  return o;
-}
-constexpr int64_t PB_TOTAL = PB_OFF(9);
-static_assert(PB_TOTAL == 557056, "packed bwd size");
-
-// ---- saved activations, SoA over P points ----
-constexpr int ACT_DENSE = 64 + 8 * 256 + 256 + 32 + 128;   // floats per point
-static_assert(ACT_DENSE == 2528, "act floats");
-// + per tile of 64*k points: 8 layers x 4k waves x 64 ballot words (uint64) of the ReLU masks
-// (= 256 bytes per point for either tile size)
-constexpr int ACT_FLOATS = ACT_DENSE + 64;                   // 2592 per point (+ one tile of slack)
-inline __host__ __device__ int64_t act_pe(int64_t P) { return 0; }
-inline __host__ __device__ int64_t act_h(int64_t P, int l) { return P * 64 + (int64_t)l * P * 256; }
-inline __host__ __device__ int64_t act_feat(int64_t P) { return P * (64 + 2048); }
-inline __host__ __device__ int64_t act_vpe(int64_t P) { return P * (64 + 2048 + 256); }
-inline __host__ __device__ int64_t act_hv(int64_t P) { return P * (64 + 2048 + 256 + 32); }
-inline __host__ __device__ int64_t act_mask(int64_t P) { return P * ACT_DENSE; }  // uint64 words from here
+// ---- saved activations, SoA over P points: pe | h0..h7 | feat | vpe32 | hv128 | ReLU ballots ----
+constexpr int ACT_REST = 8 * 256 + 256 + 32 + 128;   // 2464 floats per point after the pe block
+constexpr int ACT_MASK = 64;                         // 256 bytes of ballot words per point
+inline __host__ __device__ int64_t act_pe(int64_t P, int pe_pad) { return 0; }
+inline __host__ __device__ int64_t act_h(int64_t P, int pe_pad, int l) { return P * pe_pad + (int64_t)l * P * 256; }
+inline __host__ __device__ int64_t act_feat(int64_t P, int pe_pad) { return P * (pe_pad + 2048); }
+inline __host__ __device__ int64_t act_vpe(int64_t P, int pe_pad) { return P * (pe_pad + 2048 + 256); }
+inline __host__ __device__ int64_t act_hv(int64_t P, int pe_pad) { return P * (pe_pad + 2048 + 256 + 32); }
+inline __host__ __device__ int64_t act_mask(int64_t P, int pe_pad) { return P * (pe_pad + ACT_REST); }  // uint64 words
+inline int64_t act_floats(int64_t P, int pe_pad) { return P * (pe_pad + ACT_REST + ACT_MASK) + 8192; }
 // ---- pre-activation gradients, SoA ----
 constexpr int DACT_FLOATS = 8 * 256 + 256 + 128;
 inline __host__ __device__ int64_t dact_y(int64_t P, int l) { return (int64_t)l * P * 256; }

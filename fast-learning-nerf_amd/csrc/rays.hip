@@ -259,3 +259,72 @@ extern "C" int fastnerf_posenc(int64_t n, int L, const float* x, float* out, fn_
   FN_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// nerf++ (ddp_train_nerf.py:54-69, 355-361)
+// ---------------------------------------------------------------------------------------
+__global__ void intersect_sphere_kernel(int64_t n, const float* __restrict__ rays, float* __restrict__ fg_far,
+                                        int* __restrict__ n_outside) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* r = rays + i * 11;
+    const float o[3] = {r[0], r[1], r[2]}, d[3] = {r[3], r[4], r[5]};
+    const float dd = fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2]));
+    const float od = fadd(fadd(fmul(d[0], o[0]), fmul(d[1], o[1])), fmul(d[2], o[2]));
+    const float d1 = -od / dd;
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = fadd(o[c], fmul(d1, d[c]));
+    const float pn2 = fadd(fadd(fmul(p[0], p[0]), fmul(p[1], p[1])), fmul(p[2], p[2]));
+    if (pn2 >= 1.0f && n_outside) atomicAdd(n_outside, 1);
+    fg_far[i] = fadd(d1, fmul(sqrtf(fsub(1.0f, pn2)), 1.0f / sqrtf(dd)));
+  }
+}
+
+__global__ void fg_depths_kernel(int64_t n, int S, float near, const float* __restrict__ fg_far,
+                                 const float* __restrict__ t_rand, int perturb, uint64_t seed, float* __restrict__ z) {
+  const int64_t total = n * S;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / S;
+    const int s = (int)(i % S);
+    const float step = fsub(fg_far[r], near) / (float)(S - 1);
+    auto zat = [&](int k) { return fadd(near, fmul((float)k, step)); };   // near + i * step
+    const float zc = zat(s);
+    float out = zc;
+    if (perturb) {
+      const float lower = (s > 0) ? fmul(0.5f, fadd(zc, zat(s - 1))) : zc;
+      const float upper = (s < S - 1) ? fmul(0.5f, fadd(zat(s + 1), zc)) : zc;
+      float u;
+      if (t_rand) {
+        u = t_rand[i];
+      } else {
+        uint32_t o[4];
+        philox4x32((uint32_t)i, (uint32_t)(i >> 32), 0x66676470u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        u = u01(o[0]);
+      }
+      out = fadd(lower, fmul(fsub(upper, lower), u));
+    }
+    z[i] = out;
+  }
+}
+
+extern "C" int fastnerf_pp_intersect_sphere(int64_t n, const float* rays11, float* fg_far, int* n_outside,
+                                            fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && (n == 0 || (rays11 && fg_far)), "null pointer");
+  if (n == 0) return 0;
+  if (n_outside) FN_HIP(hipMemsetAsync(n_outside, 0, sizeof(int), fn::S(stream)));
+  hipLaunchKernelGGL(intersect_sphere_kernel, dim3(grid_for(n)), dim3(256), 0, fn::S(stream), n, rays11, fg_far,
+                     n_outside);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fastnerf_pp_fg_depths(int64_t n, int S, float near, const float* fg_far, int perturb,
+                                     const float* t_rand, uint64_t seed, float* z, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 2 && (n == 0 || (fg_far && z)), "n>=0, S>=2, non-null pointers");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fg_depths_kernel, dim3(grid_for(n * S)), dim3(256), 0, fn::S(stream), n, S, near, fg_far, t_rand,
+                     perturb, seed, z);
+  FN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,252 @@
+"""nerf++-ours hot path on the HIP kernels: mirror of
+nerf++-ours/{nerf_network.py MLPNet, ddp_model.py NerfNet / NerfNetWithAutoExpo,
+ddp_train_nerf.py intersect_sphere / perturb_samples / sample_pdf / train_step}.
+
+The foreground MLPNet has exactly the NeRF MLP's shapes; the background MLPNet takes the 84-channel
+encoding of the 4-D inverted-sphere point.  Both run through the same fused fp32-MFMA kernels
+(`kind` 1 / 2 of fastnerf_mlp_*_ex); sigma = |.| and rgb = sigmoid(.) are applied by the
+compositing kernels, as the reference's network does internally."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .render import _Workspace, _next_seed
+
+TINY_NUMBER = 1e-6
+HUGE_NUMBER = 1e10
+
+
+def mlpnet_slices(kind):
+    """[(name, offset, shape)] in MLPNet.parameters() order (nerf_network.py:70-120)."""
+    ic = 84 if kind == 2 else 63
+    out, off = [], 0
+    dims = [ic] + [256] * 4 + [256 + ic] + [256] * 2
+    for i in range(8):
+        out.append((f'base_layers.{i}.0.weight', off, (256, dims[i]))); off += 256 * dims[i]
+        out.append((f'base_layers.{i}.0.bias', off, (256,))); off += 256
+    for name, shp in (('sigma_layers.0', (1, 256)), ('base_remap_layers.0', (256, 256)), ('rgb_layers.0', (128, 283)),
+                      ('rgb_layers.2', (3, 128))):
+        out.append((name + '.weight', off, shp)); off += shp[0] * shp[1]
+        out.append((name + '.bias', off, (shp[0],))); off += shp[0]
+    assert off == ops.net_floats(kind, 0)
+    return out
+
+
+class MLPNet(nn.Module):
+    """Parameters are views into a flat buffer in parameters() order; names match the reference."""
+
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_viewdirs=27, skips=[4], use_viewdirs=True, device='cuda',
+                 flat=None, flat_grad=None):
+        super().__init__()
+        if not (D == 8 and W == 256 and input_ch in (63, 84) and input_ch_viewdirs == 27 and list(skips) == [4]
+                and use_viewdirs):
+            raise NotImplementedError('HIP MLPNet implements D=8, W=256, input_ch in {63, 84}, viewdirs 27, skips=[4]')
+        self.kind = 2 if input_ch == 84 else 1
+        self.input_ch, self.input_ch_viewdirs = input_ch, input_ch_viewdirs
+        # same module construction order as the reference => same init under torch.manual_seed
+        base, dim = [], input_ch
+        for i in range(D):
+            base.append(nn.Sequential(nn.Linear(dim, W), nn.ReLU()))
+            dim = W
+            if i in skips and i != D - 1:
+                dim += input_ch
+        self.base_layers = nn.ModuleList(base)
+        self.sigma_layers = nn.Sequential(nn.Linear(dim, 1))
+        self.base_remap_layers = nn.Sequential(nn.Linear(dim, 256))
+        self.rgb_layers = nn.Sequential(nn.Linear(256 + input_ch_viewdirs, W // 2), nn.ReLU(), nn.Linear(W // 2, 3),
+                                        nn.Sigmoid())
+        dev = torch.device(device)
+        n = ops.net_floats(self.kind, 0)
+        self.flat = flat if flat is not None else torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_grad = flat_grad if flat_grad is not None else torch.zeros(n, device=dev, dtype=torch.float32)
+        mods = dict(self.named_modules())
+        for name, off, shape in mlpnet_slices(self.kind):
+            mod_name, leaf = name.rsplit('.', 1)
+            mod = mods[mod_name]
+            k = int(np.prod(shape))
+            view = self.flat[off:off + k].view(shape)
+            with torch.no_grad():
+                view.copy_(getattr(mod, leaf).detach().to(dev))
+            p = nn.Parameter(view)
+            p.grad = self.flat_grad[off:off + k].view(shape)
+            setattr(mod, leaf, p)
+        self._packed = None
+
+    def packed(self, refresh=True):
+        if self._packed is None:
+            self._packed = (torch.empty(ops.net_floats(self.kind, 1), device=self.flat.device),
+                            torch.empty(ops.net_floats(self.kind, 2), device=self.flat.device))
+            refresh = True
+        if refresh:
+            ops.mlp_pack(self.flat, *self._packed, kind=self.kind)
+        return self._packed
+
+    def forward(self, input):
+        """Reference signature on already-embedded inputs (nerf_network.py:122-142); convenience
+        path only -- NerfNet.forward runs the fused kernels on rays."""
+        pts = input[..., :self.input_ch]
+        base = self.base_layers[0](pts)
+        for i in range(len(self.base_layers) - 1):
+            if i == 4:
+                base = torch.cat((pts, base), dim=-1)
+            base = self.base_layers[i + 1](base)
+        sigma = torch.abs(self.sigma_layers(base))
+        remap = self.base_remap_layers(base)
+        rgb = self.rgb_layers(torch.cat((remap, input[..., -self.input_ch_viewdirs:]), dim=-1))
+        return OrderedDict([('rgb', rgb), ('sigma', sigma.squeeze(-1))])
+
+
+def _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save):
+    dev = rays11.device
+    n, Sf = fg_z.shape
+    Sb = bg_z.shape[1]
+    pf, pb = net.fg_net.packed(), net.bg_net.packed()
+    act_f = torch.empty(ops.act_floats(n * Sf, 1), device=dev) if save else None
+    act_b = torch.empty(ops.act_floats(n * Sb, 2), device=dev) if save else None
+    raw_f = ops.mlp_fwd(rays11, fg_z, net.fg_net.flat, pf[0], act=act_f, kind=1)
+    fg_rgb, fg_w, fg_depth, lam = ops.pp_composite_fwd(0, raw_f, fg_z, rays11, fg_far)
+    raw_b = ops.mlp_fwd(rays11, bg_z, net.bg_net.flat, pb[0], act=act_b, kind=2)
+    bg_rgb, bg_w, bg_depth, _ = ops.pp_composite_fwd(1, raw_b, bg_z, rays11)
+    saved = dict(rays11=rays11, fg_far=fg_far, fg_z=fg_z, bg_z=bg_z, raw_f=raw_f, raw_b=raw_b, act_f=act_f, act_b=act_b,
+                 lam=lam, bg_rgb=bg_rgb, pf=pf, pb=pb)
+    return (fg_rgb, fg_w, fg_depth, lam, bg_rgb, bg_w, bg_depth), saved
+
+
+def _nerfnet_backward(net, saved, g_rgb, out_f=None, out_b=None):
+    """d(loss)/d(params) of fg / bg nets from d(loss)/d(rgb) [n,3] (rgb = fg + lambda * bg)."""
+    dev = g_rgb.device
+    out_f = out_f if out_f is not None else net.fg_net.flat_grad
+    out_b = out_b if out_b is not None else net.bg_net.flat_grad
+    lam, bg_rgb = saved['lam'], saved['bg_rgb']
+    g_lam = (g_rgb * bg_rgb).sum(-1).contiguous()
+    g_bg = (lam[:, None] * g_rgb).contiguous()
+    partial = _Workspace.partial(dev)
+    n, Sf = saved['fg_z'].shape
+    Sb = saved['bg_z'].shape[1]
+    draw_f = ops.pp_composite_bwd(0, saved['raw_f'], saved['fg_z'], saved['rays11'], g_rgb, saved['fg_far'], g_lam)
+    dact = _Workspace.dact(dev, n * max(Sf, Sb) * ops.DACT_FLOATS)
+    ops.mlp_bwd(draw_f, saved['act_f'], net.fg_net.flat, saved['pf'][1], dact, partial, out_f, kind=1)
+    draw_b = ops.pp_composite_bwd(1, saved['raw_b'], saved['bg_z'], saved['rays11'], g_bg)
+    ops.mlp_bwd(draw_b, saved['act_b'], net.bg_net.flat, saved['pb'][1], dact, partial, out_b, kind=2)
+
+
+class _NerfNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, rays11, fg_far, fg_z, bg_z, *params):
+        outs, saved = _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save=True)
+        fg_rgb, fg_w, fg_depth, lam, bg_rgb, bg_w, bg_depth = outs
+        rgb = fg_rgb + lam[:, None] * bg_rgb
+        ctx.net, ctx.saved, ctx.n_params = net, saved, len(params)
+        res = (rgb, fg_w, bg_w, fg_rgb, fg_depth, lam[:, None] * bg_rgb, lam * bg_depth, lam)
+        ctx.mark_non_differentiable(*res[1:])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_rgb, *_):
+        net = ctx.net
+        out_f, out_b = torch.empty_like(net.fg_net.flat), torch.empty_like(net.bg_net.flat)
+        _nerfnet_backward(net, ctx.saved, g_rgb.contiguous(), out_f, out_b)
+        grads = [out_f[o:o + int(np.prod(s))].view(s) for _, o, s in mlpnet_slices(1)] + \
+                [out_b[o:o + int(np.prod(s))].view(s) for _, o, s in mlpnet_slices(2)]
+        assert len(grads) == ctx.n_params
+        return (None, None, None, None, None) + tuple(grads)
+
+
+class NerfNet(nn.Module):
+    """ddp_model.py:49-143.  fg and bg parameters share one flat buffer [fg | bg] (1,202,440 floats)."""
+
+    def __init__(self, args=None, device='cuda'):
+        super().__init__()
+        dev = torch.device(device)
+        nf, nb = ops.net_floats(1, 0), ops.net_floats(2, 0)
+        self.flat = torch.empty(nf + nb, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(nf + nb, device=dev, dtype=torch.float32)
+        self.fg_net = MLPNet(input_ch=63, device=dev, flat=self.flat[:nf], flat_grad=self.flat_grad[:nf])
+        self.bg_net = MLPNet(input_ch=84, device=dev, flat=self.flat[nf:], flat_grad=self.flat_grad[nf:])
+
+    def forward(self, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals):
+        ops.require_gpu(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
+        rays11 = ops.pack_rays(ray_o, ray_d, 0.0, 0.0)
+        fg_far, fg_z, bg_z = (t.contiguous().float() for t in (fg_z_max, fg_z_vals, bg_z_vals))
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            res = _NerfNetFn.apply(self, rays11, fg_far, fg_z, bg_z, *params)
+        else:
+            (fg_rgb, fg_w, fg_depth, lam, bg_rgb, bg_w, bg_depth), _ = _nerfnet_forward(self, rays11, fg_far, fg_z, bg_z,
+                                                                                       save=False)
+            res = (fg_rgb + lam[:, None] * bg_rgb, fg_w, bg_w, fg_rgb, fg_depth, lam[:, None] * bg_rgb, lam * bg_depth, lam)
+        keys = ('rgb', 'fg_weights', 'bg_weights', 'fg_rgb', 'fg_depth', 'bg_rgb', 'bg_depth', 'bg_lambda')
+        return OrderedDict(zip(keys, res))
+
+
+class NerfNetWithAutoExpo(nn.Module):
+    """ddp_model.py:157-188 with optim_autoexpo=False (the configs on this path never enable it)."""
+
+    def __init__(self, args=None, optim_autoexpo=False, img_names=None, device='cuda'):
+        super().__init__()
+        if optim_autoexpo:
+            raise NotImplementedError('optim_autoexpo is not used by the tanks-and-temples configs')
+        self.nerf_net = NerfNet(args, device=device)
+
+    def forward(self, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, img_name=None):
+        return self.nerf_net(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
+
+
+def intersect_sphere(ray_o, ray_d):
+    """ddp_train_nerf.py:54-69."""
+    return ops.pp_intersect_sphere(ops.pack_rays(ray_o, ray_d, 0.0, 0.0))
+
+
+def sample_pdf(bins, weights, N_samples, det=False):
+    raise NotImplementedError('use ops.pp_sample_pdf_merge (sampler + sort-merge in one kernel)')
+
+
+class CascadeTrainer:
+    """Fused train_step batch of ddp_train_nerf.py:347-404 over `cascade_samples` levels, each level
+    with its own net + Adam (no LR decay in this fork), gradients all-reduced when world_size > 1."""
+
+    def __init__(self, nets, cascade_samples=(64, 128), lrate=5e-4, min_depth=1e-4):
+        self.nets = [getattr(n, 'nerf_net', n) for n in nets]
+        self.cascade_samples = list(cascade_samples)
+        self.lrate, self.min_depth = lrate, min_depth
+        self.m = [torch.zeros_like(n.flat) for n in self.nets]
+        self.v = [torch.zeros_like(n.flat) for n in self.nets]
+        self.t = [0] * len(self.nets)
+
+    def step(self, ray_o, ray_d, target, rand=None, leaf_tag=None, table=None, max_leaves=0, n_global=None,
+             update=True):
+        from . import parallel
+        n = ray_o.shape[0]
+        rays11 = ops.pack_rays(ray_o, ray_d, 0.0, 0.0)
+        fg_far = ops.pp_intersect_sphere(rays11)
+        losses, ret = [], None
+        fg_z = bg_z = None
+        for m, net in enumerate(self.nets):
+            N = self.cascade_samples[m]
+            r = rand[m] if rand is not None else {}
+            if m == 0:
+                fg_z = ops.pp_fg_depths(fg_far, N, self.min_depth, True, r.get('fg_t'), _next_seed())
+                bg_z = ops.sample_coarse(ops.pack_rays(ray_o, ray_d, 0.0, 1.0), N, perturb=True, t_rand=r.get('bg_t'),
+                                         seed=_next_seed())
+            else:
+                fg_z, _ = ops.pp_sample_pdf_merge(fg_z, ret[1], N, u=r.get('fg_u'), seed=_next_seed())
+                bg_z, _ = ops.pp_sample_pdf_merge(bg_z, ret[5], N, u=r.get('bg_u'), seed=_next_seed())
+            outs, saved = _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save=True)
+            fg_rgb, fg_w, fg_depth, lam, bg_rgb, bg_w, bg_depth = outs
+            rgb = fg_rgb + lam[:, None] * bg_rgb
+            last = m == len(self.nets) - 1
+            scale = 1.0 if n_global is None else float(n) / float(n_global)
+            loss2, g, _ = ops.mse_leafmax(rgb, None, target, grad_scale=scale, leaf_tag=leaf_tag if last else None,
+                                          max_leaves=max_leaves, table=table if last else None)
+            _nerfnet_backward(net, saved, g)
+            if parallel.world_size() > 1:
+                parallel.all_reduce_sum(net.flat_grad)
+            if update:
+                self.t[m] += 1
+                ops.adam_step(net.flat, net.flat_grad, self.m[m], self.v[m], self.lrate, self.t[m])
+            losses.append(loss2[0])
+            ret = outs
+        return torch.stack(losses), rgb

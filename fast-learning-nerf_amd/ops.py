@@ -16,9 +16,14 @@ ACT_SLACK = 8192
 DACT_FLOATS = 2432
 
 
-def act_floats(P):
-    """Size (floats) of the saved-activation buffer for P points."""
-    return P * ACT_FLOATS + ACT_SLACK
+def act_floats(P, kind=0):
+    """Size (floats) of the saved-activation buffer for P points of a net of the given kind."""
+    return int(lib().fastnerf_mlp_act_floats(int(kind), int(P)))
+
+
+def net_floats(kind, what=0):
+    """what: 0 parameters, 1 packed-forward, 2 packed-backward, 3 padded PE width."""
+    return int(lib().fastnerf_net_floats(int(kind), int(what)))
 
 
 def _f32(t):
@@ -89,26 +94,29 @@ def posenc(x, L):
     return out.reshape(list(sh[:-1]) + [3 + 6 * L])
 
 
-def mlp_pack(params, packed_fwd=None, packed_bwd=None):
+def mlp_pack(params, packed_fwd=None, packed_bwd=None, kind=0):
     require_gpu(params)
-    assert params.numel() == NET_PARAMS and params.is_contiguous()
+    assert params.numel() == net_floats(kind, 0) and params.is_contiguous()
     if packed_fwd is None:
-        packed_fwd = torch.empty(PACKED_FWD, device=params.device, dtype=torch.float32)
+        packed_fwd = torch.empty(net_floats(kind, 1), device=params.device, dtype=torch.float32)
     if packed_bwd is None:
-        packed_bwd = torch.empty(PACKED_BWD, device=params.device, dtype=torch.float32)
-    check(lib().fastnerf_mlp_pack(ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()), 'fastnerf_mlp_pack')
+        packed_bwd = torch.empty(net_floats(kind, 2), device=params.device, dtype=torch.float32)
+    check(lib().fastnerf_mlp_pack_ex(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),
+          'fastnerf_mlp_pack_ex')
     return packed_fwd, packed_bwd
 
 
-def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None):
+def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None, kind=0):
+    """kind 0/1: points o + d*z; kind 2 (nerf++ background): inverted-sphere points of depth z, consumed
+    far->near (raw[:, s] belongs to z[:, S-1-s])."""
     require_gpu(rays11, z, params, packed_fwd)
     n, S = z.shape
     if raw is None:
         raw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
     if act is not None:
-        assert act.numel() >= act_floats(n * S)
-    check(lib().fastnerf_mlp_fwd(n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw), ptr(act), stream()),
-          'fastnerf_mlp_fwd')
+        assert act.numel() >= act_floats(n * S, kind)
+    check(lib().fastnerf_mlp_fwd_ex(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw),
+                                    ptr(act), stream()), 'fastnerf_mlp_fwd_ex')
     return raw
 
 
@@ -116,12 +124,12 @@ def mlp_bwd_partial_floats():
     return int(lib().fastnerf_mlp_bwd_partial_floats())
 
 
-def mlp_bwd(draw, act, params, packed_bwd, dact, partial, grads):
+def mlp_bwd(draw, act, params, packed_bwd, dact, partial, grads, kind=0):
     require_gpu(draw, act, params, packed_bwd, dact, partial, grads)
     n, S = draw.shape[0], draw.shape[1]
-    assert dact.numel() >= n * S * DACT_FLOATS and grads.numel() == NET_PARAMS
-    check(lib().fastnerf_mlp_bwd(n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact), ptr(partial),
-                                 ptr(grads), stream()), 'fastnerf_mlp_bwd')
+    assert dact.numel() >= n * S * DACT_FLOATS and grads.numel() == net_floats(kind, 0)
+    check(lib().fastnerf_mlp_bwd_ex(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
+                                    ptr(partial), ptr(grads), stream()), 'fastnerf_mlp_bwd_ex')
     return grads
 
 
@@ -194,3 +202,65 @@ def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     require_gpu(params, grads, m, v)
     check(lib().fastnerf_adam_step(params.numel(), ptr(params), ptr(grads), ptr(m), ptr(v), float(lr), float(beta1),
                                    float(beta2), float(eps), int(step), stream()), 'fastnerf_adam_step')
+
+
+# ---- nerf++-ours additions -------------------------------------------------------------------
+def pp_intersect_sphere(rays11, check_inside=True):
+    """ddp_train_nerf.py:54-69.  Raises (like the reference) when a camera is outside the unit sphere;
+    check_inside=False skips the device->host read of the counter."""
+    require_gpu(rays11)
+    n = rays11.shape[0]
+    fg_far = torch.empty(n, device=rays11.device, dtype=torch.float32)
+    cnt = torch.zeros(1, device=rays11.device, dtype=torch.int32) if check_inside else None
+    check(lib().fastnerf_pp_intersect_sphere(n, ptr(rays11), ptr(fg_far), ptr(cnt), stream()),
+          'fastnerf_pp_intersect_sphere')
+    if check_inside and int(cnt.item()) > 0:
+        raise Exception('Not all your cameras are bounded by the unit sphere; please make sure the cameras are '
+                        'normalized properly!')
+    return fg_far
+
+
+def pp_fg_depths(fg_far, S, near=1e-4, perturb=True, t_rand=None, seed=0):
+    require_gpu(fg_far, t_rand)
+    n = fg_far.shape[0]
+    z = torch.empty(n, S, device=fg_far.device, dtype=torch.float32)
+    if t_rand is not None:
+        t_rand = _f32(t_rand)
+    check(lib().fastnerf_pp_fg_depths(n, S, float(near), ptr(fg_far), int(bool(perturb) or t_rand is not None),
+                                      ptr(t_rand), int(seed), ptr(z), stream()), 'fastnerf_pp_fg_depths')
+    return z
+
+
+def pp_sample_pdf_merge(z, weights, Ni, det=False, u=None, seed=0):
+    require_gpu(z, weights, u)
+    n, S = z.shape
+    z_out = torch.empty(n, S + Ni, device=z.device, dtype=torch.float32)
+    z_samples = torch.empty(n, Ni, device=z.device, dtype=torch.float32)
+    if u is not None:
+        u = _f32(u)
+    check(lib().fastnerf_pp_sample_pdf_merge(n, S, Ni, ptr(z), ptr(weights), int(bool(det)), ptr(u), int(seed),
+                                             ptr(z_out), ptr(z_samples), stream()), 'fastnerf_pp_sample_pdf_merge')
+    return z_out, z_samples
+
+
+def pp_composite_fwd(part, raw, z, rays11, fg_far=None):
+    require_gpu(raw, z, rays11, fg_far)
+    n, S = z.shape
+    dev = z.device
+    rgb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    w = torch.empty(n, S, device=dev, dtype=torch.float32)
+    depth = torch.empty(n, device=dev, dtype=torch.float32)
+    lam = torch.empty(n, device=dev, dtype=torch.float32) if part == 0 else None
+    check(lib().fastnerf_pp_composite_fwd(n, S, int(part), ptr(raw), ptr(z), ptr(rays11), ptr(fg_far), ptr(rgb), ptr(w),
+                                          ptr(depth), ptr(lam), stream()), 'fastnerf_pp_composite_fwd')
+    return rgb, w, depth, lam
+
+
+def pp_composite_bwd(part, raw, z, rays11, g_rgb, fg_far=None, g_lambda=None):
+    require_gpu(raw, z, rays11, g_rgb, fg_far, g_lambda)
+    n, S = z.shape
+    draw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
+    check(lib().fastnerf_pp_composite_bwd(n, S, int(part), ptr(raw), ptr(z), ptr(rays11), ptr(fg_far), ptr(_f32(g_rgb)),
+                                          ptr(None if g_lambda is None else _f32(g_lambda)), ptr(draw), stream()),
+          'fastnerf_pp_composite_bwd')
+    return draw

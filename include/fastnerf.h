@@ -62,7 +62,7 @@ int fastnerf_posenc(int64_t n, int L, const float* x, float* out, fn_stream_t st
 /* saved activations: n*S*FASTNERF_ACT_FLOATS + FASTNERF_ACT_SLACK floats
  * (per point pe64 + 8*h256 + feat256 + vpe32 + hv128 + 64 floats of ReLU ballot masks) */
 #define FASTNERF_ACT_FLOATS 2592
-#define FASTNERF_ACT_SLACK 8192
+#define FASTNERF_ACT_SLACK 8192   /* kind 0; in general use fastnerf_mlp_act_floats() */
 /* per-point pre-activation gradients (floats): 8*dY256 + dfeat256 + dYv128 */
 #define FASTNERF_DACT_FLOATS 2432
 
@@ -119,6 +119,39 @@ int fastnerf_mse_leafmax(int64_t n, const float* rgb, const float* rgb0, const f
 /* torch.optim.Adam step (run_nerf.py:99,494) over a flat buffer. */
 int fastnerf_adam_step(int64_t n, float* params, const float* grads, float* m, float* v, double lr, double beta1,
                        double beta2, double eps, int step, fn_stream_t stream);
+
+/* ---- generalised MLP entry points: kind 0 = NeRF (model.py), 1 = nerf++ MLPNet foreground,
+ * 2 = nerf++ MLPNet background (4-D inverted-sphere input, samples consumed far->near;
+ * nerf++-ours/nerf_network.py:70-142, ddp_model.py:110-124) ------------------------------------- */
+/* what: 0 parameter floats, 1 packed-forward floats, 2 packed-backward floats, 3 padded PE width */
+int64_t fastnerf_net_floats(int kind, int what);
+int64_t fastnerf_mlp_act_floats(int kind, int64_t n_points);
+int fastnerf_mlp_pack_ex(int kind, const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream);
+int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                        const float* packed_fwd, float* raw, float* act, fn_stream_t stream);
+int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                        const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
+
+/* ---- nerf++-ours additions ------------------------------------------- */
+/* intersect_sphere (ddp_train_nerf.py:54-69); *n_outside counts rays whose camera is not inside the
+ * unit sphere (the reference raises in that case). */
+int fastnerf_pp_intersect_sphere(int64_t n, const float* rays11, float* fg_far, int* n_outside, fn_stream_t stream);
+/* foreground depths near + i*step, optionally perturbed (ddp_train_nerf.py:355-361, 72-81). */
+int fastnerf_pp_fg_depths(int64_t n, int S, float near, const float* fg_far, int perturb, const float* t_rand,
+                          uint64_t seed, float* z, fn_stream_t stream);
+/* nerf++ sample_pdf + sort-merge (ddp_train_nerf.py:84-133, 369-382). */
+int fastnerf_pp_sample_pdf_merge(int64_t n, int S, int Ni, const float* z, const float* weights, int det,
+                                 const float* u, uint64_t seed, float* z_out, float* z_samples, fn_stream_t stream);
+/* fg (part 0) / bg (part 1) compositing of NerfNet.forward (ddp_model.py:97-135) and its backward.
+ * raw is the MLP output in network order (bg: far->near); z is always stored near->far.
+ * fwd outputs: rgb_map [n,3], weights [n,S], depth [n] (may be NULL), lambda [n] (part 0 only).
+ * bwd inputs: g_rgb [n,3], g_lambda [n] (part 0; may be NULL) -> draw [n,S,4]. */
+int fastnerf_pp_composite_fwd(int64_t n, int S, int part, const float* raw, const float* z, const float* rays11,
+                              const float* fg_far, float* rgb_map, float* weights, float* depth, float* lambda,
+                              fn_stream_t stream);
+int fastnerf_pp_composite_bwd(int64_t n, int S, int part, const float* raw, const float* z, const float* rays11,
+                              const float* fg_far, const float* g_rgb, const float* g_lambda, float* draw,
+                              fn_stream_t stream);
 
 /* ---- host quadtree (tree.py), no device work --------------------------- */
 typedef struct fn_tree fn_tree; /* opaque: per-image DFS leaf lists */
