@@ -48,6 +48,9 @@ SIGNATURES = {
     'fastnerf_pp_sample_pdf_merge': (I, [L, I, I, P, P, I, P, U64, P, P, P]),
     'fastnerf_pp_composite_fwd': (I, [L, I, I, P, P, P, P, P, P, P, P, P]),
     'fastnerf_pp_composite_bwd': (I, [L, I, I, P, P, P, P, P, P, P, P]),
+    'fastnerf_pp_gen_rays': (I, [I, I, P, P, P, P, P]),
+    'fastnerf_leaf_sumcount': (I, [L, P, P, P, I, P, P, P]),
+    'fastnerf_tree_adjust_mean': (L, [P, P, P, I, D]),
     'fastnerf_tree_create': (P, [I, I, I, I]),
     'fastnerf_tree_destroy': (None, [P]),
     'fastnerf_tree_num_leaves': (I, [P, I]),

@@ -328,3 +328,42 @@ extern "C" int fastnerf_pp_fg_depths(int64_t n, int S, float near, const float* 
   FN_LAUNCH_CHECK();
   return 0;
 }
+
+
+// nerf++ ray generator (nerf_sample_ray_split.py:10-34): OpenCV convention, pixel centres at +0.5,
+// d = R * K^-1 * [u, v, 1], evaluated in fp64 like the reference's numpy code and rounded once.
+struct Mat9d { double m[9]; };
+__global__ void pp_gen_rays_kernel(int H, int W, Mat9d RK, float ox, float oy, float oz, float* __restrict__ ro,
+                                   float* __restrict__ rd) {
+  const int64_t n = (int64_t)H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double u = (double)((float)(i % W) + 0.5f), v = (double)((float)(i / W) + 0.5f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rd[i * 3 + k] = (float)(RK.m[3 * k] * u + RK.m[3 * k + 1] * v + RK.m[3 * k + 2]);
+    ro[i * 3] = ox; ro[i * 3 + 1] = oy; ro[i * 3 + 2] = oz;
+  }
+}
+
+extern "C" int fastnerf_pp_gen_rays(int H, int W, const double* intrinsics_host, const double* c2w_host, float* rays_o,
+                                    float* rays_d, fn_stream_t stream) {
+  FN_CHECK_ARG(H > 0 && W > 0 && intrinsics_host && c2w_host && rays_o && rays_d, "H,W>0 and non-null pointers");
+  // K^-1 of the upper-left 3x3 of the 4x4 intrinsics, then R * K^-1 (both row-major 4x4 inputs)
+  const double* K = intrinsics_host;
+  const double a = K[0], b = K[1], c = K[2], d = K[4], e = K[5], f = K[6], g = K[8], h = K[9], i = K[10];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  FN_CHECK_ARG(det != 0.0, "singular intrinsics");
+  const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                         (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                         (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  Mat9d RK;
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += c2w_host[4 * r + k] * inv[3 * k + cc];
+      RK.m[3 * r + cc] = s;
+    }
+  hipLaunchKernelGGL(pp_gen_rays_kernel, dim3(grid_for((int64_t)H * W)), dim3(256), 0, fn::S(stream), H, W, RK,
+                     (float)c2w_host[3], (float)c2w_host[7], (float)c2w_host[11], rays_o, rays_d);
+  FN_LAUNCH_CHECK();
+  return 0;
+}

@@ -126,3 +126,34 @@ extern "C" int fastnerf_adam_step(int64_t n, float* params, const float* grads, 
   FN_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// nerf++ quadtree fork: split criterion = MEAN of |gt - pred| over a leaf's rays and channels
+// (nerf++-ours/tree.py:622).  Accumulated per (image, leaf) as an fp64 sum + a count so that the
+// result does not depend on the order rays arrive in (fp32 atomics would).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) leaf_sumcount_kernel(int64_t n, const float* __restrict__ rgb,
+                                                             const float* __restrict__ target,
+                                                             const int32_t* __restrict__ tag, int max_leaves,
+                                                             double* __restrict__ sum, int32_t* __restrict__ count) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double e = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e += (double)fabsf(fsub(target[i * 3 + c], rgb[i * 3 + c]));
+    const int64_t slot = (int64_t)tag[i * 2] * max_leaves + tag[i * 2 + 1];
+    atomicAdd(sum + slot, e);
+    atomicAdd(count + slot, 1);
+  }
+}
+
+extern "C" int fastnerf_leaf_sumcount(int64_t n, const float* rgb, const float* target, const int32_t* leaf_tag,
+                                      int max_leaves, double* sum, int32_t* count, fn_stream_t stream) {
+  FN_CHECK_ARG(n > 0 && rgb && target && leaf_tag && sum && count && max_leaves > 0, "n>0, non-null pointers");
+  int64_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(leaf_sumcount_kernel, dim3((int)g), dim3(256), 0, fn::S(stream), n, rgb, target, leaf_tag,
+                     max_leaves, sum, count);
+  FN_LAUNCH_CHECK();
+  return 0;
+}

@@ -150,3 +150,37 @@ extern "C" int64_t fastnerf_tree_adjust(fn_tree* t, const float* table_host, int
   }
   return total;
 }
+
+
+// nerf++ fork (nerf++-ours/tree.py:609-632): same walk, criterion `leaf_loss.mean() > thres` with the mean
+// over the leaf's rays x 3 channels.  sum_host / count_host: [n_images, max_leaves] (fp64 sums of
+// |gt-pred| over rays and channels, ray counts).  Leaves without rays are left alone.
+extern "C" int64_t fastnerf_tree_adjust_mean(fn_tree* t, const double* sum_host, const int32_t* count_host,
+                                             int max_leaves, double thres) {
+  if (!t || !sum_host || !count_host || max_leaves < 1) { fn::set_error("fastnerf_tree_adjust_mean: bad argument"); return -1; }
+  const float thr = (float)thres;
+  int64_t total = 0;
+  for (int img = 0; img < t->n_images; ++img) {
+    OneTree& tr = t->trees[img];
+    if ((int)tr.leaves.size() > max_leaves) { fn::set_error("fastnerf_tree_adjust_mean: table too narrow"); return -1; }
+    const double min_before = tr.min_area;
+    std::vector<Box> next;
+    next.reserve(tr.leaves.size() * 2);
+    for (size_t li = 0; li < tr.leaves.size(); ++li) {
+      const Box& b = tr.leaves[li];
+      const int32_t cnt = count_host[(size_t)img * max_leaves + li];
+      const float mean = cnt > 0 ? (float)(sum_host[(size_t)img * max_leaves + li] / (3.0 * (double)cnt)) : 0.0f;
+      if (cnt > 0 && mean > thr && area(b) == min_before) {
+        Box c[4];
+        split(b, c);
+        for (int k = 0; k < 4; ++k) next.push_back(c[k]);
+        if (tr.min_area == min_before) tr.min_area /= 4;
+      } else {
+        next.push_back(b);
+      }
+    }
+    tr.leaves.swap(next);
+    total += (int64_t)tr.leaves.size();
+  }
+  return total;
+}

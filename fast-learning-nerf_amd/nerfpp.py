@@ -250,3 +250,43 @@ class CascadeTrainer:
             losses.append(loss2[0])
             ret = outs
         return torch.stack(losses), rgb
+
+
+class QuadTreeManager:
+    """nerf++-ours/tree.py fork of the manager: ctor takes ray samplers (objects with H, W, img [H*W,3],
+    rays_o / rays_d [H*W,3]); picks are 30%..50% variance-weighted (prob=True, rand=args.randSamp_perc);
+    split criterion is the MEAN leaf loss.  Backed by the same native tree as nerf-ours."""
+
+    def __init__(self, ray_samplers, mseThres=0.1, max_depth=5, device='cuda', sharp_imgs=None):
+        from .tree import QuadTreeManager as Base
+        n = len(ray_samplers)
+        H, W = ray_samplers[0].H, ray_samplers[0].W
+        images = torch.as_tensor(np.stack([np.asarray(rs.img).reshape(H, W, 3) for rs in ray_samplers], 0))
+        poses = torch.eye(4)[None, :3, :4].repeat(n, 1, 1)   # unused: rays are supplied by the samplers
+        self._b = Base(H, W, np.eye(3), images, poses, mseThres, max_depth, device=device, criterion='mean',
+                       sharp_imgs=sharp_imgs)
+        dev = torch.device(device)
+        self.origins = torch.stack([torch.as_tensor(np.asarray(rs.rays_o), dtype=torch.float32) for rs in ray_samplers],
+                                   0).reshape(n, H, W, 3)
+        self.dirs = torch.stack([torch.as_tensor(np.asarray(rs.rays_d), dtype=torch.float32) for rs in ray_samplers],
+                                0).reshape(n, H, W, 3)
+        self.images = images
+        self._dev = dev
+        self._dev_data = None
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__['_b'], name)
+
+    def gen_rays_v3_multiThread(self, down_scale=16, prob=True, rand=0.7, debug=False, last_epoch=False):
+        b = self._b
+        pix = b.gen_pixels(down_scale, last_epoch, True, prob=prob, rand=rand)
+        b.result_leaf_tag = b._tags_i32.to(self._dev).contiguous() if self._dev.type == 'cuda' else b._tags_i32
+        if self._dev_data is None:
+            self._dev_data = (self.origins.to(self._dev), self.dirs.to(self._dev), self.images.to(self._dev))
+        o, d, im = self._dev_data
+        p = pix.to(self._dev)
+        i, r, c = p[:, 0], p[:, 1], p[:, 2]
+        return o[i, r, c].contiguous(), d[i, r, c].contiguous(), im[i, r, c].contiguous()
+
+    def adjust_tree_multiThread(self, rgb_gt, rgb_pred, thres=0.001, debug=False):
+        return self._b.adjust_tree_multiThread(rgb_gt, rgb_pred, thres, debug)

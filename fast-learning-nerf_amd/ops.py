@@ -264,3 +264,22 @@ def pp_composite_bwd(part, raw, z, rays11, g_rgb, fg_far=None, g_lambda=None):
                                           ptr(None if g_lambda is None else _f32(g_lambda)), ptr(draw), stream()),
           'fastnerf_pp_composite_bwd')
     return draw
+
+
+def leaf_sumcount(rgb, target, leaf_tag, max_leaves, sums, counts):
+    """Accumulate per-(image, leaf) fp64 sums of |gt-pred| (rays x channels) and ray counts."""
+    require_gpu(rgb, target, leaf_tag, sums, counts)
+    assert sums.dtype == torch.float64 and counts.dtype == torch.int32
+    check(lib().fastnerf_leaf_sumcount(rgb.shape[0], ptr(_f32(rgb)), ptr(_f32(target)), ptr(leaf_tag), int(max_leaves),
+                                       ptr(sums), ptr(counts), stream()), 'fastnerf_leaf_sumcount')
+
+
+def pp_gen_rays(H, W, intrinsics, c2w, device='cuda'):
+    """get_rays_single_image (nerf_sample_ray_split.py:10-34) -> rays_o, rays_d [H*W,3] on the device."""
+    K = np.ascontiguousarray(np.asarray(intrinsics, dtype=np.float64).reshape(4, 4))
+    M = np.ascontiguousarray(np.asarray(c2w, dtype=np.float64).reshape(4, 4))
+    ro = torch.empty(H * W, 3, device=device, dtype=torch.float32)
+    rd = torch.empty(H * W, 3, device=device, dtype=torch.float32)
+    check(lib().fastnerf_pp_gen_rays(int(H), int(W), K.ctypes.data, M.ctypes.data, ptr(ro), ptr(rd), stream()),
+          'fastnerf_pp_gen_rays')
+    return ro, rd

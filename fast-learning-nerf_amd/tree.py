@@ -21,7 +21,14 @@ from ._lib import check, lib
 
 
 class QuadTreeManager:
-    def __init__(self, H, W, K, images, poses, mseThres=0.1, max_depth=5, device='cuda'):
+    def __init__(self, H, W, K, images, poses, mseThres=0.1, max_depth=5, device='cuda', criterion='max',
+                 sharp_imgs=None):
+        """criterion: 'max' (nerf-ours, tree.py:642) or 'mean' (nerf++-ours fork, tree.py:622).
+        sharp_imgs: optional per-image variance maps for prob=True picks (see image_process.py)."""
+        assert criterion in ('max', 'mean')
+        self.criterion = criterion
+        self._sharp_in = sharp_imgs
+        self.processor = None
         if mseThres != 0.0:
             raise NotImplementedError('variance-gated initial subdivision (mseThres>0) is never used by the '
                                       'reference driver (run_nerf.py:337 passes 0.0)')
@@ -110,17 +117,39 @@ class QuadTreeManager:
         rgb = imgs[p[:, 0].long(), p[:, 1].long(), p[:, 2].long()]
         return ro, rd, rgb.contiguous()
 
-    def gen_pixels(self, down_scale=1, last_epoch=False, compat_rng=True):
+    def gen_pixels(self, down_scale=1, last_epoch=False, compat_rng=True, prob=False, rand=1.0):
         """Pixel picks + leaf tags of one epoch (host side of tree.py:377-428 / 569-626).
-        Returns pix [N,3] int64 (image,row,col), already shuffled; sets result_leaf_id."""
+        Returns pix [N,3] int64 (image,row,col), already shuffled; sets result_leaf_id.
+        prob=True: int(n*(1-rand)) picks per leaf are drawn with probability proportional to the local
+        variance map (np.random.choice, then the uniform torch.randint picks: the reference's call
+        order), nerf++-ours/tree.py:566-578."""
         ray_num_per_image = self.epoch_size / self.n_images / down_scale
         ray_num_per_pixel = ray_num_per_image / self.h / self.w
         plans = [self.leaf_plan(i, ray_num_per_pixel, last_epoch) for i in range(self.n_images)]
+        if prob:
+            if self.processor is None:
+                from .image_process import ImageProcessor
+                self.processor = ImageProcessor([self.images[i].cpu().numpy() for i in range(self.n_images)], scale=0,
+                                                sharp_imgs=self._sharp_in)
+            compat_rng = True   # the weighted draw is host-side numpy, as in the reference
         if compat_rng:
             pix, tags = [], []
             for ti, plan in enumerate(plans):
+                boxes = None if (last_epoch or not prob) else self.leaves(ti)
                 for li in range(plan.shape[0]):
                     n, r0, r1, c0, c1 = (int(v) for v in plan[li])
+                    if prob:
+                        x0, y0, x1, y1 = (0.0, 0.0, float(self.h), float(self.w)) if last_epoch else boxes[li]
+                        n1 = int(n * (1 - rand))
+                        n2 = n - n1
+                        block = self.processor.sharp_imgs[ti][int(x0):int(x1), int(y0):int(y1)]
+                        sel = self.processor.sample_pixels(block, n1) + torch.LongTensor([int(x0), int(y0)])
+                        pix.append(torch.cat([torch.full((n1, 1), ti, dtype=torch.int64), sel], 1))
+                        xs = torch.randint(r0, r1, (n2,))
+                        ys = torch.randint(c0, c1, (n2,))
+                        pix.append(torch.stack([torch.full((n2,), ti, dtype=torch.int64), xs, ys], 1))
+                        tags.append(torch.tensor([[ti, li]], dtype=torch.float32).repeat([n, 1]))
+                        continue
                     xs = torch.randint(r0, r1, (n,))
                     ys = torch.randint(c0, c1, (n,))
                     pix.append(torch.stack([torch.full((n,), ti, dtype=torch.int64), xs, ys], 1))
@@ -156,10 +185,7 @@ class QuadTreeManager:
         reference's exact call order (per image, per leaf: randint rows, randint cols; then one
         randperm), so a seeded run selects identical pixels; compat_rng=False draws the same
         distribution vectorised on the device.  Returns (origins, dirs, rgb) on the device."""
-        if prob:
-            raise NotImplementedError('prob=True (variance-weighted picks) is not on the nerf-ours path '
-                                      '(run_nerf.py:440,452 pass prob=False); see SURVEY 8(f) f2')
-        pix = self.gen_pixels(down_scale, last_epoch, compat_rng)
+        pix = self.gen_pixels(down_scale, last_epoch, compat_rng, prob=prob, rand=randSamp_proc)
         self.result_leaf_tag = self._tags_i32.to(self.device).contiguous()
         return self.gather(pix)
 
@@ -177,6 +203,16 @@ class QuadTreeManager:
         self.cur_level += 1
         return int(tot)
 
+    def adjust_tree_from_sumcount(self, sums, counts, thres):
+        """nerf++ fork's MEAN rule (nerf++-ours/tree.py:609-632) from per-(image, leaf) fp64 sums of
+        |gt-pred| and ray counts."""
+        s = sums.detach().double().cpu().contiguous().view(self.n_images, -1)
+        c = counts.detach().to(torch.int32).cpu().contiguous().view(self.n_images, -1)
+        tot = check(lib().fastnerf_tree_adjust_mean(self._t, s.data_ptr(), c.data_ptr(), int(s.shape[1]), float(thres)),
+                    'fastnerf_tree_adjust_mean')
+        self.cur_level += 1
+        return int(tot)
+
     def adjust_tree_multiThread(self, rgb_gt, rgb_pred, thres=0.001, debug=False):
         """tree.py:533-557 with the reference's arguments: the epoch's gt / predicted colours in
         the order of self.result_leaf_id.  The segmented max runs on the device."""
@@ -184,6 +220,13 @@ class QuadTreeManager:
         gt = torch.as_tensor(rgb_gt, dtype=torch.float32).to(dev).contiguous()
         pred = torch.as_tensor(rgb_pred, dtype=torch.float32).to(dev).contiguous()
         ml = self.max_leaves()
+        if self.criterion == 'mean':
+            sums = torch.zeros(self.n_images * ml, device=dev, dtype=torch.float64)
+            counts = torch.zeros(self.n_images * ml, device=dev, dtype=torch.int32)
+            ops.leaf_sumcount(pred, gt, self.result_leaf_tag, ml, sums, counts)
+            tot = self.adjust_tree_from_sumcount(sums, counts, thres)
+            print('After sudivide, there are {} child nodes'.format(tot))
+            return tot
         table = torch.zeros(self.n_images * ml, device=dev, dtype=torch.int32)
         ops.mse_leafmax(pred, None, gt, want_grads=False, leaf_tag=self.result_leaf_tag, max_leaves=ml, table=table)
         tot = self.adjust_tree_from_table(table.view(self.n_images, ml), thres)

@@ -133,6 +133,14 @@ int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const flo
                         const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
 
 /* ---- nerf++-ours additions ------------------------------------------- */
+/* get_rays_single_image (nerf_sample_ray_split.py:10-34): intrinsics_host / c2w_host are 4x4 row-major
+ * doubles; rays_o / rays_d [H*W,3]. */
+int fastnerf_pp_gen_rays(int H, int W, const double* intrinsics_host, const double* c2w_host, float* rays_o,
+                         float* rays_d, fn_stream_t stream);
+/* nerf++ quadtree fork: per-(image, leaf) sum of |gt-pred| over rays and channels (fp64) and ray count
+ * feeding the MEAN split criterion (nerf++-ours/tree.py:622); the caller zeroes sum / count. */
+int fastnerf_leaf_sumcount(int64_t n, const float* rgb, const float* target, const int32_t* leaf_tag, int max_leaves,
+                           double* sum, int32_t* count, fn_stream_t stream);
 /* intersect_sphere (ddp_train_nerf.py:54-69); *n_outside counts rays whose camera is not inside the
  * unit sphere (the reference raises in that case). */
 int fastnerf_pp_intersect_sphere(int64_t n, const float* rays11, float* fg_far, int* n_outside, fn_stream_t stream);
@@ -172,6 +180,9 @@ int fastnerf_tree_leaf_plan(const fn_tree* t, int image, double ray_num_per_pixe
  * table: table_host [n_images, max_leaves] floats (max |gt-pred| per leaf,
  * negative = leaf had no ray).  Returns total leaves after the split, <0 on error. */
 int64_t fastnerf_tree_adjust(fn_tree* t, const float* table_host, int max_leaves, double thres);
+/* nerf++ fork: mean criterion from fp64 sums + counts ([n_images, max_leaves] each). */
+int64_t fastnerf_tree_adjust_mean(fn_tree* t, const double* sum_host, const int32_t* count_host, int max_leaves,
+                                  double thres);
 
 #ifdef __cplusplus
 }

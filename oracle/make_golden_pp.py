@@ -95,6 +95,40 @@ def main():
         rec['l0.' + k] = ret[k].numpy()
     rec['l0.fg_z'] = fg_depth.numpy(); rec['l0.bg_z'] = bg_depth.numpy(); rec['fg_far'] = fg_far.numpy()
     np.savez(os.path.join(OUT, 'g10_pp_step.npz'), **rec)
+    # ---- G12: nerf++ quadtree fork (prob=True picks, MEAN criterion) ---------------------------
+    import tree as TP   # nerf++-ours/tree.py (REF is first on sys.path)
+
+    class RS:           # the attributes QuadTreeManager reads from a RaySamplerSingleImage (tree.py:171-184)
+        pass
+    Ht, Wt, nimg = 48, 40, 2
+    samplers = []
+    for i in range(nimg):
+        rs = RS()
+        rs.H, rs.W = Ht, Wt
+        rr, cc = np.meshgrid(np.arange(Ht), np.arange(Wt), indexing='ij')
+        tex = 0.5 + 0.5 * np.sin(0.37 * rr + 0.11 * i) * np.cos(0.23 * cc)          # smooth texture for the variance map
+        rs.img = np.stack([tex, (rr * Wt + cc) / 4096.0, np.full_like(tex, i / 8.0)], -1).astype(np.float32).reshape(-1, 3)
+        rs.rays_o = np.tile(np.array([[0.1 * i, 0.0, 0.2]], dtype=np.float32), (Ht * Wt, 1))
+        rs.rays_d = np.stack([cc.reshape(-1) / Wt - 0.5, rr.reshape(-1) / Ht - 0.5, -np.ones(Ht * Wt)], -1).astype(np.float32)
+        samplers.append(rs)
+    mgr = TP.QuadTreeManager(samplers, mseThres=0.0, max_depth=2)
+    rec = {'H': Ht, 'W': Wt, 'images': np.stack([s_.img.reshape(Ht, Wt, 3) for s_ in samplers], 0),
+           'rays_d': np.stack([s_.rays_d.reshape(Ht, Wt, 3) for s_ in samplers], 0),
+           'sharp': np.stack(mgr.processor.sharp_imgs, 0)}
+    for rnd in range(4):
+        torch.manual_seed(200 + rnd)
+        np.random.seed(300 + rnd)
+        o, d, rgbt = mgr.gen_rays_v3_multiThread(down_scale=1, prob=True, rand=0.5, last_epoch=False)
+        rec[f'r{rnd}_leaf_id'] = mgr.result_leaf_id.numpy().copy()
+        rec[f'r{rnd}_rgb'] = rgbt.numpy().copy()
+        rec[f'r{rnd}_d'] = d.numpy().copy()
+        pred = torch.clamp(rgbt + (torch.rand(rgbt.shape, generator=g) - 0.5) * 0.2 *
+                           (torch.rand(rgbt.shape[0], 1, generator=g) < 0.5).float(), 0, 1)
+        rec[f'r{rnd}_pred'] = pred.numpy().copy()
+        mgr.adjust_tree_multiThread(rgbt, pred, thres=0.012)
+        for ti in range(nimg):
+            rec[f'r{rnd}_after_t{ti}'] = np.array([[c_.x0, c_.y0, c_.x1, c_.y1] for c_ in mgr.childrens[ti]], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g12_pp_tree.npz'), **rec)
     print('wrote g10 goldens', sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.startswith('g10')))
 
 

@@ -163,3 +163,47 @@ def test_cascade_step_g10(fn, golden_dir):
     before = net.flat.clone()
     tr.step(ro, rd, tgt, rand=rand, update=True)
     assert float((net.flat - before).abs().max()) <= 5e-4 * 1.001
+
+
+def test_pp_gen_rays_and_sumcount(fn, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g10_pp_ops.npz'))
+    ro, rd = fn.ops.pp_gen_rays(6, 8, g['intr'], g['c2w'])
+    assert np.abs(ro.cpu().numpy() - g['ro_s']).max() < 1e-7
+    assert np.abs(rd.cpu().numpy() - g['rd_s']).max() < 1e-6 * np.abs(g['rd_s']).max()
+    # per-(image, leaf) fp64 sums / counts == host reduction; mean rule on the device tags
+    gen = torch.Generator().manual_seed(9)
+    n, ml = 5000, 13
+    rgb, tgt = torch.rand(n, 3, generator=gen), torch.rand(n, 3, generator=gen)
+    tag = torch.stack([torch.randint(0, 3, (n,), generator=gen), torch.randint(0, ml, (n,), generator=gen)], 1).int()
+    sums = torch.zeros(3 * ml, dtype=torch.float64).cuda()
+    counts = torch.zeros(3 * ml, dtype=torch.int32).cuda()
+    fn.ops.leaf_sumcount(rgb.cuda(), tgt.cuda(), tag.cuda(), ml, sums, counts)
+    slot = tag[:, 0].long() * ml + tag[:, 1].long()
+    ref_s = torch.zeros(3 * ml, dtype=torch.float64).index_add_(0, slot, (tgt - rgb).abs().double().sum(-1))
+    ref_c = torch.zeros(3 * ml, dtype=torch.int32).index_add_(0, slot, torch.ones(n, dtype=torch.int32))
+    assert torch.equal(counts.cpu(), ref_c) and (sums.cpu() - ref_s).abs().max() < 1e-9
+
+
+def test_pp_quadtree_on_device(fn, golden_dir):
+    """nerf++ manager end to end on the GPU: picks identical to the reference's (G12), device gather,
+    device sum/count reduction, MEAN split."""
+    g = np.load(os.path.join(golden_dir, 'g12_pp_tree.npz'))
+    H, W = int(g['H']), int(g['W'])
+
+    class RS:
+        pass
+    samplers = []
+    for i in range(g['images'].shape[0]):
+        rs = RS(); rs.H, rs.W = H, W
+        rs.img = g['images'][i].reshape(-1, 3); rs.rays_o = np.zeros((H * W, 3), dtype=np.float32)
+        rs.rays_d = g['rays_d'][i].reshape(-1, 3)
+        samplers.append(rs)
+    mgr = fn.nerfpp.QuadTreeManager(samplers, mseThres=0.0, max_depth=2, sharp_imgs=list(g['sharp']))
+    for rnd in range(4):
+        torch.manual_seed(200 + rnd); np.random.seed(300 + rnd)
+        o, d, rgb = mgr.gen_rays_v3_multiThread(down_scale=1, prob=True, rand=0.5)
+        assert rgb.is_cuda and np.array_equal(rgb.cpu().numpy(), g[f'r{rnd}_rgb'])
+        assert np.array_equal(d.cpu().numpy(), g[f'r{rnd}_d'])
+        mgr.adjust_tree_multiThread(rgb, torch.from_numpy(g[f'r{rnd}_pred']).cuda(), thres=0.012)
+        for ti in range(len(samplers)):
+            assert np.array_equal(mgr.leaves(ti), g[f'r{rnd}_after_t{ti}']), (rnd, ti)
