@@ -43,6 +43,11 @@ SIGNATURES = {
     'fastnerf_mlp_pack_ex': (I, [I, P, P, P, P]),
     'fastnerf_mlp_fwd_ex': (I, [I, L, I, P, P, P, P, P, P, P]),
     'fastnerf_mlp_bwd_ex': (I, [I, L, I, P, P, P, P, P, P, P, P]),
+    'fastnerf_mlp_bf16_floats': (L, [I, I, L]),
+    'fastnerf_mlp_bf16_partial_floats': (L, []),
+    'fastnerf_mlp_bf16_pack': (I, [I, P, P, P, P]),
+    'fastnerf_mlp_bf16_fwd': (I, [I, L, I, P, P, P, P, P, P, P]),
+    'fastnerf_mlp_bf16_bwd': (I, [I, L, I, P, P, P, P, P, P, P, P]),
     'fastnerf_pp_intersect_sphere': (I, [L, P, P, P, P]),
     'fastnerf_pp_fg_depths': (I, [L, I, F, P, I, P, U64, P, P]),
     'fastnerf_pp_sample_pdf_merge': (I, [L, I, I, P, P, I, P, U64, P, P, P]),

@@ -1,0 +1,1011 @@
+// mlp_bf16.hip -- split-bf16 ("bf16x3") implementation of the fused 8x256 MLP (forward, dX chain, dW) for gfx950.
+//
+// Every fp32 operand x is carried as a pair of bf16 values (hi = bf16(x), lo = bf16(x - hi)); a product
+// a*b is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_32x32x16_bf16 (three
+// 32-cycle K=16 instructions instead of eight 64-cycle K=2 fp32 instructions: 5.3x the matrix rate).  The
+// dropped lo*lo term and the residual of the two-term split are ~2^-17 relative per product; measured against
+// the fp32-MFMA kernels of mlp.hip this moves raw network outputs by ~1e-6 relative and the rendered RGB by
+// 5e-7 (tools/bf16x3_study.py), i.e. fp32 rounding class -- two orders below the 1e-4 parity tolerance.
+//
+// Same network functions as mlp.hip (nerf-ours/model.py:37-63, nerf++-ours/nerf_network.py:70-142); kinds 0/1.
+//
+// Tiling: 64-point tiles, two 256-thread workgroups per CU, wave = 64x64 output block (2x2 MFMA tiles).
+// LDS per workgroup: H as two bf16 planes [64][256] (hi, lo: 32 KiB each) + E planes [64][64] (8 KiB each).
+// Output columns are interleaved between a wave's two MFMA column tiles (n = wn*64 + 2*j + nt) so that a lane
+// owns two ADJACENT outputs and the epilogue writes them as one packed 32-bit LDS store per plane.
+//
+// Saved tensors (activations for dW, pre-activation gradients) are written straight from the accumulator
+// registers in "K-fragment order": the MFMA C layout gives a lane 4 consecutive POINTS of one channel, which
+// is half of the 8-point x 1-channel 16-byte element an A/B operand of the dW GEMM (K = points) wants.  Layout
+// of a tensor with C channels (CT = C/32 channel tiles), in 16-byte units:
+//     (((tile*CT + ct)*4 + ks)*2 + part)*64 + kb*32 + c        part: 0 hi / 1 lo;  points tile*64+ks*16+kb*8+0..7
+// so the dW kernel loads every operand fragment as one contiguous 1 KiB wave access with no LDS transpose.
+// 256-channel tensors are stored in the wave-permuted channel order q = (n>>6)*64 + (n&1)*32 + ((n&63)>>1)
+// (then every store instruction writes 512 contiguous bytes); the final reduction un-permutes.
+#include <stdlib.h>
+#include "common.h"
+#include "mlp_layout.h"
+
+using namespace fnl;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned long long u64;
+
+#define BTM 64
+#define BNTHR 256
+#define BLDS_BYTES (2 * BTM * 256 * 2 + 2 * BTM * 64 * 2)   // 81920
+
+static int b_num_cus() {
+  static int n = 0;
+  if (n > 0) return n;
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+  if (n <= 0) n = 256;
+  return n;
+}
+
+__device__ __forceinline__ unsigned bf16_rne(float v) {   // bits of bf16(v), round to nearest even
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void split2(float v, unsigned& hi, unsigned& lo) {
+  hi = bf16_rne(v);
+  lo = bf16_rne(v - __uint_as_float(hi << 16));
+}
+__device__ __forceinline__ void unpk8(const uint4& h, const uint4& l, float (&o)[8]) {
+  const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    o[2 * q] = __uint_as_float(hw[q] << 16) + __uint_as_float(lw[q] << 16);
+    o[2 * q + 1] = __uint_as_float(hw[q] & 0xffff0000u) + __uint_as_float(lw[q] & 0xffff0000u);
+  }
+}
+
+// ---- saved-tensor layouts (16-byte units) -----------------------------------------------------------
+// activations: pe(2 ct) | h0..h7 (8 ct each) | feat (8) | vpe (1) | hv (4) | ReLU sign bits h0..h7 | sign bits hv
+__host__ __device__ inline int64_t ba_pe(int64_t nt) { return 0; }
+__host__ __device__ inline int64_t ba_h(int64_t nt, int l) { return nt * 1024 + (int64_t)l * nt * 4096; }
+__host__ __device__ inline int64_t ba_feat(int64_t nt) { return nt * (1024 + 8 * 4096); }
+__host__ __device__ inline int64_t ba_vpe(int64_t nt) { return ba_feat(nt) + nt * 4096; }
+__host__ __device__ inline int64_t ba_hv(int64_t nt) { return ba_vpe(nt) + nt * 512; }
+__host__ __device__ inline int64_t ba_mask(int64_t nt) { return ba_hv(nt) + nt * 2048; }    // 1024 units / tile
+__host__ __device__ inline int64_t ba_maskv(int64_t nt) { return ba_mask(nt) + nt * 1024; }  // 64 units / tile
+__host__ __device__ inline int64_t ba_total(int64_t nt) { return ba_maskv(nt) + nt * 64; }
+// pre-activation gradients: dY0..dY7 (8 ct each) | dfeat (8) | dYv (4) | dalpha (fp32, 64 per tile)
+__host__ __device__ inline int64_t bd_y(int64_t nt, int l) { return (int64_t)l * nt * 4096; }
+__host__ __device__ inline int64_t bd_feat(int64_t nt) { return 8 * nt * 4096; }
+__host__ __device__ inline int64_t bd_yv(int64_t nt) { return 9 * nt * 4096; }
+__host__ __device__ inline int64_t bd_alpha(int64_t nt) { return 9 * nt * 4096 + nt * 2048; }
+__host__ __device__ inline int64_t bd_total(int64_t nt) { return bd_alpha(nt) + nt * 16; }
+
+// ---- packed bf16 weights --------------------------------------------------------------------------
+// dst (uint4 units): ((nt_g*KS + ks)*2 + part)*64 + lane  ->  8 bf16 = B[k = ks*16 + (lane>>5)*8 + 0..7][n(nt_g, lane)]
+//   N == 256: n = (nt_g>>1)*64 + 2*(lane&31) + (nt_g&1)      N == 128 (view layer): n = nt_g*32 + (lane&31)
+//   forward  (trans 0): B[k][n] = W[n][col(k)]   (two input segments, the first padded to segA_pad)
+//   backward (trans 1): B[k][n] = W[k][coloff + n] for k < segA_valid
+struct BPackDesc {
+  int64_t src_off, dst_off;   // floats / uint4
+  int ld, N, Kp, segA_pad, segA_valid, segB_valid, trans, coloff;
+};
+struct BPackTable { BPackDesc d[19]; };
+
+__global__ void __launch_bounds__(256) bpack_kernel(BPackTable tab, const float* __restrict__ params,
+                                                     uint4* __restrict__ dst_fwd, uint4* __restrict__ dst_bwd) {
+  const BPackDesc d = tab.d[blockIdx.y];
+  const int KS = d.Kp / 16;
+  const int64_t total = (int64_t)(d.N / 32) * KS * 2 * 64;
+  uint4* dst = (d.trans ? dst_bwd : dst_fwd) + d.dst_off;
+  const float* src = params + d.src_off;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(e & 63);
+    const int part = (int)((e >> 6) & 1);
+    const int64_t blk = e >> 7;
+    const int nt = (int)(blk / KS), ks = (int)(blk % KS);
+    const int n = (d.N == 256) ? ((nt >> 1) * 64 + 2 * (l & 31) + (nt & 1)) : (nt * 32 + (l & 31));
+    unsigned w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kp = ks * 16 + (l >> 5) * 8 + j;
+      float v = 0.f;
+      if (d.trans) {
+        if (kp < d.segA_valid) v = src[(int64_t)kp * d.ld + d.coloff + n];
+      } else {
+        int col = -1;
+        if (kp < d.segA_pad) { if (kp < d.segA_valid) col = kp; }
+        else { const int q = kp - d.segA_pad; if (q < d.segB_valid) col = d.segA_valid + q; }
+        if (col >= 0) v = src[(int64_t)n * d.ld + col];
+      }
+      unsigned hi, lo;
+      split2(v, hi, lo);
+      w[j] = part ? lo : hi;
+    }
+    uint4 o;
+    o.x = w[0] | (w[1] << 16); o.y = w[2] | (w[3] << 16); o.z = w[4] | (w[5] << 16); o.w = w[6] | (w[7] << 16);
+    dst[e] = o;
+  }
+}
+
+// packed offsets in uint4 units; forward ids 0..7 trunk, 8 feature, 9 view; backward ids 0 Vt, 1 Ft, 2..8 = L7t..L1t
+struct BOff { int64_t off[10]; int64_t total; };
+static BOff b_offsets(const NetLayout& L) {
+  BOff o{};
+  int64_t p = 0;
+  for (int l = 0; l < 10; ++l) {
+    o.off[l] = p;
+    const int kp = (l == 0) ? L.pe_pad : (l == 5 ? L.pe_pad + 256 : (l == 9 ? 288 : 256));
+    const int N = (l == 9) ? 128 : 256;
+    p += (int64_t)(N / 32) * (kp / 16) * 2 * 64;
+  }
+  o.total = p;
+  return o;
+}
+static BOff b_offsets_bwd() {
+  BOff o{};
+  int64_t p = 0;
+  for (int j = 0; j < 9; ++j) {
+    o.off[j] = p;
+    p += (int64_t)8 * ((j == 0 ? 128 : 256) / 16) * 2 * 64;
+  }
+  o.off[9] = p;
+  o.total = p;
+  return o;
+}
+static const NetLayout& b_layout(int kind) {
+  static const NetLayout L[3] = {make_layout(0), make_layout(1), make_layout(2)};
+  return L[kind < 0 || kind > 2 ? 0 : kind];
+}
+
+extern "C" int64_t fastnerf_mlp_bf16_floats(int kind, int what, int64_t n_points) {
+  if (kind < 0 || kind > 1) return -1;
+  const int64_t nt = (n_points + BTM - 1) / BTM;
+  switch (what) {
+    case 1: return b_offsets(b_layout(kind)).total * 4;   // packed forward weights
+    case 2: return b_offsets_bwd().total * 4;              // packed backward (transposed) weights
+    case 3: return ba_total(nt) * 4;                       // saved activations for n_points
+    case 4: return bd_total(nt) * 4;                       // pre-activation gradients for n_points
+    default: return -1;
+  }
+}
+
+extern "C" int fastnerf_mlp_bf16_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd,
+                                      fn_stream_t stream) {
+  FN_CHECK_ARG((kind == 0 || kind == 1) && params && packed_fwd, "kind in {0,1}, non-null pointers");
+  const NetLayout& L = b_layout(kind);
+  const BOff O = b_offsets(L), OB = b_offsets_bwd();
+  BPackTable T;
+  for (int l = 0; l < 8; ++l) {
+    BPackDesc d{};
+    d.src_off = L.LW[l]; d.dst_off = O.off[l]; d.N = 256;
+    d.ld = (l == 0) ? L.in_pe : (l == 5 ? 256 + L.in_pe : 256);
+    d.Kp = (l == 0) ? L.pe_pad : (l == 5 ? L.pe_pad + 256 : 256);
+    if (l == 0) { d.segA_pad = L.pe_pad; d.segA_valid = L.in_pe; d.segB_valid = 0; }
+    else if (l == 5) { d.segA_pad = L.pe_pad; d.segA_valid = L.in_pe; d.segB_valid = 256; }
+    else { d.segA_pad = 256; d.segA_valid = 256; d.segB_valid = 0; }
+    T.d[l] = d;
+  }
+  { BPackDesc d{}; d.src_off = L.FW; d.dst_off = O.off[8]; d.ld = 256; d.N = 256; d.Kp = 256; d.segA_pad = 256; d.segA_valid = 256; T.d[8] = d; }
+  { BPackDesc d{}; d.src_off = L.VW; d.dst_off = O.off[9]; d.ld = 283; d.N = 128; d.Kp = 288; d.segA_pad = 256; d.segA_valid = 256; d.segB_valid = 27; T.d[9] = d; }
+  int njobs = 10;
+  if (packed_bwd) {
+    // Vt: dfeat[m][i] = sum_o dYv[m][o] Wv[o][i]
+    { BPackDesc d{}; d.trans = 1; d.src_off = L.VW; d.dst_off = OB.off[0]; d.ld = 283; d.N = 256; d.Kp = 128; d.segA_valid = 128; T.d[10] = d; }
+    { BPackDesc d{}; d.trans = 1; d.src_off = L.FW; d.dst_off = OB.off[1]; d.ld = 256; d.N = 256; d.Kp = 256; d.segA_valid = 256; T.d[11] = d; }
+    for (int l = 7; l >= 1; --l) {
+      BPackDesc d{};
+      d.trans = 1; d.src_off = L.LW[l]; d.dst_off = OB.off[9 - l]; d.N = 256; d.Kp = 256; d.segA_valid = 256;
+      d.ld = (l == 5) ? 256 + L.in_pe : 256;
+      d.coloff = (l == 5) ? L.in_pe : 0;
+      T.d[12 + (7 - l)] = d;
+    }
+    njobs = 19;
+  }
+  hipLaunchKernelGGL(bpack_kernel, dim3(32, njobs), dim3(256), 0, fn::S(stream), T, params,
+                     reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- LDS addressing (byte offsets inside a plane) ---------------------------------------------------
+__device__ __forceinline__ int hoff(int m, int slot) { return m * 512 + ((slot ^ (m & 15)) << 4); }        // 32 slots/row
+__device__ __forceinline__ int eoff(int m, int slot) { return m * 128 + ((slot ^ ((m >> 1) & 7)) << 4); }  // 8 slots/row
+
+__device__ __forceinline__ f32x16 bmfma(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// accumulate nks (even) k-steps of 16.  A planes in LDS (H layout or E layout); B packed in global.
+template <int NT, bool A_IS_E>
+__device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, const char* Alo, int a_ks0, int nks,
+                                      const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane) {
+  asm volatile("" : "+v"(lane));
+  const int lrow = lane & 31, kb = lane >> 5;
+  auto aoff = [&](int mt, int ks) {
+    const int m = mt * 32 + lrow;
+    return A_IS_E ? eoff(m, (a_ks0 + ks) * 2 + kb) : hoff(m, (a_ks0 + ks) * 2 + kb);
+  };
+  const uint4* bptr[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128 + lane;
+  uint4 ah0[2], al0[2], bh0[NT], bl0[NT], ah1[2], al1[2], bh1[NT], bl1[NT];
+  auto ld = [&](uint4 (&ah)[2], uint4 (&al)[2], uint4 (&bh)[NT], uint4 (&bl)[NT], int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { bh[nt] = bptr[nt][ks * 128]; bl[nt] = bptr[nt][ks * 128 + 64]; }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int o = aoff(mt, ks);
+      ah[mt] = *reinterpret_cast<const uint4*>(Ahi + o);
+      al[mt] = *reinterpret_cast<const uint4*>(Alo + o);
+    }
+  };
+  auto mm = [&](const uint4 (&ah)[2], const uint4 (&al)[2], const uint4 (&bh)[NT], const uint4 (&bl)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bmfma(ah[mt], bh[nt], acc[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bmfma(ah[mt], bl[nt], acc[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bmfma(al[mt], bh[nt], acc[mt][nt]);
+  };
+  ld(ah0, al0, bh0, bl0, 0);
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks += 2) {
+    ld(ah1, al1, bh1, bl1, ks + 1);
+    mm(ah0, al0, bh0, bl0);
+    if (ks + 2 < nks) ld(ah0, al0, bh0, bl0, ks + 2);
+    mm(ah1, al1, bh1, bl1);
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void bzero(f32x16 (&acc)[2][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+}
+// C layout of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int bcrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+struct EpiArgs {
+  const float* bias;          // BIAS
+  const float* dalpha4;       // RANK1: LDS float4 rows, .w = dalpha
+  const float* wa;            // RANK1: alpha / sigma weights
+  const void* mask_in;        // MASK: the forward's ReLU sign bits of this tile and layer (one word per thread)
+  void* mask_out;             // MOUT: where this tile's sign bits go
+  uint2* gsave;               // GSAVE: K-fragment tensor, already offset to the tile
+};
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {   // bf16(a) | bf16(b) << 16, one v_cvt_pk_bf16_f32
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = cvt_pk(a, b);
+  lo = cvt_pk(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void split1(float a, unsigned& hi, unsigned& lo) {   // low 16 bits of hi / lo
+  hi = cvt_pk(a, 0.f);
+  lo = cvt_pk(a - __uint_as_float(hi << 16), 0.f);
+}
+// ReLU sign bits: every thread shifts one bit per value into a private word, most significant = first value.
+// v is the value AFTER v_max_f32(v, +0), which never returns -0, so "positive" == "bits != 0".
+__device__ __forceinline__ unsigned mask_push(unsigned m, float v) {
+  return __builtin_amdgcn_alignbit(m, __float_as_uint(v) + 0x7fffffffu, 31);   // (m << 1) | (v > 0)
+}
+__device__ __forceinline__ float mask_pop(unsigned& m, float v) {
+  const unsigned keep = (unsigned)((int)m >> 31);
+  m <<= 1;
+  return __uint_as_float(__float_as_uint(v) & keep);
+}
+
+// Epilogue of the 256-wide layers.  Lane (j = lane&31, half = lane>>5) owns columns n0 = wn*64 + 2j (+1) of the
+// rows mt*32 + bcrow(r, lane).  v = acc (+bias) (+dalpha*wa) (ReLU | forward-mask), split to (hi, lo), then
+//   - LDS: the column pair is one packed 32-bit store per plane and row,
+//   - global: 4 consecutive rows of one column = 8 bytes of a K-fragment element (see the file header),
+//   - sign bits (forward, ReLU layers): 64 per thread and layer, order mt, r, nt.
+template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE>
+__device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs& ea, char* Hhi, char* Hlo, int wn,
+                                        int lane) {
+  asm volatile("" : "+v"(lane));
+  const int j = lane & 31, half = lane >> 5;
+  const int n0 = wn * 64 + 2 * j;
+  float b0 = 0.f, b1 = 0.f, wa0 = 0.f, wa1 = 0.f;
+  if (BIAS) { b0 = ea.bias[n0]; b1 = ea.bias[n0 + 1]; }
+  if (RANK1) { wa0 = ea.wa[n0]; wa1 = ea.wa[n0 + 1]; }
+  uint2 min2 = make_uint2(0u, 0u), mout2 = make_uint2(0u, 0u);
+  if (MASK) min2 = reinterpret_cast<const uint2*>(ea.mask_in)[wn * 64 + lane];
+  const int slot = n0 >> 3, inslot = (n0 & 7) * 2;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    unsigned H[16], L[16];
+    unsigned mi = mt ? min2.y : min2.x, mo = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mt * 32 + bcrow(r, lane);
+      float v0 = acc[mt][0][r] + b0, v1 = acc[mt][1][r] + b1;
+      if (RANK1) {
+        const float da = ea.dalpha4[m * 4 + 3];
+        v0 = fmaf(da, wa0, v0);
+        v1 = fmaf(da, wa1, v1);
+      }
+      if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      if (MOUT) { mo = mask_push(mo, v0); mo = mask_push(mo, v1); }
+      if (MASK) { v0 = mask_pop(mi, v0); v1 = mask_pop(mi, v1); }
+      split_pair(v0, v1, H[r], L[r]);
+      const int o = hoff(m, slot) + inslot;
+      *reinterpret_cast<unsigned*>(Hhi + o) = H[r];
+      *reinterpret_cast<unsigned*>(Hlo + o) = L[r];
+    }
+    if (mt) mout2.y = mo; else mout2.x = mo;
+    if (GSAVE) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ct = wn * 2 + nt, ks = mt * 2 + (g >> 1), kb = g & 1;
+          uint2* p = ea.gsave + ((((ct * 4 + ks) * 2) * 64 + kb * 32 + j) * 2 + half);
+          const unsigned sel = nt ? 0x07060302u : 0x05040100u;   // the nt-th 16 bits of two consecutive rows
+          uint2 h, l;
+          h.x = __builtin_amdgcn_perm(H[4 * g + 1], H[4 * g], sel); h.y = __builtin_amdgcn_perm(H[4 * g + 3], H[4 * g + 2], sel);
+          l.x = __builtin_amdgcn_perm(L[4 * g + 1], L[4 * g], sel); l.y = __builtin_amdgcn_perm(L[4 * g + 3], L[4 * g + 2], sel);
+          p[0] = h;
+          p[128] = l;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (MOUT) reinterpret_cast<uint2*>(ea.mask_out)[wn * 64 + lane] = mout2;
+}
+
+// Epilogue of the 128-wide view layer / dYv: wave wn owns columns wn*32 + j (natural order, 4 channel tiles);
+// a lane converts two consecutive rows at a time (= consecutive points of the K-fragment element).
+template <bool BIAS, bool RELU, bool MASK, bool MOUT, bool GSAVE>
+__device__ __forceinline__ void bepi128(const f32x16 (&acc)[2][1], const EpiArgs& ea, char* Hhi, char* Hlo, int wn,
+                                        int lane) {
+  asm volatile("" : "+v"(lane));
+  const int j = lane & 31, half = lane >> 5;
+  const int n = wn * 32 + j;
+  const float bv = BIAS ? ea.bias[n] : 0.f;
+  unsigned mi = 0u, mo = 0u;
+  if (MASK) mi = reinterpret_cast<const unsigned*>(ea.mask_in)[wn * 64 + lane];
+  const int slot = n >> 3, inslot = (n & 7) * 2;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    unsigned H[8], L[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int m = mt * 32 + bcrow(r, lane);   // rows m, m+1
+      float v0 = acc[mt][0][r] + bv, v1 = acc[mt][0][r + 1] + bv;
+      if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      if (MOUT) { mo = mask_push(mo, v0); mo = mask_push(mo, v1); }
+      if (MASK) { v0 = mask_pop(mi, v0); v1 = mask_pop(mi, v1); }
+      split_pair(v0, v1, H[r >> 1], L[r >> 1]);
+      const int o0 = hoff(m, slot) + inslot, o1 = hoff(m + 1, slot) + inslot;
+      *reinterpret_cast<unsigned short*>(Hhi + o0) = (unsigned short)H[r >> 1];
+      *reinterpret_cast<unsigned short*>(Hhi + o1) = (unsigned short)(H[r >> 1] >> 16);
+      *reinterpret_cast<unsigned short*>(Hlo + o0) = (unsigned short)L[r >> 1];
+      *reinterpret_cast<unsigned short*>(Hlo + o1) = (unsigned short)(L[r >> 1] >> 16);
+    }
+    if (GSAVE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ks = mt * 2 + (g >> 1), kb = g & 1;
+        uint2* p = ea.gsave + ((((wn * 4 + ks) * 2) * 64 + kb * 32 + j) * 2 + half);
+        p[0] = make_uint2(H[2 * g], H[2 * g + 1]);
+        p[128] = make_uint2(L[2 * g], L[2 * g + 1]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (MOUT) reinterpret_cast<unsigned*>(ea.mask_out)[wn * 64 + lane] = mo;
+}
+
+// =========================================================================================
+// forward
+// =========================================================================================
+template <bool SAVE>
+__global__ void __launch_bounds__(BNTHR, 2)
+mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
+                    const float* __restrict__ params, const uint4* __restrict__ pk, float* __restrict__ raw,
+                    uint4* __restrict__ act, NetLayout lay, BOff boff) {
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  char* Hhi = bsm;
+  char* Hlo = bsm + BTM * 512;
+  char* Ehi = bsm + 2 * BTM * 512;
+  char* Elo = Ehi + BTM * 128;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (P + BTM - 1) / BTM;
+  u64* maskw_all = SAVE ? reinterpret_cast<u64*>(act + ba_mask(ntiles)) : nullptr;            // [tile][8][256] u64
+  unsigned* maskv_all = SAVE ? reinterpret_cast<unsigned*>(act + ba_maskv(ntiles)) : nullptr;   // [tile][256] u32
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * BTM;
+    const int valid = (int)((P - p0) < BTM ? (P - p0) : BTM);
+    const int pm = tid >> 2, pq = tid & 3;
+    int64_t pp = p0 + pm;
+    if (pp >= P) pp = P - 1;
+    const int64_t ray = pp / S;
+    const float* rr = rays + ray * 11;
+    // store one PE channel at row pm: E planes, and (SAVE) the K-fragment staging copy that aliases H
+    auto est = [&](int c, float v) {
+      unsigned h, l;
+      split1(v, h, l);
+      const int o = eoff(pm, c >> 3) + (c & 7) * 2;
+      *reinterpret_cast<unsigned short*>(Ehi + o) = (unsigned short)h;
+      *reinterpret_cast<unsigned short*>(Elo + o) = (unsigned short)l;
+      if (SAVE) {
+        const int t = (((((c >> 5) * 4 + (pm >> 4)) * 2) * 64) + ((pm >> 3) & 1) * 32 + (c & 31)) * 16 + (pm & 7) * 2;
+        *reinterpret_cast<unsigned short*>(bsm + t) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(bsm + t + 1024) = (unsigned short)l;
+      }
+    };
+    {
+      const float zz = zv[pp];
+      float x[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[c] = fadd(rr[c], fmul(rr[3 + c], zz));
+      if (pq == 0) { est(0, x[0]); est(1, x[1]); est(2, x[2]); est(63, 0.f); }
+      for (int jj = pq; jj < 30; jj += 4) {
+        const int k = jj / 3, dim = jj - 3 * k;
+        const float a = fmul(x[dim], (float)(1 << k));
+        est(3 + 6 * k + dim, sinf(a));
+        est(6 + 6 * k + dim, cosf(a));
+      }
+    }
+    __syncthreads();
+    if (SAVE) {   // PE tile in K-fragment order: 16 KiB staged at the head of H
+      uint4* dst = act + ba_pe(ntiles) + tile * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i * 256 + tid] = *reinterpret_cast<const uint4*>(bsm + (i * 256 + tid) * 16);
+    }
+    f32x16 acc[2][2];
+    EpiArgs ea{};
+    // L0
+    bzero<2>(acc);
+    bgemm<2, true>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 4, 0, wn * 2, lane);
+    if (SAVE) __syncthreads();   // staging copy read out before H is written
+    ea.bias = params + lay.LB[0];
+    if (SAVE) {
+      ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, 0) + tile * 4096);
+      ea.mask_out = maskw_all + (tile * 8 + 0) * 256;
+    }
+    bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l < 8; ++l) {
+      bzero<2>(acc);
+      const uint4* B = pk + boff.off[l];
+      if (l == 5) {
+        bgemm<2, true>(acc, Ehi, Elo, 0, 4, B, 20, 0, wn * 2, lane);
+        bgemm<2, false>(acc, Hhi, Hlo, 0, 16, B, 20, 4, wn * 2, lane);
+      } else {
+        bgemm<2, false>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane);
+      }
+      __syncthreads();
+      ea.bias = params + lay.LB[l];
+      if (SAVE) {
+        ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, l) + tile * 4096);
+        ea.mask_out = maskw_all + (tile * 8 + l) * 256;
+      }
+      bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+      __syncthreads();
+    }
+    // alpha head + view-direction encoding
+    float alpha_val;
+    {
+      const float* wa = params + lay.AW;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = pq * 64 + i * 8;
+        const int o = hoff(pm, k >> 3);
+        float h8[8];
+        unpk8(*reinterpret_cast<const uint4*>(Hhi + o), *reinterpret_cast<const uint4*>(Hlo + o), h8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s = fmaf(h8[q], wa[k + q], s);
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      alpha_val = s + params[lay.AB];
+      const float v[3] = {rr[8], rr[9], rr[10]};
+      unsigned short* gv = SAVE ? reinterpret_cast<unsigned short*>(act + ba_vpe(ntiles) + tile * 512) : nullptr;
+      auto estv = [&](int c, float val) {
+        unsigned h, l;
+        split1(val, h, l);
+        const int o = eoff(pm, c >> 3) + (c & 7) * 2;
+        *reinterpret_cast<unsigned short*>(Ehi + o) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(Elo + o) = (unsigned short)l;
+        if (SAVE) {
+          const int t = ((((pm >> 4) * 2) * 64) + ((pm >> 3) & 1) * 32 + c) * 8 + (pm & 7);   // 2-byte units
+          gv[t] = (unsigned short)h;
+          gv[t + 512] = (unsigned short)l;
+        }
+      };
+      if (pq == 0) {
+        estv(0, v[0]); estv(1, v[1]); estv(2, v[2]);
+#pragma unroll
+        for (int c = 27; c < 32; ++c) estv(c, 0.f);
+      }
+      for (int jj = pq; jj < 12; jj += 4) {
+        const int k = jj / 3, dim = jj - 3 * k;
+        const float a = fmul(v[dim], (float)(1 << k));
+        estv(3 + 6 * k + dim, sinf(a));
+        estv(6 + 6 * k + dim, cosf(a));
+      }
+    }
+    // feature layer (no ReLU)
+    bzero<2>(acc);
+    bgemm<2, false>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane);
+    __syncthreads();
+    ea.bias = params + lay.FB;
+    if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(ntiles) + tile * 4096);
+    bepi256<true, false, false, false, false, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+    __syncthreads();
+    // view layer: [feat256 | vpe32] -> 128, ReLU
+    {
+      f32x16 av[2][1];
+      bzero<1>(av);
+      bgemm<1, false>(av, Hhi, Hlo, 0, 16, pk + boff.off[9], 18, 0, wn, lane);
+      bgemm<1, true>(av, Ehi, Elo, 0, 2, pk + boff.off[9], 18, 16, wn, lane);
+      __syncthreads();
+      ea.bias = params + lay.VB;
+      if (SAVE) {
+        ea.gsave = reinterpret_cast<uint2*>(act + ba_hv(ntiles) + tile * 2048);
+        ea.mask_out = maskv_all + tile * 256;
+      }
+      bepi128<true, true, false, SAVE, SAVE>(av, ea, Hhi, Hlo, wn, lane);
+      __syncthreads();
+    }
+    // rgb head
+    {
+      const float* wr = params + lay.RW;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = pq * 32 + i * 8;
+        const int o = hoff(pm, k >> 3);
+        float h8[8];
+        unpk8(*reinterpret_cast<const uint4*>(Hhi + o), *reinterpret_cast<const uint4*>(Hlo + o), h8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          s0 = fmaf(h8[q], wr[k + q], s0);
+          s1 = fmaf(h8[q], wr[128 + k + q], s1);
+          s2 = fmaf(h8[q], wr[256 + k + q], s2);
+        }
+      }
+      s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+      s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+      s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+      if (pq == 0 && pm < valid) {
+        float4 o;
+        o.x = s0 + params[lay.RB]; o.y = s1 + params[lay.RB + 1]; o.z = s2 + params[lay.RB + 2]; o.w = alpha_val;
+        *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const float* z,
+                                     const float* params, const float* packed_fwd, float* raw, float* act,
+                                     fn_stream_t stream) {
+  FN_CHECK_ARG((kind == 0 || kind == 1) && n >= 0 && S >= 1, "kind in {0,1}, n>=0, S>=1");
+  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
+  if (n == 0) return 0;
+  const NetLayout& lay = b_layout(kind);
+  const BOff O = b_offsets(lay);
+  const int64_t P = n * S;
+  const int64_t ntiles = (P + BTM - 1) / BTM;
+  int grid = b_num_cus() * 2;
+  if (ntiles < grid) grid = (int)ntiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
+    attr_done = true;
+  }
+  const uint4* pk = reinterpret_cast<const uint4*>(packed_fwd);
+  if (act)
+    hipLaunchKernelGGL(mlp_fwd_bf16_kernel<true>, dim3(grid), dim3(BNTHR), BLDS_BYTES, fn::S(stream), P, S, rays11, z,
+                       params, pk, raw, reinterpret_cast<uint4*>(act), lay, O);
+  else
+    hipLaunchKernelGGL(mlp_fwd_bf16_kernel<false>, dim3(grid), dim3(BNTHR), BLDS_BYTES, fn::S(stream), P, S, rays11, z,
+                       params, pk, raw, static_cast<uint4*>(nullptr), lay, O);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+// =========================================================================================
+// backward: dX chain (pre-activation gradients of every layer, K-fragment order)
+// =========================================================================================
+__global__ void __launch_bounds__(BNTHR, 2)
+mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* __restrict__ act,
+                       const float* __restrict__ params, const uint4* __restrict__ pkt, uint4* __restrict__ dact,
+                       NetLayout lay, BOff boff) {
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  char* Hhi = bsm;
+  char* Hlo = bsm + BTM * 512;
+  float* Dr = reinterpret_cast<float*>(bsm + 2 * BTM * 512);   // [64] float4: drgb, dalpha of the tile's rows
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (P + BTM - 1) / BTM;
+  const u64* maskw_all = reinterpret_cast<const u64*>(act + ba_mask(ntiles));
+  const unsigned* maskv_all = reinterpret_cast<const unsigned*>(act + ba_maskv(ntiles));
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * BTM;
+    if (tid < BTM) {
+      const int64_t p = p0 + tid;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < P) d = *reinterpret_cast<const float4*>(draw + p * 4);
+      *reinterpret_cast<float4*>(Dr + tid * 4) = d;
+      reinterpret_cast<float*>(dact + bd_alpha(ntiles))[p0 + tid] = d.w;   // compact copy for the dW rank-1 row
+    }
+    __syncthreads();
+    EpiArgs ea{};
+    // ---- dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] ---------------------------------------------------
+    {
+      f32x16 av[2][1];
+      const int n = wn * 32 + (lane & 31);
+      const float* wr = params + lay.RW;
+      const float w0 = wr[n], w1 = wr[128 + n], w2 = wr[256 + n];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float4 d = *reinterpret_cast<const float4*>(Dr + (mt * 32 + bcrow(r, lane)) * 4);
+          av[mt][0][r] = fmaf(d.z, w2, fmaf(d.y, w1, d.x * w0));
+        }
+      ea.mask_in = maskv_all + tile * 256;
+      ea.gsave = reinterpret_cast<uint2*>(dact + bd_yv(ntiles) + tile * 2048);
+      bepi128<false, false, true, false, true>(av, ea, Hhi, Hlo, wn, lane);
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+    // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ----------------------------------------------------------
+    bzero<2>(acc);
+    bgemm<2, false>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane);
+    __syncthreads();
+    ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(ntiles) + tile * 4096);
+    bepi256<false, false, false, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+    __syncthreads();
+    // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ---------------------------------------------------
+    bzero<2>(acc);
+    bgemm<2, false>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane);
+    __syncthreads();
+    ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, 7) + tile * 4096);
+    ea.mask_in = maskw_all + (tile * 8 + 7) * 256;
+    ea.dalpha4 = Dr;
+    ea.wa = params + lay.AW;
+    bepi256<false, false, true, true, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+    __syncthreads();
+    // ---- dY_{l-1} = (dY_l . W_l[:, h part]) * [h_{l-1} > 0],  l = 7..1 ---------------------------------
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+      bzero<2>(acc);
+      bgemm<2, false>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane);
+      __syncthreads();
+      ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, l - 1) + tile * 4096);
+      ea.mask_in = maskw_all + (tile * 8 + (l - 1)) * 256;
+      bepi256<false, false, true, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+      __syncthreads();
+    }
+  }
+}
+
+// =========================================================================================
+// backward: dW = dY^T X.  Operand fragments come straight from the K-fragment tensors (no LDS); every
+// workgroup owns a contiguous range of 64-point tiles and writes one fp32 partial (position order).
+// =========================================================================================
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+__global__ void __launch_bounds__(WO * WI * 64, 1)
+mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, int CTo, const uint4* __restrict__ X,
+                       int CTi, const float* __restrict__ dalpha, float* __restrict__ partial_w,
+                       float* __restrict__ partial_b, float* __restrict__ partial_r) {
+  constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave / WI, wi = wave % WI;
+  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = blockIdx.x * per;
+  int64_t t1 = t0 + per;
+  if (t1 > ntiles) t1 = ntiles;
+
+  f32x16 acc[TO][TI];
+#pragma unroll
+  for (int a = 0; a < TO; ++a)
+#pragma unroll
+    for (int b = 0; b < TI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum[TO], rsum[TI];
+#pragma unroll
+  for (int a = 0; a < TO; ++a) bsum[a] = 0.f;
+#pragma unroll
+  for (int b = 0; b < TI; ++b) rsum[b] = 0.f;
+
+  const int64_t nq = (t1 > t0) ? (t1 - t0) * 4 : 0;   // k-steps of 16 points
+  uint4 ah0[TO], al0[TO], xh0[TI], xl0[TI], ah1[TO], al1[TO], xh1[TI], xl1[TI];
+  auto ld = [&](uint4 (&ah)[TO], uint4 (&al)[TO], uint4 (&xh)[TI], uint4 (&xl)[TI], int64_t q) {
+    const int64_t tile = t0 + (q >> 2);
+    const int ks = (int)(q & 3);
+    const uint4* pa = dY + ((tile * CTo + wo * TO) * 4 + ks) * 128 + lane;
+    const uint4* px = X + ((tile * CTi + wi * TI) * 4 + ks) * 128 + lane;
+#pragma unroll
+    for (int i = 0; i < TO; ++i) { ah[i] = pa[i * 512]; al[i] = pa[i * 512 + 64]; }
+#pragma unroll
+    for (int j = 0; j < TI; ++j) { xh[j] = px[j * 512]; xl[j] = px[j * 512 + 64]; }
+  };
+  auto mm = [&](const uint4 (&ah)[TO], const uint4 (&al)[TO], const uint4 (&xh)[TI], const uint4 (&xl)[TI], int64_t q) {
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+      for (int j = 0; j < TI; ++j) acc[i][j] = bmfma(ah[i], xh[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+      for (int j = 0; j < TI; ++j) acc[i][j] = bmfma(ah[i], xl[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+      for (int j = 0; j < TI; ++j) acc[i][j] = bmfma(al[i], xh[j], acc[i][j]);
+    if (BIAS && wi == 0) {
+#pragma unroll
+      for (int i = 0; i < TO; ++i) {
+        float v[8];
+        unpk8(ah[i], al[i], v);
+        bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+    }
+    if (RANK1 && wo == 0) {
+      const float4* dp = reinterpret_cast<const float4*>(dalpha + (t0 + (q >> 2)) * 64 + (q & 3) * 16 + (lane >> 5) * 8);
+      const float4 d0 = dp[0], d1 = dp[1];
+      const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int j = 0; j < TI; ++j) {
+        float v[8];
+        unpk8(xh[j], xl[j], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rsum[j] = fmaf(da[e], v[e], rsum[j]);
+      }
+    }
+  };
+  if (nq > 0) {
+    ld(ah0, al0, xh0, xl0, 0);
+#pragma unroll 1
+    for (int64_t q = 0; q < nq; q += 2) {
+      ld(ah1, al1, xh1, xl1, q + 1);
+      mm(ah0, al0, xh0, xl0, q);
+      if (q + 2 < nq) ld(ah0, al0, xh0, xl0, q + 2);
+      mm(ah1, al1, xh1, xl1, q + 1);
+    }
+  }
+  float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (wo * TO + i) * 32 + bcrow(r, lane);
+        const int c = (wi * TI + j) * 32 + (lane & 31);
+        pw[(int64_t)o * KI + c] = acc[i][j][r];
+      }
+  if (BIAS && wi == 0) {
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+      const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (lane < 32) partial_b[(int64_t)blockIdx.x * NO + (wo * TO + i) * 32 + lane] = s;
+    }
+  }
+  if (RANK1 && wo == 0) {
+#pragma unroll
+    for (int j = 0; j < TI; ++j) {
+      const float s = rsum[j] + __shfl_xor(rsum[j], 32, 64);
+      if (lane < 32) partial_r[(int64_t)blockIdx.x * KI + (wi * TI + j) * 32 + lane] = s;
+    }
+  }
+}
+
+// rgb head + alpha bias gradients: out[wg][0..383] = dWr[c][k], [384..386] = dbr[c], [387] = dba
+__global__ void __launch_bounds__(128) head_grads_bf16_kernel(int64_t P, int64_t ntiles, const float* __restrict__ draw,
+                                                               const uint4* __restrict__ hv,
+                                                               float* __restrict__ partial) {
+  const int k = threadIdx.x;
+  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int64_t ta = blockIdx.x * per;
+  int64_t tb = ta + per;
+  if (tb > ntiles) tb = ntiles;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, sb = 0.f;
+  for (int64_t t = ta; t < tb; ++t) {
+#pragma unroll 2
+    for (int c = 0; c < 8; ++c) {   // c = ks*2 + kb: 8 points each
+      const uint4* p = hv + ((t * 4 + (k >> 5)) * 4 + (c >> 1)) * 128 + (c & 1) * 32 + (k & 31);
+      float h[8];
+      unpk8(p[0], p[64], h);
+      const int64_t pb = t * 64 + c * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pb + e < P) d = *reinterpret_cast<const float4*>(draw + (pb + e) * 4);
+        s0 = fmaf(d.x, h[e], s0); s1 = fmaf(d.y, h[e], s1); s2 = fmaf(d.z, h[e], s2);
+        if (k < 4) sb += (k == 0) ? d.x : (k == 1) ? d.y : (k == 2) ? d.z : d.w;
+      }
+    }
+  }
+  float* o = partial + (int64_t)blockIdx.x * 388;
+  o[k] = s0; o[128 + k] = s1; o[256 + k] = s2;
+  if (k < 4) o[384 + k] = sb;
+}
+
+// ---- one launch reduces every job's per-workgroup partials into the flat gradient ------------
+// perm bit 0: rows are in wave-permuted channel order, bit 1: columns are
+struct BRedSeg {
+  int64_t src, wg_stride, dst;
+  int nwg, rows, cols, ld, valid_cols, perm;
+};
+#define BMAX_SEGS 32
+struct BRedTable {
+  BRedSeg s[BMAX_SEGS];
+  int n;
+};
+__host__ __device__ inline int b_unperm(int q) { return (q & ~63) + 2 * (q & 31) + ((q >> 5) & 1); }
+
+__global__ void __launch_bounds__(256) breduce_kernel(BRedTable tab, const float* __restrict__ partial,
+                                                       float* __restrict__ grads) {
+  const BRedSeg sg = tab.s[blockIdx.y];
+  const int64_t total = (int64_t)sg.rows * sg.cols;
+  const float* src = partial + sg.src;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / sg.cols), c = (int)(e % sg.cols);
+    if (sg.perm & 1) r = b_unperm(r);
+    if (sg.perm & 2) c = b_unperm(c);
+    if (c >= sg.valid_cols) continue;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 8 <= sg.nwg; w += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
+    }
+    for (; w < sg.nwg; ++w) a[0] += src[(int64_t)w * sg.wg_stride + e];
+    grads[sg.dst + (int64_t)r * sg.ld + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+}
+
+struct BJob { int NO, KI, bias, rank1; };
+static BJob b_job(int j) {
+  switch (j) {
+    case 0: return {256, 64, 1, 0};     // L0 (pe)
+    case 8: return {256, 64, 0, 0};     // L5 (pe part)
+    case 9: return {256, 256, 1, 1};    // feature / remap (+ alpha / sigma row)
+    case 10: return {128, 256, 1, 0};   // view layer (feature part)
+    case 11: return {128, 32, 0, 0};    // view layer (vpe part)
+    default: return {256, 256, 1, 0};   // 1..7: L1..L7 (h part)
+  }
+}
+#define BHEAD_MAX_WG 1024
+static int64_t b_job_floats(int j) {
+  const BJob d = b_job(j);
+  return (int64_t)d.NO * d.KI + (d.bias ? d.NO : 0) + (d.rank1 ? d.KI : 0);
+}
+static int64_t b_job_base(int j, int ncu) {
+  int64_t o = 0;
+  for (int i = 0; i < j; ++i) o += b_job_floats(i) * ncu;
+  return o;
+}
+extern "C" int64_t fastnerf_mlp_bf16_partial_floats(void) {
+  return b_job_base(12, b_num_cus()) + (int64_t)BHEAD_MAX_WG * 388;
+}
+
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, const uint4* X, int CTi, const float* dalpha,
+                       float* base, int nwg, hipStream_t st) {
+  constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  float* pw = base;
+  float* pb = base + (int64_t)nwg * NO * KI;
+  float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
+  hipLaunchKernelGGL((mlp_bwd_dw_bf16_kernel<WO, WI, TO, TI, BIAS, RANK1>), dim3(nwg), dim3(WO * WI * 64), 0, st, P,
+                     ntiles, dY, CTo, X, CTi, dalpha, pw, pb, pr);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+static void b_add_seg(BRedTable& T, int64_t src, int64_t wg_stride, int nwg, int rows, int cols, int64_t dst, int ld,
+                      int valid_cols, int perm) {
+  BRedSeg& s = T.s[T.n++];
+  s.src = src; s.wg_stride = wg_stride; s.nwg = nwg; s.rows = rows; s.cols = cols; s.dst = dst; s.ld = ld;
+  s.valid_cols = valid_cols; s.perm = perm;
+}
+
+extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const float* act_f,
+                                     const float* params, const float* packed_bwd, float* dact_f, float* partial,
+                                     float* grads, fn_stream_t stream) {
+  FN_CHECK_ARG((kind == 0 || kind == 1) && n > 0 && S >= 1, "kind in {0,1}, n>0, S>=1");
+  FN_CHECK_ARG(draw && act_f && params && packed_bwd && dact_f && partial && grads, "null pointer");
+  const NetLayout& L = b_layout(kind);
+  const BOff OB = b_offsets_bwd();
+  hipStream_t st = fn::S(stream);
+  const int64_t P = n * S;
+  const int64_t nt = (P + BTM - 1) / BTM;
+  const int ncu = b_num_cus();
+  const uint4* act = reinterpret_cast<const uint4*>(act_f);
+  uint4* dact = reinterpret_cast<uint4*>(dact_f);
+  int grid = ncu * 2;
+  if (nt < grid) grid = (int)nt;
+  static bool attr_done = false;
+  if (!attr_done) {
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_dx_bf16_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(mlp_bwd_dx_bf16_kernel, dim3(grid), dim3(BNTHR), BLDS_BYTES, st, P, draw, act, params,
+                     reinterpret_cast<const uint4*>(packed_bwd), dact, L, OB);
+  FN_LAUNCH_CHECK();
+
+  int nwg = ncu;
+  if (nt < nwg) nwg = (int)nt;
+  BRedTable T;
+  T.n = 0;
+  int rc;
+  auto region = [&](int j) { return partial + b_job_base(j, ncu); };
+  // permW: bit0 rows permuted, bit1 cols permuted
+  auto segs = [&](int j, int64_t dstW, int ld, int validc, int permW, int64_t dstB, int64_t dstR) {
+    const BJob d = b_job(j);
+    const int64_t b = b_job_base(j, ncu);
+    b_add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc, permW);
+    int64_t o = b + (int64_t)nwg * d.NO * d.KI;
+    if (d.bias) { b_add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO, (permW & 1) ? 2 : 0); o += (int64_t)nwg * d.NO; }
+    if (d.rank1) b_add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI, (permW & 2));
+  };
+  const uint4* a_pe = act + ba_pe(nt);
+  // L0
+  if ((rc = b_launch_dw<4, 1, 2, 2, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 2, nullptr, region(0), nwg, st))) return rc;
+  segs(0, L.LW[0], L.in_pe, L.in_pe, 1, L.LB[0], 0);
+  // L1..L7 (h part)
+  for (int l = 1; l < 8; ++l) {
+    if ((rc = b_launch_dw<2, 2, 4, 4, true, false>(P, nt, dact + bd_y(nt, l), 8, act + ba_h(nt, l - 1), 8, nullptr, region(l), nwg, st))) return rc;
+    segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, 3, L.LB[l], 0);
+  }
+  // L5 pe part
+  if ((rc = b_launch_dw<4, 1, 2, 2, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st))) return rc;
+  segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 1, 0, 0);
+  // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
+  if ((rc = b_launch_dw<2, 2, 4, 4, true, true>(P, nt, dact + bd_feat(nt), 8, act + ba_h(nt, 7), 8,
+                                                 reinterpret_cast<const float*>(dact + bd_alpha(nt)), region(9), nwg, st))) return rc;
+  segs(9, L.FW, 256, 256, 3, L.FB, L.AW);
+  // view layer
+  if ((rc = b_launch_dw<2, 2, 2, 4, true, false>(P, nt, dact + bd_yv(nt), 4, act + ba_feat(nt), 8, nullptr, region(10), nwg, st))) return rc;
+  segs(10, L.VW, 283, 256, 2, L.VB, 0);
+  if ((rc = b_launch_dw<4, 1, 1, 1, false, false>(P, nt, dact + bd_yv(nt), 4, act + ba_vpe(nt), 1, nullptr, region(11), nwg, st))) return rc;
+  segs(11, L.VW + 256, 283, 27, 0, 0, 0);
+  // rgb head + alpha bias
+  {
+    int hg = (int)(nt > BHEAD_MAX_WG ? BHEAD_MAX_WG : nt);
+    if (hg < 1) hg = 1;
+    const int64_t hb = b_job_base(12, ncu);
+    hipLaunchKernelGGL(head_grads_bf16_kernel, dim3(hg), dim3(128), 0, st, P, nt, draw, act + ba_hv(nt), partial + hb);
+    FN_LAUNCH_CHECK();
+    b_add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387, 0);   // dWr (384) + dbr (3), contiguous in every layout
+    b_add_seg(T, hb + 387, 388, hg, 1, 1, L.AB, 1, 1, 0);   // dba
+  }
+  hipLaunchKernelGGL(breduce_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
+  FN_LAUNCH_CHECK();
+  return 0;
+}

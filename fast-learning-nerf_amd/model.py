@@ -76,9 +76,10 @@ class NeRF(nn.Module):
         """(packed_fwd, packed_bwd) fragment-ordered copies of the weights.  Re-packed from the
         flat buffer on every call unless refresh=False (one ~5 MB launch; callers that update
         the weights themselves, e.g. the fused Trainer, pass refresh=False between updates)."""
-        if self._packed is None:
-            self._packed = (torch.empty(ops.PACKED_FWD, device=self.flat.device),
-                            torch.empty(ops.PACKED_BWD, device=self.flat.device))
+        if self._packed is None or self._packed_mode != ops.get_math():
+            self._packed = (torch.empty(ops.packed_floats(0, 1), device=self.flat.device),
+                            torch.empty(ops.packed_floats(0, 2), device=self.flat.device))
+            self._packed_mode = ops.get_math()
             refresh = True
         if refresh:
             ops.mlp_pack(self.flat, *self._packed)

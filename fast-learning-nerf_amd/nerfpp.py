@@ -76,9 +76,10 @@ class MLPNet(nn.Module):
         self._packed = None
 
     def packed(self, refresh=True):
-        if self._packed is None:
-            self._packed = (torch.empty(ops.net_floats(self.kind, 1), device=self.flat.device),
-                            torch.empty(ops.net_floats(self.kind, 2), device=self.flat.device))
+        if self._packed is None or self._packed_mode != ops.get_math():
+            self._packed = (torch.empty(ops.packed_floats(self.kind, 1), device=self.flat.device),
+                            torch.empty(ops.packed_floats(self.kind, 2), device=self.flat.device))
+            self._packed_mode = ops.get_math()
             refresh = True
         if refresh:
             ops.mlp_pack(self.flat, *self._packed, kind=self.kind)
@@ -127,7 +128,7 @@ def _nerfnet_backward(net, saved, g_rgb, out_f=None, out_b=None):
     n, Sf = saved['fg_z'].shape
     Sb = saved['bg_z'].shape[1]
     draw_f = ops.pp_composite_bwd(0, saved['raw_f'], saved['fg_z'], saved['rays11'], g_rgb, saved['fg_far'], g_lam)
-    dact = _Workspace.dact(dev, n * max(Sf, Sb) * ops.DACT_FLOATS)
+    dact = _Workspace.dact(dev, max(ops.dact_floats(n * Sf, 1), ops.dact_floats(n * Sb, 2)))
     ops.mlp_bwd(draw_f, saved['act_f'], net.fg_net.flat, saved['pf'][1], dact, partial, out_f, kind=1)
     draw_b = ops.pp_composite_bwd(1, saved['raw_b'], saved['bg_z'], saved['rays11'], g_bg)
     ops.mlp_bwd(draw_b, saved['act_b'], net.bg_net.flat, saved['pb'][1], dact, partial, out_b, kind=2)

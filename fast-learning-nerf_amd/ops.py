@@ -16,9 +16,50 @@ ACT_SLACK = 8192
 DACT_FLOATS = 2432
 
 
+# ---- matrix-core math mode of the 8x256 MLP kernels ---------------------------------------------
+# 'fp32'   : v_mfma_f32_32x32x2_f32 (csrc/mlp.hip), every kind
+# 'bf16x3' : 3-term split-bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/mlp_bf16.hip),
+#            fp32-class accuracy at ~2.5x the rate; kinds 0/1 (the nerf++ background net stays on fp32)
+import os
+_MATH = os.environ.get('FASTNERF_MATH', 'bf16x3')
+assert _MATH in ('fp32', 'bf16x3'), 'FASTNERF_MATH must be fp32 or bf16x3'
+
+
+def get_math():
+    return _MATH
+
+
+def set_math(mode):
+    """Switch the math mode.  Packed weights / saved activations are mode-specific: models re-pack on their
+    next packed() call; do not mix buffers produced under different modes."""
+    global _MATH
+    assert mode in ('fp32', 'bf16x3')
+    _MATH = mode
+
+
+def _split(kind):
+    return _MATH == 'bf16x3' and int(kind) in (0, 1)
+
+
 def act_floats(P, kind=0):
     """Size (floats) of the saved-activation buffer for P points of a net of the given kind."""
+    if _split(kind):
+        return int(lib().fastnerf_mlp_bf16_floats(int(kind), 3, int(P)))
     return int(lib().fastnerf_mlp_act_floats(int(kind), int(P)))
+
+
+def dact_floats(P, kind=0):
+    """Size (floats) of the pre-activation-gradient workspace for P points."""
+    if _split(kind):
+        return int(lib().fastnerf_mlp_bf16_floats(int(kind), 4, int(P)))
+    return int(P) * DACT_FLOATS
+
+
+def packed_floats(kind, which):
+    """which: 1 forward, 2 backward packed-weight buffer (floats) under the current math mode."""
+    if _split(kind):
+        return int(lib().fastnerf_mlp_bf16_floats(int(kind), int(which), 0))
+    return net_floats(kind, which)
 
 
 def net_floats(kind, what=0):
@@ -98,9 +139,15 @@ def mlp_pack(params, packed_fwd=None, packed_bwd=None, kind=0):
     require_gpu(params)
     assert params.numel() == net_floats(kind, 0) and params.is_contiguous()
     if packed_fwd is None:
-        packed_fwd = torch.empty(net_floats(kind, 1), device=params.device, dtype=torch.float32)
+        packed_fwd = torch.empty(packed_floats(kind, 1), device=params.device, dtype=torch.float32)
     if packed_bwd is None:
-        packed_bwd = torch.empty(net_floats(kind, 2), device=params.device, dtype=torch.float32)
+        packed_bwd = torch.empty(packed_floats(kind, 2), device=params.device, dtype=torch.float32)
+    assert packed_fwd.numel() == packed_floats(kind, 1) and packed_bwd.numel() == packed_floats(kind, 2), \
+        'packed buffers were sized under a different math mode'
+    if _split(kind):
+        check(lib().fastnerf_mlp_bf16_pack(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),
+              'fastnerf_mlp_bf16_pack')
+        return packed_fwd, packed_bwd
     check(lib().fastnerf_mlp_pack_ex(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),
           'fastnerf_mlp_pack_ex')
     return packed_fwd, packed_bwd
@@ -115,19 +162,29 @@ def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None, kind=0):
         raw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
     if act is not None:
         assert act.numel() >= act_floats(n * S, kind)
+    assert packed_fwd.numel() == packed_floats(kind, 1), 'packed weights were produced under a different math mode'
+    if _split(kind):
+        check(lib().fastnerf_mlp_bf16_fwd(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw),
+                                          ptr(act), stream()), 'fastnerf_mlp_bf16_fwd')
+        return raw
     check(lib().fastnerf_mlp_fwd_ex(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw),
                                     ptr(act), stream()), 'fastnerf_mlp_fwd_ex')
     return raw
 
 
 def mlp_bwd_partial_floats():
-    return int(lib().fastnerf_mlp_bwd_partial_floats())
+    return max(int(lib().fastnerf_mlp_bwd_partial_floats()), int(lib().fastnerf_mlp_bf16_partial_floats()))
 
 
 def mlp_bwd(draw, act, params, packed_bwd, dact, partial, grads, kind=0):
     require_gpu(draw, act, params, packed_bwd, dact, partial, grads)
     n, S = draw.shape[0], draw.shape[1]
-    assert dact.numel() >= n * S * DACT_FLOATS and grads.numel() == net_floats(kind, 0)
+    assert dact.numel() >= dact_floats(n * S, kind) and grads.numel() == net_floats(kind, 0)
+    assert packed_bwd.numel() == packed_floats(kind, 2), 'packed weights were produced under a different math mode'
+    if _split(kind):
+        check(lib().fastnerf_mlp_bf16_bwd(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
+                                          ptr(partial), ptr(grads), stream()), 'fastnerf_mlp_bf16_bwd')
+        return grads
     check(lib().fastnerf_mlp_bwd_ex(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
                                     ptr(partial), ptr(grads), stream()), 'fastnerf_mlp_bwd_ex')
     return grads

@@ -98,7 +98,7 @@ def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None):
         if g_rgb is None:
             g_rgb = torch.zeros(n, 3, device=dev)
         draw1 = ops.raw2outputs_bwd(saved['raw1'], saved['z1'], rays11, g_rgb, saved['noise1'], saved['white'])
-        dact = _Workspace.dact(dev, n * S1 * ops.DACT_FLOATS)
+        dact = _Workspace.dact(dev, ops.dact_floats(n * S1))
         if net_f is net_c:
             gtmp = torch.empty_like(out_c)
             ops.mlp_bwd(draw1, saved['act1'], net_f.flat, saved['pf'][1], dact, partial, gtmp)
@@ -112,7 +112,7 @@ def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None):
     if g_c is None:
         g_c = torch.zeros(n, 3, device=dev)
     draw0 = ops.raw2outputs_bwd(saved['raw0'], saved['z0'], rays11, g_c, saved['noise0'], saved['white'])
-    dact = _Workspace.dact(dev, n * S0 * ops.DACT_FLOATS)
+    dact = _Workspace.dact(dev, ops.dact_floats(n * S0))
     ops.mlp_bwd(draw0, saved['act0'], net_c.flat, saved['pc'][1], dact, partial, out_c)
     if gtmp is not None:
         out_c.add_(gtmp)

@@ -132,6 +132,21 @@ int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const f
 int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                         const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
 
+/* ---- split-bf16 ("bf16x3") math mode for kinds 0/1 ---------------------------------------------------
+ * Same network functions and call protocol as fastnerf_mlp_pack_ex / fwd_ex / bwd_ex (run_nerf.py:91-107
+ * run_network -> model.py:37-63, autograd backward of the same), computed on the bf16 matrix cores: every fp32
+ * operand is carried as a (hi, lo) bf16 pair and products are hi*hi + hi*lo + lo*hi with fp32 accumulation
+ * (csrc/mlp_bf16.hip).  Buffers are opaque and sized by fastnerf_mlp_bf16_floats (in 4-byte units):
+ * what 1 packed forward weights, 2 packed backward weights, 3 saved activations for n_points, 4 pre-activation
+ * gradients for n_points.  act == NULL in fwd: inference, nothing saved. */
+int64_t fastnerf_mlp_bf16_floats(int kind, int what, int64_t n_points);
+int64_t fastnerf_mlp_bf16_partial_floats(void);
+int fastnerf_mlp_bf16_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream);
+int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                          const float* packed_fwd, float* raw, float* act, fn_stream_t stream);
+int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                          const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
+
 /* ---- nerf++-ours additions ------------------------------------------- */
 /* get_rays_single_image (nerf_sample_ray_split.py:10-34): intrinsics_host / c2w_host are 4x4 row-major
  * doubles; rays_o / rays_d [H*W,3]. */

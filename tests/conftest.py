@@ -16,3 +16,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=['fp32', 'bf16x3'])
+def math_mode(request):
+    """Run a GPU test under both matrix-core math modes of the MLP kernels (ops.set_math)."""
+    import fastnerf
+    old = fastnerf.ops.get_math()
+    fastnerf.ops.set_math(request.param)
+    yield request.param
+    fastnerf.ops.set_math(old)

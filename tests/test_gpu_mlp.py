@@ -1,5 +1,6 @@
-"""The fp32-MFMA MLP kernels vs the oracle (torch CPU fp32): forward on explicit points,
-backward w.r.t. all 24 parameter tensors, weight packing, tail tiles, linearity."""
+"""The MLP kernels (fp32-MFMA and split-bf16 math modes) vs the oracle (torch CPU fp32): forward on
+explicit points, backward w.r.t. all 24 parameter tensors, weight packing, saved-tensor layout, tail tiles,
+linearity."""
 import os
 
 import numpy as np
@@ -35,7 +36,56 @@ def rays_for_points(pts, viewdirs):
     return r
 
 
+def bf16_pair_to_f32(u16_hi, u16_lo):
+    hi = (u16_hi.astype(np.uint32) << 16).view(np.float32)
+    lo = (u16_lo.astype(np.uint32) << 16).view(np.float32)
+    return hi + lo
+
+
+def decode_kfrag(buf_u16, base_u4, CT, ntiles, permuted):
+    """Test-side restatement of the K-fragment layout (csrc/mlp_bf16.hip header): returns [ntiles*64, CT*32]."""
+    n = ntiles * CT * 4 * 2 * 64 * 8
+    a = buf_u16[base_u4 * 8: base_u4 * 8 + n].reshape(ntiles, CT, 4, 2, 2, 32, 8)   # tile ct ks part kb c e
+    v = bf16_pair_to_f32(a[:, :, :, 0], a[:, :, :, 1])                                # tile ct ks kb c e
+    v = v.transpose(0, 2, 3, 5, 1, 4).reshape(ntiles * 64, CT * 32)                   # (tile ks kb e) (ct c)
+    if permuted:
+        q = np.arange(CT * 32)
+        n_of_q = (q & ~63) + 2 * (q & 31) + ((q >> 5) & 1)
+        out = np.empty_like(v)
+        out[:, n_of_q] = v
+        v = out
+    return v
+
+
+def test_pack_roundtrip_bf16(fn, weights):
+    fn.ops.set_math('bf16x3')
+    flat = flat_of(weights).cuda()
+    pf, pb = fn.ops.mlp_pack(flat)
+    pf = pf.cpu().numpy().view(np.uint16)
+    pb = pb.cpu().numpy().view(np.uint16)
+    W1 = weights['pts_linears.1.weight'].numpy()
+    # layer 1 block: [nt_g][ks][part][lane][8], value = W[n][ks*16 + (lane>>5)*8 + e], n = (nt_g>>1)*64 + 2*(lane&31) + (nt_g&1)
+    off = (8 * 4 * 2 * 64) * 8   # layer 0: 8 column tiles x 4 k-steps
+    blk = pf[off: off + 8 * 16 * 2 * 64 * 8].reshape(8, 16, 2, 64, 8)
+    for nt, ks, l, e in ((0, 0, 0, 0), (3, 5, 37, 2), (7, 15, 63, 7)):
+        n = (nt >> 1) * 64 + 2 * (l & 31) + (nt & 1)
+        got = bf16_pair_to_f32(blk[nt, ks, 0, l, e:e + 1], blk[nt, ks, 1, l, e:e + 1])[0]
+        want = W1[n, ks * 16 + (l >> 5) * 8 + e]
+        assert abs(got - want) <= 2.0 ** -16 * abs(want)
+    # transposed feature layer (second backward block, after Vt with K = 128)
+    Wf = weights['feature_linear.weight'].numpy()
+    off = (8 * 8 * 2 * 64) * 8
+    bt = pb[off: off + 8 * 16 * 2 * 64 * 8].reshape(8, 16, 2, 64, 8)
+    for nt, ks, l, e in ((0, 0, 0, 0), (5, 9, 50, 1)):
+        n = (nt >> 1) * 64 + 2 * (l & 31) + (nt & 1)
+        got = bf16_pair_to_f32(bt[nt, ks, 0, l, e:e + 1], bt[nt, ks, 1, l, e:e + 1])[0]
+        want = Wf[ks * 16 + (l >> 5) * 8 + e, n]
+        assert abs(got - want) <= 2.0 ** -16 * abs(want)
+    fn.ops.set_math(os.environ.get('FASTNERF_MATH', 'bf16x3'))
+
+
 def test_pack_roundtrip(fn, weights):
+    fn.ops.set_math('fp32')
     flat = flat_of(weights).cuda()
     pf, pb = fn.ops.mlp_pack(flat)
     pf, pb = pf.cpu().numpy(), pb.cpu().numpy()
@@ -53,10 +103,11 @@ def test_pack_roundtrip(fn, weights):
     bt = pb[128 * 256:128 * 256 + 65536].reshape(8, 32, 64, 4)
     for jt, ks, l, t in ((0, 0, 0, 0), (5, 9, 50, 1)):
         assert bt[jt, ks, l, t] == Wf[ks * 8 + (l >> 5) * 4 + t, jt * 32 + (l & 31)]
+    fn.ops.set_math(os.environ.get('FASTNERF_MATH', 'bf16x3'))
 
 
 @pytest.mark.parametrize('P', [1, 127, 128, 129, 1000])
-def test_mlp_forward_points(fn, weights, P):
+def test_mlp_forward_points(fn, weights, P, math_mode):
     gen = torch.Generator().manual_seed(P)
     pts = (torch.rand(P, 3, generator=gen) * 2 - 1) * 4.0
     vd = torch.randn(P, 3, generator=gen)
@@ -73,12 +124,21 @@ def test_mlp_forward_points(fn, weights, P):
     act = torch.empty(fn.ops.act_floats(P)).cuda()
     raw2 = fn.ops.mlp_fwd(rays, torch.zeros(P, 1).cuda(), flat, pf, act=act)[:, 0]
     assert torch.equal(raw, raw2)
-    pe = act[:P * 64].view(P, 64).cpu()
+    if math_mode == 'fp32':
+        pe = act[:P * 64].view(P, 64).cpu()
+    else:   # K-fragment tensors: pe (natural channel order), h0 (wave-permuted order)
+        nt = (P + 63) // 64
+        u16 = act.cpu().numpy().view(np.uint16)
+        pe = torch.from_numpy(decode_kfrag(u16, 0, 2, nt, False)[:P])
+        h0 = torch.from_numpy(decode_kfrag(u16, nt * 1024, 8, nt, True)[:P])
+        h0_ref = torch.relu(O.posenc(pts, 10) @ weights['pts_linears.0.weight'].T + weights['pts_linears.0.bias'])
+        assert (h0 - h0_ref).abs().max() < 2e-5
     assert (pe[:, 63] == 0).all()
-    assert (pe[:, :63] - O.posenc(pts, 10)).abs().max() < 2e-6
+    # fp32 mode stores fp32; split mode stores (hi, lo) bf16 pairs = 16 significand bits (|x| <= 4 here)
+    assert (pe[:, :63] - O.posenc(pts, 10)).abs().max() < (2e-6 if math_mode == 'fp32' else 4 * 2.0 ** -16)
 
 
-def test_mlp_backward_vs_autograd(fn, weights):
+def test_mlp_backward_vs_autograd(fn, weights, math_mode):
     gen = torch.Generator().manual_seed(77)
     n, S = 9, 50          # P = 450: 3 full tiles + a tail
     ro = torch.randn(n, 3, generator=gen) * 0.5
@@ -96,7 +156,7 @@ def test_mlp_backward_vs_autograd(fn, weights):
     act = torch.empty(fn.ops.act_floats(P)).cuda()
     raw = fn.ops.mlp_fwd(rb.cuda(), z.cuda(), flat, pf, act=act)
     assert (raw.cpu() - out.detach()).abs().max() < 2e-5
-    dact = torch.empty(P * fn.ops.DACT_FLOATS).cuda()
+    dact = torch.empty(fn.ops.dact_floats(P)).cuda()
     partial = torch.empty(fn.ops.mlp_bwd_partial_floats()).cuda()
     grads = torch.full((fn.ops.NET_PARAMS,), float('nan')).cuda()
     fn.ops.mlp_bwd(cot.cuda(), act, flat, pb, dact, partial, grads)

@@ -101,7 +101,7 @@ def test_bg_mlp_vs_oracle(fn, golden_dir):
     raw_o = torch.cat((torch.logit(rgb.clamp(1e-6, 1 - 1e-6)), torch.zeros(n, S, 1)), -1)
     loss = (torch.logit(rgb) * cot[..., :3]).sum() + (sigma * torch.sign(raw[..., 3]) * cot[..., 3]).sum()
     grads_ref = torch.autograd.grad(loss, list(sd.values()))
-    dact = torch.empty(n * S * fn.ops.DACT_FLOATS).cuda()
+    dact = torch.empty(fn.ops.dact_floats(n * S, 2)).cuda()
     partial = torch.empty(fn.ops.mlp_bwd_partial_floats()).cuda()
     grads = torch.empty(fn.ops.net_floats(2, 0)).cuda()
     fn.ops.mlp_bwd(cot.cuda(), act, flat, pb, dact, partial, grads, kind=2)
@@ -114,7 +114,7 @@ def test_bg_mlp_vs_oracle(fn, golden_dir):
         off += k
 
 
-def test_nerfnet_forward_g10(fn, golden_dir):
+def test_nerfnet_forward_g10(fn, golden_dir, math_mode):
     g = np.load(os.path.join(golden_dir, 'g10_pp_step.npz'))
     nets = make_nets(fn, golden_dir)
     with torch.no_grad():
@@ -126,7 +126,7 @@ def test_nerfnet_forward_g10(fn, golden_dir):
         assert err < TOL_RGB * max(1.0, np.abs(ref).max()), (k, err)
 
 
-def test_cascade_step_g10(fn, golden_dir):
+def test_cascade_step_g10(fn, golden_dir, math_mode):
     g = np.load(os.path.join(golden_dir, 'g10_pp_step.npz'))
     nets = make_nets(fn, golden_dir)
     tr = fn.nerfpp.CascadeTrainer(nets, cascade_samples=(64, 128), lrate=5e-4)

@@ -33,7 +33,7 @@ def build(fn, golden_dir, **over):
     return ktr, kte, grad_vars, optim
 
 
-def test_render_g7(fn, golden_dir):
+def test_render_g7(fn, golden_dir, math_mode):
     g = np.load(os.path.join(golden_dir, 'g7_render.npz'))
     K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
     ktr, kte, _, _ = build(fn, golden_dir)
@@ -57,7 +57,7 @@ def test_render_g7(fn, golden_dir):
     assert set(ex.keys()) == {'raw'} and rgb.shape == (64, 3)
 
 
-def test_train_step_g8_fused(fn, golden_dir):
+def test_train_step_g8_fused(fn, golden_dir, math_mode):
     g = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
     K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
     ktr, _, _, _ = build(fn, golden_dir)
@@ -160,7 +160,7 @@ def test_train_step_g8_autograd_route(fn, golden_dir):
     assert bad <= tot * 0.15, (bad, tot)
 
 
-def test_properties_at_baseline_size(fn, golden_dir):
+def test_properties_at_baseline_size(fn, golden_dir, math_mode):
     """4096 rays, 64+128 samples (BASELINE config 2): properties that need no oracle run."""
     K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
     ktr, kte, _, _ = build(fn, golden_dir)

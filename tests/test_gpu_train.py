@@ -15,7 +15,7 @@ def fn():
     return fastnerf
 
 
-def test_psnr_at_equal_iterations(fn):
+def test_psnr_at_equal_iterations(fn, math_mode):
     imgs, poses, focal = fn.synthetic.make_dataset(n_images=6, H=24, W=24)
     H = W = 24
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])

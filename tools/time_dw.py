@@ -12,7 +12,7 @@ rays11 = ops.pack_rays(ro, rd, 2.0, 6.0)
 z = torch.sort(torch.rand(N, S, device=dev) * 4 + 2, -1).values
 P = N * S
 act = torch.empty(ops.act_floats(P), device=dev); raw = torch.empty(N, S, 4, device=dev)
-dact = torch.empty(P * ops.DACT_FLOATS, device=dev); partial = torch.empty(ops.mlp_bwd_partial_floats(), device=dev)
+dact = torch.empty(ops.dact_floats(P), device=dev); partial = torch.empty(ops.mlp_bwd_partial_floats(), device=dev)
 grads = torch.empty(ops.NET_PARAMS, device=dev); draw = torch.randn(N, S, 4, device=dev) * 1e-3
 ops.mlp_fwd(rays11, z, net.flat, pf, act=act, raw=raw)
 for _ in range(2): ops.mlp_bwd(draw, act, net.flat, pb, dact, partial, grads)
