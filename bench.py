@@ -29,6 +29,7 @@ MAC_PER_POINT = 593408
 FWD_FLOP_PER_POINT = 2 * MAC_PER_POINT     # 1.186816 MFLOP
 TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)  # 893.2 MFLOP
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: dense fp32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 matrix peak
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -144,17 +145,26 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         flops = P * FWD_FLOP_PER_POINT
         achieved = flops / (ms * 1e-3) / 1e12
+        split = ops.get_math() == 'bf16x3'
+        kname = 'void mlp_fwd_bf16_kernel<true>' if split else 'void mlp_fwd_kernel<true>'
         traffic = None   # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            traffic = pmc['kernels']['void mlp_fwd_kernel<true>']['hbm_bytes']
+            traffic = pmc['kernels'][kname]['hbm_bytes']
         except Exception:
             pass
-        roof = {'bound': 'mfma', 'kernel': 'mlp_fwd_kernel<true> (fine pass, 786432 points/launch)',
-                'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01_pmc_traffic.json)',
-                'avg_launch_ms': ms,
-                'flop_per_launch': flops}
+        if split:
+            # every algorithmic multiply-add is issued as 3 bf16 MFMA terms (hi*hi + hi*lo + lo*hi): price the
+            # matrix work actually executed against the dense bf16 MFMA peak
+            peak, executed = BF16_MFMA_PEAK_TFLOPS, 3.0 * achieved
+        else:
+            peak, executed = FP32_MFMA_PEAK_TFLOPS, achieved
+        roof = {'bound': 'mfma', 'kernel': kname[5:] + ' (fine pass, 786432 points/launch)',
+                'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01_pmc_traffic.json)',
+                'avg_launch_ms': ms, 'flop_per_launch': flops, 'algorithmic_tflops': achieved,
+                'mfma_terms_per_product': 3 if split else 1,
+                'hbm_write_GBps': (ops.act_floats(P) * 4 / (ms * 1e-3) / 1e9)}
         del act
 
     if rank == 0:
@@ -163,12 +173,15 @@ def main():
         out = {
             'metric': 'training rays/sec (Lego-like 800x800, 64+128 samples)', 'value': rays_per_s, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (split-bf16 x3 on the bf16 matrix cores, fp32 accumulate)' if ops.get_math() == 'bf16x3' else 'f32',
+            'math_mode': ops.get_math(), 'data': 'synthetic',
             'config': {'workload': 'nerf-ours Lego full 800x800, 4096 rays/GPU/step, 64+128 samples, use_viewdirs, '
                                    'white_bkgd, perturb=1 (BASELINE configs[1])',
                        'rays_per_gpu_per_step': N_RAYS, 'parallelism': f'dp{world}'},
             'final_loss': [float(x) for x in loss2.tolist()],
             'step_tflops_per_gpu': step_tflops, 'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
+            'step_frac_of_bf16_mfma_peak_x3': 3.0 * step_tflops / BF16_MFMA_PEAK_TFLOPS,
             'roofline': roof,
             'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(),
         }
