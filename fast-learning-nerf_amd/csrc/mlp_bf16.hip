@@ -31,6 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
+#ifndef DW_PF
+#define DW_PF 2
+#endif
+#ifndef DW_CFG
+#define DW_CFG 2, 2, 4, 4
+#endif
 #define BTM 64
 #define BNTHR 256
 #define BLDS_BYTES (2 * BTM * 256 * 2 + 2 * BTM * 64 * 2)   // 81920
@@ -714,7 +720,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
 // workgroup owns a contiguous range of 64-point tiles and writes one fp32 partial (position order).
 // =========================================================================================
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
-__global__ void __launch_bounds__(WO * WI * 64, 1)
+__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, int CTo, const uint4* __restrict__ X,
                        int CTi, const float* __restrict__ dalpha, float* __restrict__ partial_w,
                        float* __restrict__ partial_b, float* __restrict__ partial_r) {
@@ -766,7 +772,7 @@ mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, 
     for (int i = 0; i < TO; ++i)
 #pragma unroll
       for (int j = 0; j < TI; ++j) acc[i][j] = bmfma(al[i], xh[j], acc[i][j]);
-    if (BIAS && wi == 0) {
+    if (BIAS && wi == wo % WI) {
 #pragma unroll
       for (int i = 0; i < TO; ++i) {
         float v[8];
@@ -774,7 +780,7 @@ mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, 
         bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       }
     }
-    if (RANK1 && wo == 0) {
+    if (RANK1 && wo == (wi + 1) % WO) {
       const float4* dp = reinterpret_cast<const float4*>(dalpha + (t0 + (q >> 2)) * 64 + (q & 3) * 16 + (lane >> 5) * 8);
       const float4 d0 = dp[0], d1 = dp[1];
       const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -787,6 +793,26 @@ mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, 
       }
     }
   };
+#if DW_PF == 3
+  uint4 ah2[TO], al2[TO], xh2[TI], xl2[TI];
+  if (nq > 0) {
+    ld(ah0, al0, xh0, xl0, 0);
+    if (nq > 1) ld(ah1, al1, xh1, xl1, 1);
+#pragma unroll 1
+    for (int64_t q = 0; q < nq; q += 3) {   // two k-steps of operands in flight behind the one being multiplied
+      if (q + 2 < nq) ld(ah2, al2, xh2, xl2, q + 2);
+      mm(ah0, al0, xh0, xl0, q);
+      if (q + 1 < nq) {
+        if (q + 3 < nq) ld(ah0, al0, xh0, xl0, q + 3);
+        mm(ah1, al1, xh1, xl1, q + 1);
+      }
+      if (q + 2 < nq) {
+        if (q + 4 < nq) ld(ah1, al1, xh1, xl1, q + 4);
+        mm(ah2, al2, xh2, xl2, q + 2);
+      }
+    }
+  }
+#else
   if (nq > 0) {
     ld(ah0, al0, xh0, xl0, 0);
 #pragma unroll 1
@@ -797,6 +823,7 @@ mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, 
       mm(ah1, al1, xh1, xl1, q + 1);
     }
   }
+#endif
   float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
 #pragma unroll
   for (int i = 0; i < TO; ++i)
@@ -808,14 +835,14 @@ mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, 
         const int c = (wi * TI + j) * 32 + (lane & 31);
         pw[(int64_t)o * KI + c] = acc[i][j][r];
       }
-  if (BIAS && wi == 0) {
+  if (BIAS && wi == wo % WI) {
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
       const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
       if (lane < 32) partial_b[(int64_t)blockIdx.x * NO + (wo * TO + i) * 32 + lane] = s;
     }
   }
-  if (RANK1 && wo == 0) {
+  if (RANK1 && wo == (wi + 1) % WO) {
 #pragma unroll
     for (int j = 0; j < TI; ++j) {
       const float s = rsum[j] + __shfl_xor(rsum[j], 32, 64);
@@ -980,14 +1007,14 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   segs(0, L.LW[0], L.in_pe, L.in_pe, 1, L.LB[0], 0);
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
-    if ((rc = b_launch_dw<2, 2, 4, 4, true, false>(P, nt, dact + bd_y(nt, l), 8, act + ba_h(nt, l - 1), 8, nullptr, region(l), nwg, st))) return rc;
+    if ((rc = b_launch_dw<DW_CFG, true, false>(P, nt, dact + bd_y(nt, l), 8, act + ba_h(nt, l - 1), 8, nullptr, region(l), nwg, st))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, 3, L.LB[l], 0);
   }
   // L5 pe part
   if ((rc = b_launch_dw<4, 1, 2, 2, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st))) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 1, 0, 0);
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
-  if ((rc = b_launch_dw<2, 2, 4, 4, true, true>(P, nt, dact + bd_feat(nt), 8, act + ba_h(nt, 7), 8,
+  if ((rc = b_launch_dw<DW_CFG, true, true>(P, nt, dact + bd_feat(nt), 8, act + ba_h(nt, 7), 8,
                                                  reinterpret_cast<const float*>(dact + bd_alpha(nt)), region(9), nwg, st))) return rc;
   segs(9, L.FW, 256, 256, 3, L.FB, L.AW);
   // view layer
