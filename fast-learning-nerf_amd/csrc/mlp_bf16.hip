@@ -31,6 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
+#ifndef DW_NST
+#define DW_NST 3   // LDS stages of the dW operand ring (DW_NST - 1 k-steps prefetched)
+#endif
+#ifndef DW_LDS
+#define DW_LDS 1
+#endif
 #ifndef DW_PF
 #define DW_PF 2
 #endif
@@ -851,6 +857,194 @@ mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, 
   }
 }
 
+// one k-step (16 points) of a dW job from an LDS stage: fragments, 3-term MFMAs, bias / rank-1 side sums
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 bmfma4(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void unpk8v(const u32x4& h, const u32x4& l, float (&o)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    o[2 * q] = __uint_as_float(h[q] << 16) + __uint_as_float(l[q] << 16);
+    o[2 * q + 1] = __uint_as_float(h[q] & 0xffff0000u) + __uint_as_float(l[q] & 0xffff0000u);
+  }
+}
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+__device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&bsum)[TO], float (&rsum)[TI], const uint4* st, int wo,
+                                                 int wi, int lane, const float4& d0, const float4& d1) {
+  constexpr int CTO = WO * TO;
+  // The fragment reads are inline asm: for a plain LDS load hipcc inserts s_waitcnt vmcnt(0) while an LDS-DMA is
+  // pending (it cannot see that the DMA targets another stage), which would drain the prefetch every k-step.
+  // The hand-over in the caller (counted vmcnt + s_barrier) is what orders these reads behind the DMA of THIS stage.
+  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(const char*)st + lane * 16;
+  u32x4 ah[TO], al[TO], xh[TI], xl[TI];
+#pragma unroll
+  for (int i = 0; i < TO; ++i) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(ah[i]) : "v"(lbase + ((wo * TO + i) * 128) * 16));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(al[i]) : "v"(lbase + ((wo * TO + i) * 128 + 64) * 16));
+  }
+#pragma unroll
+  for (int j = 0; j < TI; ++j) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(xh[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128) * 16));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(xl[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128 + 64) * 16));
+  }
+  // wait for the reads; tying the registers to the wait keeps every consumer behind it
+#pragma unroll
+  for (int i = 0; i < TO; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
+#pragma unroll
+  for (int j = 0; j < TI; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[j]), "+v"(xl[j]));
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(ah[i], xh[j], acc[i][j]);
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(ah[i], xl[j], acc[i][j]);
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(al[i], xh[j], acc[i][j]);
+  if (BIAS && wi == wo % WI) {
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+      float v[8];
+      unpk8v(ah[i], al[i], v);
+      bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
+  if (RANK1 && wo == (wi + 1) % WO) {
+    const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+    for (int j = 0; j < TI; ++j) {
+      float v[8];
+      unpk8v(xh[j], xl[j], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rsum[j] = fmaf(da[e], v[e], rsum[j]);
+    }
+  }
+}
+
+// LDS-staged variant: every operand byte is fetched from HBM exactly once per workgroup (the direct-from-global
+// variant above lets the two waves that share an operand tile both miss in L2: PMC showed 1.7x the algorithmic fetch
+// bytes).  Per k-step of 16 points the (CTO + CTI) operand tiles (2 KiB each: hi + lo plane) are copied by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave instruction) into a ring of three stages, two k-steps ahead of the MFMAs;
+// the hand-over is a raw s_barrier behind a counted vmcnt wait so that the newest stage stays in flight across it.
+// dW is HBM bound (matrix pipe ~35% busy), so the DMA issue cost is irrelevant here.
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
+mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, const uint4* __restrict__ X,
+                           const float* __restrict__ dalpha, float* __restrict__ partial_w, float* __restrict__ partial_b,
+                           float* __restrict__ partial_r) {
+  constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  constexpr int CTO = WO * TO, CTI = WI * TI;
+  constexpr int NW = WO * WI;
+  constexpr int STAGE_U4 = (CTO + CTI) * 128;            // uint4 per k-step stage
+  constexpr int NPIECE = 2 * (CTO + CTI);                // 1 KiB pieces per stage
+  constexpr int PPW = (NPIECE + NW - 1) / NW;            // pieces per wave
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave / WI, wi = wave % WI;
+  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = blockIdx.x * per;
+  int64_t t1 = t0 + per;
+  if (t1 > ntiles) t1 = ntiles;
+
+  f32x16 acc[TO][TI];
+#pragma unroll
+  for (int a = 0; a < TO; ++a)
+#pragma unroll
+    for (int b = 0; b < TI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum[TO], rsum[TI];
+#pragma unroll
+  for (int a = 0; a < TO; ++a) bsum[a] = 0.f;
+#pragma unroll
+  for (int b = 0; b < TI; ++b) rsum[b] = 0.f;
+
+  const int64_t nq = (t1 > t0) ? (t1 - t0) * 4 : 0;   // k-steps of 16 points
+  // piece i of this wave = piece p = i*NW + wave of the stage: operand tile p>>1, plane p&1
+  auto dma_stage = [&](int64_t q, int buf) __attribute__((always_inline)) {
+    const int64_t tile = t0 + (q >> 2);
+    const int ks = (int)(q & 3);
+    char* dst = dsm + (size_t)buf * (STAGE_U4 * 16);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = i * NW + wave;
+      if (NPIECE % NW == 0 || p < NPIECE) {
+        const int ct = p >> 1, half = p & 1;
+        const uint4* src = (ct < CTO) ? dY + ((tile * CTO + ct) * 4 + ks) * 128 + half * 64 + lane
+                                      : X + ((tile * CTI + (ct - CTO)) * 4 + ks) * 128 + half * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+  if (nq > 0) {   // nq is a multiple of 4 (>= DW_NST - 1)
+    const bool full_share = (NPIECE % NW == 0) || (PPW - 1) * NW + wave < NPIECE;   // this wave issues PPW pieces / stage
+    // wait until at most n of this wave's newest stages are still in flight
+    auto wait_stages = [&](int n) __attribute__((always_inline)) {
+      if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (n == 1) { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW - 1) : "memory"); }
+      else { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PPW - 1)) : "memory"); }
+    };
+#pragma unroll
+    for (int i = 0; i < DW_NST - 1; ++i) dma_stage(i, i);
+    wait_stages(DW_NST - 2);   // stage 0 landed (own pieces)
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+#pragma unroll 1
+    for (int64_t q = 0; q < nq; ++q) {
+      float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+      if (RANK1 && wo == (wi + 1) % WO) {   // before the DMA issue: its wait must not drain the newest stage
+        const float4* dp = reinterpret_cast<const float4*>(dalpha + (t0 + (q >> 2)) * 64 + (q & 3) * 16 + (lane >> 5) * 8);
+        d0 = dp[0]; d1 = dp[1];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const int bn = (buf >= 1) ? buf - 1 : DW_NST - 1;   // (buf + DW_NST - 1) % DW_NST: the stage consumed at step q-1
+      const int64_t qn = q + DW_NST - 1;
+      if (qn < nq) dma_stage(qn, bn);
+      dw_stage_compute<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, reinterpret_cast<const uint4*>(dsm) + buf * STAGE_U4, wo, wi,
+                                                    lane, d0, d1);
+      // stage q+1 must have landed; the newer ones may stay in flight
+      const int64_t newer = (nq - 1 - (q + 1));   // stages issued after q+1 (clamped below)
+      if (newer >= DW_NST - 2) wait_stages(DW_NST - 2);
+      else if (newer == 1) wait_stages(1);
+      else wait_stages(0);
+      __builtin_amdgcn_s_barrier();
+      buf = (buf == DW_NST - 1) ? 0 : buf + 1;
+    }
+  }
+  float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (wo * TO + i) * 32 + bcrow(r, lane);
+        const int c = (wi * TI + j) * 32 + (lane & 31);
+        pw[(int64_t)o * KI + c] = acc[i][j][r];
+      }
+  if (BIAS && wi == wo % WI) {
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+      const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      if (lane < 32) partial_b[(int64_t)blockIdx.x * NO + (wo * TO + i) * 32 + lane] = s;
+    }
+  }
+  if (RANK1 && wo == (wi + 1) % WO) {
+#pragma unroll
+    for (int j = 0; j < TI; ++j) {
+      const float s = rsum[j] + __shfl_xor(rsum[j], 32, 64);
+      if (lane < 32) partial_r[(int64_t)blockIdx.x * KI + (wi * TI + j) * 32 + lane] = s;
+    }
+  }
+}
+
 // rgb head + alpha bias gradients: out[wg][0..383] = dWr[c][k], [384..386] = dbr[c], [387] = dba
 __global__ void __launch_bounds__(128) head_grads_bf16_kernel(int64_t P, int64_t ntiles, const float* __restrict__ draw,
                                                                const uint4* __restrict__ hv,
@@ -948,8 +1142,20 @@ static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, cons
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
   float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
+#if DW_LDS
+  FN_CHECK_ARG(CTo == WO * TO && CTi == WI * TI, "dW job shape");
+  constexpr int lds = DW_NST * (WO * TO + WI * TI) * 128 * 16;
+  auto kern = mlp_bwd_dw_lds_bf16_kernel<WO, WI, TO, TI, BIAS, RANK1>;
+  static bool attr = false;
+  if (!attr) {
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, ntiles, dY, X, dalpha, pw, pb, pr);
+#else
   hipLaunchKernelGGL((mlp_bwd_dw_bf16_kernel<WO, WI, TO, TI, BIAS, RANK1>), dim3(nwg), dim3(WO * WI * 64), 0, st, P,
                      ntiles, dY, CTo, X, CTi, dalpha, pw, pb, pr);
+#endif
   FN_LAUNCH_CHECK();
   return 0;
 }
