@@ -87,7 +87,7 @@ def main():
     torch.manual_seed(0)   # identical initial weights on every rank
     args = fastnerf.run_nerf.make_args(N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, perturb=1.0, white_bkgd=True,
                                        no_reload=True, lrate=5e-4, lrate_decay=500)
-    ktr, _, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
+    ktr, kte, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
@@ -167,6 +167,27 @@ def main():
                 'hbm_write_GBps': (ops.act_floats(P) * 4 / (ms * 1e-3) / 1e9)}
         del act
 
+    # ---- inference rays/s (render_path-style, perturb=0, no saved activations), rank 0 only -------------
+    infer = None
+    if rank == 0:
+        n_inf = 32768
+        g2 = torch.Generator().manual_seed(7)
+        pix = torch.stack([torch.randint(0, 100, (n_inf,), generator=g2), torch.randint(0, H, (n_inf,), generator=g2),
+                           torch.randint(0, W, (n_inf,), generator=g2)], 1).int().to(dev)
+        ro_i, rd_i = ops.gen_rays_pixels(pix, poses, K)
+        with torch.no_grad():
+            for _ in range(2):
+                fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kte)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_rep = 5
+            for _ in range(n_rep):
+                fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kte)
+            torch.cuda.synchronize()
+            dt_i = (time.perf_counter() - t1) / n_rep
+        infer = {'value': n_inf / dt_i, 'unit': 'rays/s', 'rays_per_call': n_inf, 'ms_per_call': 1e3 * dt_i,
+                 'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), 1 GPU'}
+
     if rank == 0:
         rays_per_s = N_RAYS * world * a.steps / dt
         step_tflops = rays_per_s * TRAIN_FLOP_PER_RAY / 1e12 / world
@@ -183,6 +204,7 @@ def main():
             'step_tflops_per_gpu': step_tflops, 'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
             'step_frac_of_bf16_mfma_peak_x3': 3.0 * step_tflops / BF16_MFMA_PEAK_TFLOPS,
             'roofline': roof,
+            'inference': infer,
             'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(),
         }
         print(json.dumps(out))
