@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from .model import NeRF, param_slices
-from .run_nerf_helpers import get_rays, to8b
+from .run_nerf_helpers import compute_ssim, get_rays, to8b
 
 _SEED_GEN = torch.Generator()
 
@@ -249,11 +249,11 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
 
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
     """render.py:94-146 without the LPIPS dependency (external, optional in the reference env):
-    renders every pose, reports PSNR when ground truth is given, writes PNGs when imageio exists."""
+    renders every pose, reports PSNR and SSIM when ground truth is given, writes PNGs when imageio exists."""
     H, W, focal = hwf
     if render_factor != 0:
         H, W, focal = H // render_factor, W // render_factor, focal / render_factor
-    rgbs, disps, psnrs = [], [], []
+    rgbs, disps, psnrs, ssims = [], [], [], []
     with torch.no_grad():
         for i, c2w in enumerate(render_poses):
             rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=torch.as_tensor(c2w)[:3, :4], **render_kwargs)
@@ -262,6 +262,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
             if gt_imgs is not None and render_factor == 0:
                 gt = gt_imgs[i].cpu().numpy() if torch.is_tensor(gt_imgs[i]) else np.asarray(gt_imgs[i])
                 psnrs.append(-10. * np.log10(np.mean(np.square(rgbs[-1] - gt))))
+                ssims.append(float(compute_ssim(torch.as_tensor(gt).float(), rgb.cpu())))
             if savedir is not None:
                 try:
                     import imageio
@@ -270,6 +271,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
                     np.save(os.path.join(savedir, '{:03d}.npy'.format(i)), to8b(rgbs[-1]))
     if psnrs and savedir is not None:
         with open(os.path.join(savedir, 'results.txt'), 'w') as f:
-            f.write('mean PSNR: {}\n'.format(np.mean(psnrs)))
+            f.write('mean PSNR: {}\nmean SSIM: {}\n'.format(np.mean(psnrs), np.mean(ssims)))
     render_path.last_psnrs = psnrs
+    render_path.last_ssims = ssims
     return np.stack(rgbs, 0), np.stack(disps, 0)

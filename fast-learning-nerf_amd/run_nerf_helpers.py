@@ -1,7 +1,8 @@
 """Mirror of nerf-ours/run_nerf_helpers.py on the HIP ops (same names, arguments, returns).
 
 get_rays :68-78, get_rays_np :81-88, ndc_rays :91-108, get_embedder :48-63, sample_pdf :112-155,
-img2mse/mse2psnr/to8b :9-11.  Tensors must live on the GPU; there is no CPU fallback."""
+img2mse/mse2psnr/to8b :9-11, compute_ssim :158-234 (evaluation metric, plain torch on whatever device the images
+live on).  The ray / sampling functions need GPU tensors; there is no CPU fallback for them."""
 import numpy as np
 import torch
 
@@ -69,3 +70,34 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
     out = ops.sample_pdf(bins.reshape(-1, bins.shape[-1]), weights.reshape(-1, weights.shape[-1]), N_samples,
                          det=det, u=u, seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
     return out.reshape(lead + [N_samples])
+
+
+def compute_ssim(img0, img1, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03, return_map=False):
+    """Mean SSIM of image pairs `[..., width, height, channels]` (run_nerf_helpers.py:158-234: Gaussian-window
+    SSIM with zero padding, variances clipped at 0 and the covariance clipped to sqrt(var0 var1)); with
+    `return_map` the `[B, C, width, height]` map.  Evaluation-side helper of render_path, not a hot-path op."""
+    x0 = torch.as_tensor(img0)
+    x1 = torch.as_tensor(img1).to(x0.device)
+    wd, ht, ch = x0.shape[-3:]
+    # one plane per (batch, channel): [B*C, 1, wd, ht]
+    p0 = x0.reshape(-1, wd, ht, ch).permute(0, 3, 1, 2).reshape(-1, 1, wd, ht)
+    p1 = x1.reshape(-1, wd, ht, ch).permute(0, 3, 1, 2).reshape(-1, 1, wd, ht)
+    half = filter_size // 2
+    centre = (2 * half - filter_size + 1) / 2
+    taps = torch.exp(-0.5 * ((torch.arange(filter_size, device=x0.device) - half + centre) / filter_sigma) ** 2)
+    taps = taps / taps.sum()
+    conv = torch.nn.functional.conv2d
+
+    def blur(z):   # separable: along height first, then along width (zero padded)
+        z = conv(z, taps.view(1, 1, 1, -1), padding=(0, half))
+        return conv(z, taps.view(1, 1, -1, 1), padding=(half, 0))
+
+    m0, m1 = blur(p0), blur(p1)
+    v0 = (blur(p0 * p0) - m0 * m0).clamp(min=0.0)
+    v1 = (blur(p1 * p1) - m1 * m1).clamp(min=0.0)
+    cov = blur(p0 * p1) - m0 * m1
+    cov = torch.sign(cov) * torch.minimum(torch.sqrt(v0 * v1), cov.abs())
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    smap = ((2 * m0 * m1 + c1) * (2 * cov + c2)) / ((m0 * m0 + m1 * m1 + c1) * (v0 + v1 + c2))
+    smap = smap.reshape(-1, ch, wd, ht)
+    return smap if return_map else smap.reshape(smap.shape[0], -1).mean(-1)

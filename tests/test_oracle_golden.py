@@ -170,3 +170,17 @@ def test_g11_llff_ndc_noise(golden_dir):
         r = O.render_rays(rb, sdc, sdf, 64, 64, white_bkgd=True, t_rand=t_rand, u=u, noise0=n0, noise1=n1)
     for gk, rk in (('rgb', 'rgb_map'), ('acc', 'acc_map'), ('rgb0', 'rgb0'), ('acc0', 'acc0'), ('z_std', 'z_std')):
         assert np.allclose(r[rk].numpy(), g[gk], rtol=1e-5, atol=2e-6), gk
+
+
+def test_compute_ssim_g13(golden_dir):
+    """Evaluation metric of render_path vs values recorded from the reference."""
+    import fastnerf
+    g = np.load(os.path.join(golden_dir, 'g13_ssim.npz'))
+    H = fastnerf.run_nerf_helpers
+    a, b, c, d = (torch.from_numpy(g[k]) for k in 'abcd')
+    assert np.allclose(H.compute_ssim(a, b).numpy(), g['ssim_ab'], rtol=0, atol=2e-6)
+    assert np.allclose(H.compute_ssim(a, b, return_map=True).numpy(), g['map_ab'], rtol=0, atol=1e-5)
+    assert np.allclose(H.compute_ssim(a, a).numpy(), g['ssim_aa'], rtol=0, atol=2e-6)
+    assert np.allclose(H.compute_ssim(c, d).numpy(), g['ssim_cd'], rtol=0, atol=2e-6)
+    assert np.allclose(H.compute_ssim(c, d, max_val=2.0, filter_size=7, filter_sigma=1.0, k1=0.02, k2=0.05).numpy(),
+                       g['ssim_cd_k'], rtol=0, atol=2e-6)
