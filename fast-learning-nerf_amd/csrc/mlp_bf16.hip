@@ -240,10 +240,7 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
   const uint4* bptr[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128 + lane;
-  uint4 ah0[2], al0[2], bh0[NT], bl0[NT], ah1[2], al1[2], bh1[NT], bl1[NT];
-  auto ld = [&](uint4 (&ah)[2], uint4 (&al)[2], uint4 (&bh)[NT], uint4 (&bl)[NT], int ks) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { bh[nt] = bptr[nt][ks * 128]; bl[nt] = bptr[nt][ks * 128 + 64]; }
+  auto ldA = [&](uint4 (&ah)[2], uint4 (&al)[2], int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int o = aoff(mt, ks);
@@ -251,7 +248,11 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
       al[mt] = *reinterpret_cast<const uint4*>(Alo + o);
     }
   };
-  auto mm = [&](const uint4 (&ah)[2], const uint4 (&al)[2], const uint4 (&bh)[NT], const uint4 (&bl)[NT]) {
+  auto ldB = [&](uint4 (&bh)[NT], uint4 (&bl)[NT], int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { bh[nt] = bptr[nt][ks * 128]; bl[nt] = bptr[nt][ks * 128 + 64]; }
+  };
+  auto mm = [&](const uint4 (&ah)[2], const uint4 (&al)[2], const uint4 (&bh)[NT], const uint4 (&bl)[NT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -265,12 +266,33 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bmfma(al[mt], bh[nt], acc[mt][nt]);
   };
-  ld(ah0, al0, bh0, bl0, 0);
+  uint4 ah0[2], al0[2], ah1[2], al1[2], bh0[NT], bl0[NT], bh1[NT], bl1[NT];
+#if BF_PF == 2
+  // weights two k-steps ahead (four register sets), activations one ahead; nks % 4 == 0 except the 2-step segments
+  if (nks >= 4) {
+    uint4 bh2[NT], bl2[NT], bh3[NT], bl3[NT];
+    ldB(bh0, bl0, 0); ldB(bh1, bl1, 1); ldA(ah0, al0, 0);
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ks += 4) {
+      ldB(bh2, bl2, ks + 2); ldA(ah1, al1, ks + 1);
+      mm(ah0, al0, bh0, bl0);
+      ldB(bh3, bl3, ks + 3); ldA(ah0, al0, ks + 2);
+      mm(ah1, al1, bh1, bl1);
+      if (ks + 4 < nks) ldB(bh0, bl0, ks + 4);
+      ldA(ah1, al1, ks + 3);
+      mm(ah0, al0, bh2, bl2);
+      if (ks + 4 < nks) { ldB(bh1, bl1, ks + 5); ldA(ah0, al0, ks + 4); }
+      mm(ah1, al1, bh3, bl3);
+    }
+    return;
+  }
+#endif
+  ldB(bh0, bl0, 0); ldA(ah0, al0, 0);
 #pragma unroll 1
   for (int ks = 0; ks < nks; ks += 2) {
-    ld(ah1, al1, bh1, bl1, ks + 1);
+    ldB(bh1, bl1, ks + 1); ldA(ah1, al1, ks + 1);
     mm(ah0, al0, bh0, bl0);
-    if (ks + 2 < nks) ld(ah0, al0, bh0, bl0, ks + 2);
+    if (ks + 2 < nks) { ldB(bh0, bl0, ks + 2); ldA(ah0, al0, ks + 2); }
     mm(ah1, al1, bh1, bl1);
   }
 }
@@ -286,6 +308,33 @@ __device__ __forceinline__ void bzero(f32x16 (&acc)[2][NT]) {
 }
 // C layout of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int bcrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+#ifndef BF_PF
+#define BF_PF 2   // weight fragments two k-steps ahead in the fwd / dX k-loops (1: one ahead)
+#endif
+#ifndef BF_NT
+#define BF_NT 1   // non-temporal stores for the saved tensors (streamed once, read by dW much later)
+#endif
+__device__ __forceinline__ void gstore8(uint2* p, const uint2& v) {   // 8-byte piece of a saved K-fragment element
+#if BF_NT
+  __builtin_nontemporal_store(((u64)v.y << 32) | v.x, reinterpret_cast<u64*>(p));
+#else
+  *p = v;
+#endif
+}
+
+#ifndef BF_W16
+#define BF_W16 1
+#endif
+__device__ __forceinline__ void gstore16(uint4* p, const uint4& v) {
+#if BF_NT
+  typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+  const u32x4s t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x4s*>(p));
+#else
+  *p = v;
+#endif
+}
 
 struct EpiArgs {
   const float* bias;          // BIAS
@@ -361,6 +410,33 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
     }
     if (mt) mout2.y = mo; else mout2.x = mo;
     if (GSAVE) {
+#if BF_W16
+      // 16-byte stores: exchange halves so that lanes 0..31 hold the whole 8-point element of the even k-group
+      // and lanes 32..63 that of the odd one (v_permlane32_swap: X.hi <-> Y.lo); one wave store = 1 KiB contiguous
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int ct = wn * 2 + nt, ks = mt * 2 + k2;
+          const unsigned sel = nt ? 0x07060302u : 0x05040100u;
+          const int ge = 2 * k2, go = 2 * k2 + 1;
+          unsigned xe[2][2], xo[2][2];   // [part][word]
+          xe[0][0] = __builtin_amdgcn_perm(H[4 * ge + 1], H[4 * ge], sel); xe[0][1] = __builtin_amdgcn_perm(H[4 * ge + 3], H[4 * ge + 2], sel);
+          xe[1][0] = __builtin_amdgcn_perm(L[4 * ge + 1], L[4 * ge], sel); xe[1][1] = __builtin_amdgcn_perm(L[4 * ge + 3], L[4 * ge + 2], sel);
+          xo[0][0] = __builtin_amdgcn_perm(H[4 * go + 1], H[4 * go], sel); xo[0][1] = __builtin_amdgcn_perm(H[4 * go + 3], H[4 * go + 2], sel);
+          xo[1][0] = __builtin_amdgcn_perm(L[4 * go + 1], L[4 * go], sel); xo[1][1] = __builtin_amdgcn_perm(L[4 * go + 3], L[4 * go + 2], sel);
+#pragma unroll
+          for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              const auto r = __builtin_amdgcn_permlane32_swap(xe[part][w], xo[part][w], false, false);
+              xe[part][w] = r[0]; xo[part][w] = r[1];
+            }
+            uint4* p4 = reinterpret_cast<uint4*>(ea.gsave) + (((ct * 4 + ks) * 2 + part) * 64 + half * 32 + j);
+            gstore16(p4, make_uint4(xe[part][0], xe[part][1], xo[part][0], xo[part][1]));
+          }
+        }
+#else
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -371,9 +447,10 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
           uint2 h, l;
           h.x = __builtin_amdgcn_perm(H[4 * g + 1], H[4 * g], sel); h.y = __builtin_amdgcn_perm(H[4 * g + 3], H[4 * g + 2], sel);
           l.x = __builtin_amdgcn_perm(L[4 * g + 1], L[4 * g], sel); l.y = __builtin_amdgcn_perm(L[4 * g + 3], L[4 * g + 2], sel);
-          p[0] = h;
-          p[128] = l;
+          gstore8(p, h);
+          gstore8(p + 128, l);
         }
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -414,8 +491,8 @@ __device__ __forceinline__ void bepi128(const f32x16 (&acc)[2][1], const EpiArgs
       for (int g = 0; g < 4; ++g) {
         const int ks = mt * 2 + (g >> 1), kb = g & 1;
         uint2* p = ea.gsave + ((((wn * 4 + ks) * 2) * 64 + kb * 32 + j) * 2 + half);
-        p[0] = make_uint2(H[2 * g], H[2 * g + 1]);
-        p[128] = make_uint2(L[2 * g], L[2 * g + 1]);
+        gstore8(p, make_uint2(H[2 * g], H[2 * g + 1]));
+        gstore8(p + 128, make_uint2(L[2 * g], L[2 * g + 1]));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
