@@ -76,15 +76,15 @@ __device__ __forceinline__ void unpk8(const uint4& h, const uint4& l, float (&o)
 }
 
 // ---- saved-tensor layouts (16-byte units) -----------------------------------------------------------
-// activations: pe(2 ct) | h0..h7 (8 ct each) | feat (8) | vpe (1) | hv (4) | ReLU sign bits h0..h7 | sign bits hv
-__host__ __device__ inline int64_t ba_pe(int64_t nt) { return 0; }
-__host__ __device__ inline int64_t ba_h(int64_t nt, int l) { return nt * 1024 + (int64_t)l * nt * 4096; }
-__host__ __device__ inline int64_t ba_feat(int64_t nt) { return nt * (1024 + 8 * 4096); }
-__host__ __device__ inline int64_t ba_vpe(int64_t nt) { return ba_feat(nt) + nt * 4096; }
+// activations: h0..h7 (8 ct each) | feat (8) | vpe (1) | hv (4) | ReLU sign bits h0..h7 | sign bits hv | pe (2 or 3 ct)
+__host__ __device__ inline int64_t ba_h(int64_t nt, int l) { return (int64_t)l * nt * 4096; }
+__host__ __device__ inline int64_t ba_feat(int64_t nt) { return 8 * nt * 4096; }
+__host__ __device__ inline int64_t ba_vpe(int64_t nt) { return 9 * nt * 4096; }
 __host__ __device__ inline int64_t ba_hv(int64_t nt) { return ba_vpe(nt) + nt * 512; }
 __host__ __device__ inline int64_t ba_mask(int64_t nt) { return ba_hv(nt) + nt * 2048; }    // 1024 units / tile
 __host__ __device__ inline int64_t ba_maskv(int64_t nt) { return ba_mask(nt) + nt * 1024; }  // 64 units / tile
-__host__ __device__ inline int64_t ba_total(int64_t nt) { return ba_maskv(nt) + nt * 64; }
+__host__ __device__ inline int64_t ba_pe(int64_t nt) { return ba_maskv(nt) + nt * 64; }      // pe_pad/32 tiles of 512 units, last
+__host__ __device__ inline int64_t ba_total(int64_t nt, int pe_pad) { return ba_pe(nt) + nt * (pe_pad / 32) * 512; }
 // pre-activation gradients: dY0..dY7 (8 ct each) | dfeat (8) | dYv (4) | dalpha (fp32, 64 per tile)
 __host__ __device__ inline int64_t bd_y(int64_t nt, int l) { return (int64_t)l * nt * 4096; }
 __host__ __device__ inline int64_t bd_feat(int64_t nt) { return 8 * nt * 4096; }
@@ -170,12 +170,12 @@ static const NetLayout& b_layout(int kind) {
 }
 
 extern "C" int64_t fastnerf_mlp_bf16_floats(int kind, int what, int64_t n_points) {
-  if (kind < 0 || kind > 1) return -1;
+  if (kind < 0 || kind > 2) return -1;
   const int64_t nt = (n_points + BTM - 1) / BTM;
   switch (what) {
     case 1: return b_offsets(b_layout(kind)).total * 4;   // packed forward weights
     case 2: return b_offsets_bwd().total * 4;              // packed backward (transposed) weights
-    case 3: return ba_total(nt) * 4;                       // saved activations for n_points
+    case 3: return ba_total(nt, b_layout(kind).pe_pad) * 4;                       // saved activations for n_points
     case 4: return bd_total(nt) * 4;                       // pre-activation gradients for n_points
     default: return -1;
   }
@@ -183,7 +183,7 @@ extern "C" int64_t fastnerf_mlp_bf16_floats(int kind, int what, int64_t n_points
 
 extern "C" int fastnerf_mlp_bf16_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd,
                                       fn_stream_t stream) {
-  FN_CHECK_ARG((kind == 0 || kind == 1) && params && packed_fwd, "kind in {0,1}, non-null pointers");
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && params && packed_fwd, "kind in 0..2, non-null pointers");
   const NetLayout& L = b_layout(kind);
   const BOff O = b_offsets(L), OB = b_offsets_bwd();
   BPackTable T;
@@ -223,19 +223,26 @@ extern "C" int fastnerf_mlp_bf16_pack(int kind, const float* params, float* pack
 __device__ __forceinline__ int hoff(int m, int slot) { return m * 512 + ((slot ^ (m & 15)) << 4); }        // 32 slots/row
 __device__ __forceinline__ int eoff(int m, int slot) { return m * 128 + ((slot ^ ((m >> 1) & 7)) << 4); }  // 8 slots/row
 
+// nerf++ background: channels 64..95 of the 4-D encoding, two bf16 planes [64][32] that borrow the top 8 KiB of Hhi
+#define X2_HI_OFF 24576
+#define X2_LO_OFF 28672
+__device__ __forceinline__ int x2off(int m, int slot) { return m * 64 + ((slot ^ ((m >> 2) & 3)) << 4); }   // 4 slots/row
+
 __device__ __forceinline__ f32x16 bmfma(const uint4& a, const uint4& b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // accumulate nks (even) k-steps of 16.  A planes in LDS (H layout or E layout); B packed in global.
-template <int NT, bool A_IS_E>
+// AMODE: 0 = H planes, 1 = E planes, 2 = X2 block (pass Ahi = Hhi + X2_HI_OFF, Alo = Hhi + X2_LO_OFF)
+template <int NT, int AMODE>
 __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, const char* Alo, int a_ks0, int nks,
                                       const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane) {
   asm volatile("" : "+v"(lane));
   const int lrow = lane & 31, kb = lane >> 5;
   auto aoff = [&](int mt, int ks) {
     const int m = mt * 32 + lrow;
-    return A_IS_E ? eoff(m, (a_ks0 + ks) * 2 + kb) : hoff(m, (a_ks0 + ks) * 2 + kb);
+    const int slot = (a_ks0 + ks) * 2 + kb;
+    return AMODE == 1 ? eoff(m, slot) : (AMODE == 2 ? x2off(m, slot) : hoff(m, slot));
   };
   const uint4* bptr[NT];
 #pragma unroll
@@ -503,7 +510,43 @@ __device__ __forceinline__ void bepi128(const f32x16 (&acc)[2][1], const EpiArgs
 // =========================================================================================
 // forward
 // =========================================================================================
-template <bool SAVE>
+// inverted-sphere background point (x', y', z', 1/r) of nerf++ (ddp_model.py:16-45); same arithmetic as mlp.hip
+__device__ __forceinline__ void b_bg_point(const float* __restrict__ o, const float* __restrict__ d, float depth, float x[4]) {
+  const float dd = fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2]));
+  const float od = fadd(fadd(fmul(d[0], o[0]), fmul(d[1], o[1])), fmul(d[2], o[2]));
+  const float d1 = -od / dd;
+  float pm_[3], ps[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pm_[c] = fadd(o[c], fmul(d1, d[c]));
+  const float pmn = sqrtf(fadd(fadd(fmul(pm_[0], pm_[0]), fmul(pm_[1], pm_[1])), fmul(pm_[2], pm_[2])));
+  const float dcos = 1.0f / sqrtf(dd);
+  const float d2 = fmul(sqrtf(fsub(1.0f, fmul(pmn, pmn))), dcos);
+  const float d12 = fadd(d1, d2);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ps[c] = fadd(o[c], fmul(d12, d[c]));
+  float ax[3] = {fsub(fmul(o[1], ps[2]), fmul(o[2], ps[1])), fsub(fmul(o[2], ps[0]), fmul(o[0], ps[2])),
+                 fsub(fmul(o[0], ps[1]), fmul(o[1], ps[0]))};
+  const float an = sqrtf(fadd(fadd(fmul(ax[0], ax[0]), fmul(ax[1], ax[1])), fmul(ax[2], ax[2])));
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ax[c] = ax[c] / an;
+  const float ang = fsub(asinf(pmn), asinf(fmul(pmn, depth)));
+  const float ca = cosf(ang), sa = sinf(ang);
+  const float cr[3] = {fsub(fmul(ax[1], ps[2]), fmul(ax[2], ps[1])), fsub(fmul(ax[2], ps[0]), fmul(ax[0], ps[2])),
+                       fsub(fmul(ax[0], ps[1]), fmul(ax[1], ps[0]))};
+  const float dot = fadd(fadd(fmul(ax[0], ps[0]), fmul(ax[1], ps[1])), fmul(ax[2], ps[2]));
+  const float omc = fsub(1.0f, ca);
+  float pn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pn[c] = fadd(fadd(fmul(ps[c], ca), fmul(cr[c], sa)), fmul(fmul(ax[c], dot), omc));
+  const float nn = sqrtf(fadd(fadd(fmul(pn[0], pn[0]), fmul(pn[1], pn[1])), fmul(pn[2], pn[2])));
+  x[0] = pn[0] / nn; x[1] = pn[1] / nn; x[2] = pn[2] / nn; x[3] = depth;
+}
+
+// BG == false: points o + d*z, 63-channel encoding in the E planes.
+// BG == true : nerf++ background net: inverted-sphere points (4-D), samples consumed far -> near
+//              (ddp_model.py:118-124), 84 channels = 64 in E + 20 (padded to 32) in the X2 block that borrows the
+//              top 8 KiB of Hhi while H is free (layer 0) or after layer 5 has consumed h4 (re-encoded from registers).
+template <bool SAVE, bool BG>
 __global__ void __launch_bounds__(BNTHR, 2)
 mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                     const float* __restrict__ params, const uint4* __restrict__ pk, float* __restrict__ raw,
@@ -528,20 +571,36 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     if (pp >= P) pp = P - 1;
     const int64_t ray = pp / S;
     const float* rr = rays + ray * 11;
-    // store one PE channel at row pm: E planes, and (SAVE) the K-fragment staging copy that aliases H
-    auto est = [&](int c, float v) {
+    // store one PE channel at row pm: E planes (c < 64) or the X2 block (c >= 64), and (SAVE, stage) the K-fragment
+    // staging copy that aliases the head of H
+    auto est = [&](int c, float v, bool stage = true) {
       unsigned h, l;
       split1(v, h, l);
-      const int o = eoff(pm, c >> 3) + (c & 7) * 2;
-      *reinterpret_cast<unsigned short*>(Ehi + o) = (unsigned short)h;
-      *reinterpret_cast<unsigned short*>(Elo + o) = (unsigned short)l;
-      if (SAVE) {
+      if (c < 64) {
+        const int o = eoff(pm, c >> 3) + (c & 7) * 2;
+        *reinterpret_cast<unsigned short*>(Ehi + o) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(Elo + o) = (unsigned short)l;
+      } else {
+        const int o = x2off(pm, (c - 64) >> 3) + (c & 7) * 2;
+        *reinterpret_cast<unsigned short*>(Hhi + X2_HI_OFF + o) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(Hhi + X2_LO_OFF + o) = (unsigned short)l;
+      }
+      if (SAVE && stage) {
         const int t = (((((c >> 5) * 4 + (pm >> 4)) * 2) * 64) + ((pm >> 3) & 1) * 32 + (c & 31)) * 16 + (pm & 7) * 2;
         *reinterpret_cast<unsigned short*>(bsm + t) = (unsigned short)h;
         *reinterpret_cast<unsigned short*>(bsm + t + 1024) = (unsigned short)l;
       }
     };
-    {
+    float xq = 0.f;   // BG: coordinate pq of this row's 4-D point, kept for the layer-5 re-encode
+    auto write_x2 = [&](bool stage) {   // channels 64..95 of the 4-D encoding (dimension pq of row pm)
+      est(64 + pq, cosf(fmul(xq, 128.0f)), stage);
+      est(68 + pq, sinf(fmul(xq, 256.0f)), stage);
+      est(72 + pq, cosf(fmul(xq, 256.0f)), stage);
+      est(76 + pq, sinf(fmul(xq, 512.0f)), stage);
+      est(80 + pq, cosf(fmul(xq, 512.0f)), stage);
+      est(84 + pq, 0.f, stage); est(88 + pq, 0.f, stage); est(92 + pq, 0.f, stage);
+    };
+    if (!BG) {
       const float zz = zv[pp];
       float x[3];
 #pragma unroll
@@ -553,19 +612,40 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         est(3 + 6 * k + dim, sinf(a));
         est(6 + 6 * k + dim, cosf(a));
       }
+    } else {
+      const int sidx = (int)(pp - ray * S);
+      const float zz = zv[ray * S + (S - 1 - sidx)];   // flipped sample order
+      float x4[4];
+      b_bg_point(rr, rr + 3, zz, x4);
+      xq = x4[pq];
+      est(pq, xq);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float a = fmul(xq, (float)(1 << k));
+        est(4 + 8 * k + pq, sinf(a));
+        est(8 + 8 * k + pq, cosf(a));
+      }
+      est(60 + pq, sinf(fmul(xq, 128.0f)));
+      write_x2(true);
     }
     __syncthreads();
-    if (SAVE) {   // PE tile in K-fragment order: 16 KiB staged at the head of H
-      uint4* dst = act + ba_pe(ntiles) + tile * 1024;
+    if (SAVE) {   // PE tile in K-fragment order: 16 (24) KiB staged at the head of H
+      constexpr int PE_U4 = BG ? 1536 : 1024;
+      uint4* dst = act + ba_pe(ntiles) + tile * PE_U4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i * 256 + tid] = *reinterpret_cast<const uint4*>(bsm + (i * 256 + tid) * 16);
+      for (int i = 0; i < PE_U4 / 256; ++i) dst[i * 256 + tid] = *reinterpret_cast<const uint4*>(bsm + (i * 256 + tid) * 16);
     }
     f32x16 acc[2][2];
     EpiArgs ea{};
     // L0
     bzero<2>(acc);
-    bgemm<2, true>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 4, 0, wn * 2, lane);
-    if (SAVE) __syncthreads();   // staging copy read out before H is written
+    if (!BG) {
+      bgemm<2, 1>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 4, 0, wn * 2, lane);
+    } else {
+      bgemm<2, 1>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 6, 0, wn * 2, lane);
+      bgemm<2, 2>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, pk + boff.off[0], 6, 4, wn * 2, lane);
+    }
+    if (SAVE || BG) __syncthreads();   // staging copy / X2 block read out before H is written
     ea.bias = params + lay.LB[0];
     if (SAVE) {
       ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, 0) + tile * 4096);
@@ -578,10 +658,19 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       bzero<2>(acc);
       const uint4* B = pk + boff.off[l];
       if (l == 5) {
-        bgemm<2, true>(acc, Ehi, Elo, 0, 4, B, 20, 0, wn * 2, lane);
-        bgemm<2, false>(acc, Hhi, Hlo, 0, 16, B, 20, 4, wn * 2, lane);
+        if (!BG) {
+          bgemm<2, 1>(acc, Ehi, Elo, 0, 4, B, 20, 0, wn * 2, lane);
+          bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 20, 4, wn * 2, lane);
+        } else {
+          bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 22, 6, wn * 2, lane);
+          __syncthreads();   // h4 consumed: the top of Hhi becomes the X2 block again
+          write_x2(false);
+          __syncthreads();
+          bgemm<2, 1>(acc, Ehi, Elo, 0, 4, B, 22, 0, wn * 2, lane);
+          bgemm<2, 2>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, B, 22, 4, wn * 2, lane);
+        }
       } else {
-        bgemm<2, false>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane);
+        bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane);
       }
       __syncthreads();
       ea.bias = params + lay.LB[l];
@@ -637,7 +726,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     }
     // feature layer (no ReLU)
     bzero<2>(acc);
-    bgemm<2, false>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane);
+    bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane);
     __syncthreads();
     ea.bias = params + lay.FB;
     if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(ntiles) + tile * 4096);
@@ -647,8 +736,8 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     {
       f32x16 av[2][1];
       bzero<1>(av);
-      bgemm<1, false>(av, Hhi, Hlo, 0, 16, pk + boff.off[9], 18, 0, wn, lane);
-      bgemm<1, true>(av, Ehi, Elo, 0, 2, pk + boff.off[9], 18, 16, wn, lane);
+      bgemm<1, 0>(av, Hhi, Hlo, 0, 16, pk + boff.off[9], 18, 0, wn, lane);
+      bgemm<1, 1>(av, Ehi, Elo, 0, 2, pk + boff.off[9], 18, 16, wn, lane);
       __syncthreads();
       ea.bias = params + lay.VB;
       if (SAVE) {
@@ -691,7 +780,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
 extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const float* z,
                                      const float* params, const float* packed_fwd, float* raw, float* act,
                                      fn_stream_t stream) {
-  FN_CHECK_ARG((kind == 0 || kind == 1) && n >= 0 && S >= 1, "kind in {0,1}, n>=0, S>=1");
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
   FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
   if (n == 0) return 0;
   const NetLayout& lay = b_layout(kind);
@@ -702,19 +791,27 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<false>),
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<false, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<true>),
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<true, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16_kernel<true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
     attr_done = true;
   }
   const uint4* pk = reinterpret_cast<const uint4*>(packed_fwd);
-  if (act)
-    hipLaunchKernelGGL(mlp_fwd_bf16_kernel<true>, dim3(grid), dim3(BNTHR), BLDS_BYTES, fn::S(stream), P, S, rays11, z,
-                       params, pk, raw, reinterpret_cast<uint4*>(act), lay, O);
-  else
-    hipLaunchKernelGGL(mlp_fwd_bf16_kernel<false>, dim3(grid), dim3(BNTHR), BLDS_BYTES, fn::S(stream), P, S, rays11, z,
-                       params, pk, raw, static_cast<uint4*>(nullptr), lay, O);
+  uint4* a4 = reinterpret_cast<uint4*>(act);
+  const dim3 g(grid), b(BNTHR);
+  hipStream_t st = fn::S(stream);
+  if (kind == 2) {
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
+  } else {
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
+  }
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -769,14 +866,14 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     f32x16 acc[2][2];
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ----------------------------------------------------------
     bzero<2>(acc);
-    bgemm<2, false>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane);
+    bgemm<2, 0>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane);
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(ntiles) + tile * 4096);
     bepi256<false, false, false, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ---------------------------------------------------
     bzero<2>(acc);
-    bgemm<2, false>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane);
+    bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane);
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, 7) + tile * 4096);
     ea.mask_in = maskw_all + (tile * 8 + 7) * 256;
@@ -788,7 +885,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
       bzero<2>(acc);
-      bgemm<2, false>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane);
+      bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane);
       __syncthreads();
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, l - 1) + tile * 4096);
       ea.mask_in = maskw_all + (tile * 8 + (l - 1)) * 256;
@@ -1188,10 +1285,10 @@ __global__ void __launch_bounds__(256) breduce_kernel(BRedTable tab, const float
 }
 
 struct BJob { int NO, KI, bias, rank1; };
-static BJob b_job(int j) {
+static BJob b_job(int j, int pe_pad) {
   switch (j) {
-    case 0: return {256, 64, 1, 0};     // L0 (pe)
-    case 8: return {256, 64, 0, 0};     // L5 (pe part)
+    case 0: return {256, pe_pad, 1, 0};     // L0 (pe)
+    case 8: return {256, pe_pad, 0, 0};     // L5 (pe part)
     case 9: return {256, 256, 1, 1};    // feature / remap (+ alpha / sigma row)
     case 10: return {128, 256, 1, 0};   // view layer (feature part)
     case 11: return {128, 32, 0, 0};    // view layer (vpe part)
@@ -1199,17 +1296,17 @@ static BJob b_job(int j) {
   }
 }
 #define BHEAD_MAX_WG 1024
-static int64_t b_job_floats(int j) {
-  const BJob d = b_job(j);
+static int64_t b_job_floats(int j, int pe_pad) {
+  const BJob d = b_job(j, pe_pad);
   return (int64_t)d.NO * d.KI + (d.bias ? d.NO : 0) + (d.rank1 ? d.KI : 0);
 }
-static int64_t b_job_base(int j, int ncu) {
+static int64_t b_job_base(int j, int ncu, int pe_pad) {
   int64_t o = 0;
-  for (int i = 0; i < j; ++i) o += b_job_floats(i) * ncu;
+  for (int i = 0; i < j; ++i) o += b_job_floats(i, pe_pad) * ncu;
   return o;
 }
 extern "C" int64_t fastnerf_mlp_bf16_partial_floats(void) {
-  return b_job_base(12, b_num_cus()) + (int64_t)BHEAD_MAX_WG * 388;
+  return b_job_base(12, b_num_cus(), 96) + (int64_t)BHEAD_MAX_WG * 388;   // sized for the widest layout
 }
 
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
@@ -1247,7 +1344,7 @@ static void b_add_seg(BRedTable& T, int64_t src, int64_t wg_stride, int nwg, int
 extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const float* act_f,
                                      const float* params, const float* packed_bwd, float* dact_f, float* partial,
                                      float* grads, fn_stream_t stream) {
-  FN_CHECK_ARG((kind == 0 || kind == 1) && n > 0 && S >= 1, "kind in {0,1}, n>0, S>=1");
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(draw && act_f && params && packed_bwd && dact_f && partial && grads, "null pointer");
   const NetLayout& L = b_layout(kind);
   const BOff OB = b_offsets_bwd();
@@ -1274,11 +1371,12 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   BRedTable T;
   T.n = 0;
   int rc;
-  auto region = [&](int j) { return partial + b_job_base(j, ncu); };
+  const int PEP = L.pe_pad;
+  auto region = [&](int j) { return partial + b_job_base(j, ncu, PEP); };
   // permW: bit0 rows permuted, bit1 cols permuted
   auto segs = [&](int j, int64_t dstW, int ld, int validc, int permW, int64_t dstB, int64_t dstR) {
-    const BJob d = b_job(j);
-    const int64_t b = b_job_base(j, ncu);
+    const BJob d = b_job(j, PEP);
+    const int64_t b = b_job_base(j, ncu, PEP);
     b_add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc, permW);
     int64_t o = b + (int64_t)nwg * d.NO * d.KI;
     if (d.bias) { b_add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO, (permW & 1) ? 2 : 0); o += (int64_t)nwg * d.NO; }
@@ -1286,7 +1384,9 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   };
   const uint4* a_pe = act + ba_pe(nt);
   // L0
-  if ((rc = b_launch_dw<4, 1, 2, 2, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 2, nullptr, region(0), nwg, st))) return rc;
+  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 2, nullptr, region(0), nwg, st);
+  else rc = b_launch_dw<4, 1, 2, 3, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 3, nullptr, region(0), nwg, st);
+  if (rc) return rc;
   segs(0, L.LW[0], L.in_pe, L.in_pe, 1, L.LB[0], 0);
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
@@ -1294,7 +1394,9 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, 3, L.LB[l], 0);
   }
   // L5 pe part
-  if ((rc = b_launch_dw<4, 1, 2, 2, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st))) return rc;
+  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st);
+  else rc = b_launch_dw<4, 1, 2, 3, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 3, nullptr, region(8), nwg, st);
+  if (rc) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 1, 0, 0);
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
   if ((rc = b_launch_dw<DW_CFG, true, true>(P, nt, dact + bd_feat(nt), 8, act + ba_h(nt, 7), 8,
@@ -1309,7 +1411,7 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   {
     int hg = (int)(nt > BHEAD_MAX_WG ? BHEAD_MAX_WG : nt);
     if (hg < 1) hg = 1;
-    const int64_t hb = b_job_base(12, ncu);
+    const int64_t hb = b_job_base(12, ncu, PEP);
     hipLaunchKernelGGL(head_grads_bf16_kernel, dim3(hg), dim3(128), 0, st, P, nt, draw, act + ba_hv(nt), partial + hb);
     FN_LAUNCH_CHECK();
     b_add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387, 0);   // dWr (384) + dbr (3), contiguous in every layout

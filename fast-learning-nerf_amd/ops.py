@@ -19,7 +19,7 @@ DACT_FLOATS = 2432
 # ---- matrix-core math mode of the 8x256 MLP kernels ---------------------------------------------
 # 'fp32'   : v_mfma_f32_32x32x2_f32 (csrc/mlp.hip), every kind
 # 'bf16x3' : 3-term split-bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/mlp_bf16.hip),
-#            fp32-class accuracy at ~2.5x the rate; kinds 0/1 (the nerf++ background net stays on fp32)
+#            fp32-class accuracy at ~2.5x the rate; all three net kinds
 import os
 _MATH = os.environ.get('FASTNERF_MATH', 'bf16x3')
 assert _MATH in ('fp32', 'bf16x3'), 'FASTNERF_MATH must be fp32 or bf16x3'
@@ -38,7 +38,7 @@ def set_math(mode):
 
 
 def _split(kind):
-    return _MATH == 'bf16x3' and int(kind) in (0, 1)
+    return _MATH == 'bf16x3' and int(kind) in (0, 1, 2)
 
 
 def act_floats(P, kind=0):

@@ -132,7 +132,7 @@ int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const f
 int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                         const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
 
-/* ---- split-bf16 ("bf16x3") math mode for kinds 0/1 ---------------------------------------------------
+/* ---- split-bf16 ("bf16x3") math mode, all three net kinds ------------------------------------------
  * Same network functions and call protocol as fastnerf_mlp_pack_ex / fwd_ex / bwd_ex (run_nerf.py:91-107
  * run_network -> model.py:37-63, autograd backward of the same), computed on the bf16 matrix cores: every fp32
  * operand is carried as a (hi, lo) bf16 pair and products are hi*hi + hi*lo + lo*hi with fp32 accumulation

@@ -129,8 +129,10 @@ def test_mlp_forward_points(fn, weights, P, math_mode):
     else:   # K-fragment tensors: pe (natural channel order), h0 (wave-permuted order)
         nt = (P + 63) // 64
         u16 = act.cpu().numpy().view(np.uint16)
-        pe = torch.from_numpy(decode_kfrag(u16, 0, 2, nt, False)[:P])
-        h0 = torch.from_numpy(decode_kfrag(u16, nt * 1024, 8, nt, True)[:P])
+        # buffer order: h0..h7 | feat | vpe | hv | sign bits | pe (csrc/mlp_bf16.hip ba_*)
+        pe_off = nt * (9 * 4096 + 512 + 2048 + 1024 + 64)
+        pe = torch.from_numpy(decode_kfrag(u16, pe_off, 2, nt, False)[:P])
+        h0 = torch.from_numpy(decode_kfrag(u16, 0, 8, nt, True)[:P])
         h0_ref = torch.relu(O.posenc(pts, 10) @ weights['pts_linears.0.weight'].T + weights['pts_linears.0.bias'])
         assert (h0 - h0_ref).abs().max() < 2e-5
     assert (pe[:, 63] == 0).all()

@@ -74,7 +74,7 @@ def test_pp_ops(fn, golden_dir):
         assert (err < 2e-5).float().mean() > 0.98 and err.max() <= width + 1e-5, float(err.max())
 
 
-def test_bg_mlp_vs_oracle(fn, golden_dir):
+def test_bg_mlp_vs_oracle(fn, golden_dir, math_mode):
     """kind-2 net: inverted-sphere points + 84-channel encoding + flipped sample order."""
     fg, bg = load_levels(golden_dir)[0]
     gen = torch.Generator().manual_seed(5)
