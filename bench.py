@@ -146,7 +146,7 @@ def main():
         flops = P * FWD_FLOP_PER_POINT
         achieved = flops / (ms * 1e-3) / 1e12
         split = ops.get_math() == 'bf16x3'
-        kname = 'void mlp_fwd_bf16_kernel<true>' if split else 'void mlp_fwd_kernel<true>'
+        kname = 'void mlp_fwd_bf16_kernel<true, false>' if split else 'void mlp_fwd_kernel<true, false>'
         traffic = None   # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
