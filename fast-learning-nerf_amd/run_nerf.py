@@ -199,6 +199,49 @@ class Trainer:
     def state_dict(self):
         return {'m': self.m, 'v': self.v, 'adam_t': self.adam_t, 'global_iter': self.global_iter, 'lr': self.lr}
 
+    # ---- interchange with torch.optim.Adam (the optimizer_state_dict of the reference's .tar, run_nerf.py:121,537) ----
+    def _param_list(self):
+        ps = list(self.net_c.parameters())
+        if self.net_f is not None and self.net_f is not self.net_c:
+            ps += list(self.net_f.parameters())
+        return ps
+
+    def torch_optimizer_state_dict(self):
+        """State in torch.optim.Adam's format over grad_vars (coarse then fine parameters, parameters() order = the
+        flat buffer's order): loadable by the reference's `optimizer.load_state_dict`."""
+        state, off = {}, 0
+        for i, p in enumerate(self._param_list()):
+            k = p.numel()
+            state[i] = {'step': torch.tensor(float(self.adam_t)),
+                        'exp_avg': self.m[off:off + k].view(p.shape).clone(),
+                        'exp_avg_sq': self.v[off:off + k].view(p.shape).clone()}
+            off += k
+        assert off == self.flat.numel()
+        group = {'lr': self.lr, 'betas': (self.beta1, self.beta2), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(len(state)))}
+        return {'state': state if self.adam_t > 0 else {}, 'param_groups': [group]}
+
+    def load_torch_optimizer(self, opt):
+        """Take over the moments / step count / lr of a torch.optim.Adam (or its state_dict) over the same
+        parameters, e.g. the optimizer create_nerf restored from a reference checkpoint."""
+        sd = opt.state_dict() if hasattr(opt, 'state_dict') else opt
+        st = sd['state']
+        self.lr = float(sd['param_groups'][0]['lr'])
+        if len(st) == 0:
+            self.m.zero_(); self.v.zero_(); self.adam_t = 0
+            return
+        off, steps = 0, set()
+        for i, p in enumerate(self._param_list()):
+            k = p.numel()
+            e = st[i]
+            self.m[off:off + k].copy_(torch.as_tensor(e['exp_avg']).reshape(-1))
+            self.v[off:off + k].copy_(torch.as_tensor(e['exp_avg_sq']).reshape(-1))
+            steps.add(int(float(e['step'])))
+            off += k
+        assert off == self.flat.numel() and len(steps) == 1, 'optimizer state does not match the parameter list'
+        self.adam_t = steps.pop()
+
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v'])
         self.adam_t, self.global_iter, self.lr = sd['adam_t'], sd['global_iter'], sd['lr']
@@ -215,6 +258,8 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
     kw_train, kw_test, start_epoch, global_iter, grad_vars, optimizer = create_nerf(args, device=dev)
     trainer = Trainer(kw_train, H, W, K, near, far, lrate=args.lrate, lrate_decay=args.lrate_decay)
     trainer.global_iter = global_iter
+    if len(optimizer.state_dict()['state']) > 0:   # create_nerf restored a checkpoint (ours or the reference's)
+        trainer.load_torch_optimizer(optimizer)
     images = torch.as_tensor(images, dtype=torch.float32)
     poses = torch.as_tensor(poses, dtype=torch.float32)[:, :3, :4]
     mgr = QuadTreeManager(H, W, K, images, poses, mseThres=0.0, max_depth=args.init_level, device=dev)
@@ -274,6 +319,6 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
             torch.save({'global_epoch': epoch_id, 'global_iter': trainer.global_iter,
                         'network_fn_state_dict': kw_train['network_fn'].state_dict(),
                         'network_fine_state_dict': kw_train['network_fine'].state_dict(),
-                        'fused_optimizer_state': trainer.state_dict(),
+                        'optimizer_state_dict': trainer.torch_optimizer_state_dict(),
                         'tree_leaves': mgr.export_leaves()}, os.path.join(d, '{:03d}.tar'.format(epoch_id)))
     return kw_train, kw_test, trainer, mgr, history

@@ -73,3 +73,48 @@ def test_train_driver_with_quadtree(fn):
     rgbs, disps = fn.render.render_path(poses[:1], (32, 32, focal), K, 4096, dict(kte, near=2.0, far=6.0), gt_imgs=imgs[:1])
     assert rgbs.shape == (1, 32, 32, 3) and np.isfinite(rgbs).all()
     assert fn.render.render_path.last_psnrs[0] > 8.0
+
+
+def test_optimizer_state_interchange(fn, tmp_path):
+    """the fused trainer's Adam state round-trips through torch.optim.Adam's state_dict (the
+    `optimizer_state_dict` entry of the reference's .tar), and a checkpoint written by train() resumes."""
+    torch.manual_seed(0)
+    args = fn.run_nerf.make_args(N_importance=8, N_samples=8, perturb=1.0, white_bkgd=True, no_reload=True)
+    ktr, _, _, _, grad_vars, opt = fn.run_nerf.create_nerf(args, device='cuda')
+    K = np.array([[40.0, 0, 8.0], [0, 40.0, 8.0], [0, 0, 1]])
+    tr = fn.run_nerf.Trainer(ktr, 16, 16, K, 2.0, 6.0)
+    ro = torch.randn(64, 3).cuda() * 0.1 + torch.tensor([0., 0., 4.]).cuda()
+    rd = torch.randn(64, 3).cuda()
+    tgt = torch.rand(64, 3).cuda()
+    for _ in range(2):
+        tr.step(ro, rd, tgt)
+    sd = tr.torch_optimizer_state_dict()
+    opt.load_state_dict(sd)                      # torch accepts it as an Adam state over grad_vars
+    st = opt.state_dict()['state']
+    assert len(st) == len(grad_vars) == 48 and int(float(st[0]['step'])) == 2
+    off = 0
+    for i, p in enumerate(grad_vars):
+        k = p.numel()
+        assert torch.equal(st[i]['exp_avg'].reshape(-1), tr.m[off:off + k])
+        assert torch.equal(st[i]['exp_avg_sq'].reshape(-1), tr.v[off:off + k])
+        off += k
+    # a third step with torch's Adam on the fused gradients == the fused Adam step
+    w_before = tr.flat.clone()
+    tr.forward_backward(ro, rd, tgt)
+    g = tr.grad.clone()
+    tr2 = fn.run_nerf.Trainer(ktr, 16, 16, K, 2.0, 6.0)
+    tr2.load_torch_optimizer(opt)
+    assert tr2.adam_t == 2 and torch.equal(tr2.m, tr.m) and torch.equal(tr2.v, tr.v)
+    off = 0
+    for p in grad_vars:
+        k = p.numel()
+        p.grad = g[off:off + k].view(p.shape).clone()
+        off += k
+    opt.step()
+    w_torch = tr.flat.clone()
+    with torch.no_grad():
+        tr.flat.copy_(w_before)
+    tr.grad.copy_(g)
+    tr.adam_t += 1
+    fn.ops.adam_step(tr.flat, tr.grad, tr.m, tr.v, tr.lr, tr.adam_t, tr.beta1, tr.beta2, tr.eps)
+    assert (tr.flat - w_torch).abs().max() < 2e-7
