@@ -7,7 +7,11 @@
 //   KiB with one wave per SIMD), epilogue ~0.35 ms, slab barrier ~0.1 ms.
 // Kept as the starting point for round 2: the register-resident chain removes the activation
 // LDS traffic and halves the weight bytes per point, but with one wave per SIMD every non-MFMA instruction must
-// fit the ~28-cycle window behind an MFMA, and the LDS-DMA does not.
+// fit the ~28-cycle window behind an MFMA, and the LDS-DMA does not.  Replacing the DMA by a register-staged copy
+// (4 staging uint4 per thread, loads / ds_writes spread over the k-steps) was tried: hipcc then spills inside the
+// slab loop (560 B/lane scratch, 7.1 ms) because it does not keep the 128 input-fragment registers in AccVGPRs;
+// this kernel needs an explicit VGPR/AGPR partition (inline-asm MFMAs with "a" operands or hand-written asm).
+// tools/t_fwd.py builds and times it stand-alone.
 //
 // Orientation: every layer is computed as out^T[n][m] = sum_k W[n][k] * act^T[k][m]  (n = output channel,
 // m = point).  The MFMA A operand is a weight fragment, the B operand an activation fragment (lane = point
