@@ -144,6 +144,8 @@ def mlp_pack(params, packed_fwd=None, packed_bwd=None, kind=0):
         packed_bwd = torch.empty(packed_floats(kind, 2), device=params.device, dtype=torch.float32)
     assert packed_fwd.numel() == packed_floats(kind, 1) and packed_bwd.numel() == packed_floats(kind, 2), \
         'packed buffers were sized under a different math mode'
+    # the two modes' buffers can have the same size: tag them so that a mix-up is an error, not garbage
+    packed_fwd._fn_math = packed_bwd._fn_math = 'bf16x3' if _split(kind) else 'fp32'
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_pack(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),
               'fastnerf_mlp_bf16_pack')
@@ -162,7 +164,8 @@ def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None, kind=0):
         raw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
     if act is not None:
         assert act.numel() >= act_floats(n * S, kind)
-    assert packed_fwd.numel() == packed_floats(kind, 1), 'packed weights were produced under a different math mode'
+    assert packed_fwd.numel() == packed_floats(kind, 1) and getattr(packed_fwd, '_fn_math', None) == ('bf16x3' if _split(kind) else 'fp32'), \
+        'packed weights were not produced by mlp_pack under the current math mode'
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_fwd(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw),
                                           ptr(act), stream()), 'fastnerf_mlp_bf16_fwd')
@@ -180,7 +183,8 @@ def mlp_bwd(draw, act, params, packed_bwd, dact, partial, grads, kind=0):
     require_gpu(draw, act, params, packed_bwd, dact, partial, grads)
     n, S = draw.shape[0], draw.shape[1]
     assert dact.numel() >= dact_floats(n * S, kind) and grads.numel() == net_floats(kind, 0)
-    assert packed_bwd.numel() == packed_floats(kind, 2), 'packed weights were produced under a different math mode'
+    assert packed_bwd.numel() == packed_floats(kind, 2) and getattr(packed_bwd, '_fn_math', None) == ('bf16x3' if _split(kind) else 'fp32'), \
+        'packed weights were not produced by mlp_pack under the current math mode'
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_bwd(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
                                           ptr(partial), ptr(grads), stream()), 'fastnerf_mlp_bf16_bwd')

@@ -194,3 +194,26 @@ def test_run_network_signature(fn, weights):
         out2 = net(emb.cuda()).cpu().reshape(5, 7, 4)
     assert (out2 - ref).abs().max() < 1e-4
     assert list(net.state_dict().keys()) == [n for n, _ in O.nerf_param_shapes()]
+
+
+def test_mlp_edge_cases(fn, weights, math_mode):
+    """Empty batches, error reporting through the C ABI (no abort), mode-specific opaque buffers."""
+    flat = flat_of(weights).cuda()
+    pf, pb = fn.ops.mlp_pack(flat)
+    rays = torch.zeros(0, 11).cuda()
+    raw = fn.ops.mlp_fwd(rays, torch.zeros(0, 5).cuda(), flat, pf)
+    assert raw.shape == (0, 5, 4)
+    # a bad net kind is an error code + message, not a crash
+    lib = fn._lib.lib()
+    rc = (lib.fastnerf_mlp_bf16_fwd if math_mode == 'bf16x3' else lib.fastnerf_mlp_fwd_ex)(
+        7, 1, 1, fn._lib.ptr(torch.zeros(1, 11).cuda()), fn._lib.ptr(torch.zeros(1, 1).cuda()), fn._lib.ptr(flat), fn._lib.ptr(pf),
+        fn._lib.ptr(torch.zeros(1, 1, 4).cuda()), None, None)
+    assert rc != 0 and b'kind' in lib.fastnerf_last_error()
+    # packed weights of the other math mode are rejected by the wrappers
+    other = 'fp32' if math_mode == 'bf16x3' else 'bf16x3'
+    fn.ops.set_math(other)
+    try:
+        with pytest.raises(AssertionError):
+            fn.ops.mlp_fwd(torch.zeros(1, 11).cuda(), torch.zeros(1, 1).cuda(), flat, pf)
+    finally:
+        fn.ops.set_math(math_mode)
