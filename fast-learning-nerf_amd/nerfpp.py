@@ -278,9 +278,14 @@ class QuadTreeManager:
     def __getattr__(self, name):
         return getattr(self.__dict__['_b'], name)
 
-    def gen_rays_v3_multiThread(self, down_scale=16, prob=True, rand=0.7, debug=False, last_epoch=False):
+    def gen_rays_v3_multiThread(self, down_scale=16, prob=True, rand=0.7, debug=False, last_epoch=False, compat_rng=True):
+        """compat_rng=True: the reference's numpy / torch call order (seeded picks identical, host loop over leaves);
+        False: the same distribution drawn for all leaves at once on the device."""
         b = self._b
-        pix = b.gen_pixels(down_scale, last_epoch, True, prob=prob, rand=rand)
+        if prob and b.processor is None:
+            from .image_process import ImageProcessor
+            b.processor = ImageProcessor([b.images[i].cpu().numpy() for i in range(b.n_images)], scale=0, sharp_imgs=b._sharp_in)
+        pix = b.gen_pixels(down_scale, last_epoch, compat_rng, prob=prob, rand=rand)
         b.result_leaf_tag = b._tags_i32.to(self._dev).contiguous() if self._dev.type == 'cuda' else b._tags_i32
         if self._dev_data is None:
             self._dev_data = (self.origins.to(self._dev), self.dirs.to(self._dev), self.images.to(self._dev))

@@ -131,7 +131,8 @@ class QuadTreeManager:
                 from .image_process import ImageProcessor
                 self.processor = ImageProcessor([self.images[i].cpu().numpy() for i in range(self.n_images)], scale=0,
                                                 sharp_imgs=self._sharp_in)
-            compat_rng = True   # the weighted draw is host-side numpy, as in the reference
+        if prob and not compat_rng:
+            return self._gen_pixels_prob_device(plans, last_epoch, rand)
         if compat_rng:
             pix, tags = [], []
             for ti, plan in enumerate(plans):
@@ -176,6 +177,75 @@ class QuadTreeManager:
             pix, tags = pix[perm], tags[perm]
             self._tags_i32 = tags.to(torch.int32)
             self.result_leaf_id = self._tags_i32.float()
+        self.result_pix = pix
+        return pix
+
+    def _gen_pixels_prob_device(self, plans, last_epoch, rand):
+        """prob=True picks without the per-leaf host loop: the same distribution as
+        nerf++-ours/tree.py:566-578 + image_process.py:58-93 -- per leaf int(n*(1-rand)) draws with probability
+        proportional to clip(var + 1e-6, 0.01 * mean_leaf, max_leaf) over the leaf's block
+        [int(x0):int(x1), int(y0):int(y1)] and n - that uniform draws -- evaluated for all leaves of all images at
+        once with tensor ops on the manager's device (segmented inverse-CDF over the pixels sorted by leaf)."""
+        dev = self.device
+        H, W, nI = self.h, self.w, self.n_images
+        sharp = torch.stack([torch.as_tensor(np.asarray(self.processor.sharp_imgs[i]), dtype=torch.float64)
+                             for i in range(nI)], 0).to(dev)                      # [nI,H,W]
+        # global leaf id per pixel: paint the leaf rectangles with a 2-D difference array (they partition the image)
+        boxes, base = [], [0]
+        for i in range(nI):
+            b = np.array([[0.0, 0.0, float(H), float(W)]]) if last_epoch else self.leaves(i)
+            boxes.append(np.concatenate([np.full((b.shape[0], 1), i), np.floor(b)], 1))
+            base.append(base[-1] + b.shape[0])
+        bx = torch.from_numpy(np.concatenate(boxes, 0)).to(dev).long()            # [L,5] img,x0,y0,x1,y1 (int())
+        L = bx.shape[0]
+        gid = torch.arange(1, L + 1, device=dev, dtype=torch.int64)
+        diff = torch.zeros(nI, H + 1, W + 1, device=dev, dtype=torch.int64)
+        for (r, c, sgn) in ((1, 2, 1), (1, 4, -1), (3, 2, -1), (3, 4, 1)):
+            diff.index_put_((bx[:, 0], bx[:, r], bx[:, c]), sgn * gid, accumulate=True)
+        leaf_of = diff.cumsum(1).cumsum(2)[:, :H, :W].reshape(-1) - 1          # [nI*H*W] global leaf id, -1 = uncovered
+        g = sharp.reshape(-1) + 1e-6
+        ok = leaf_of >= 0
+        lid = torch.where(ok, leaf_of, torch.zeros_like(leaf_of))
+        cnt = torch.zeros(L, device=dev, dtype=torch.float64).index_add_(0, lid[ok], torch.ones_like(g[ok]))
+        ssum = torch.zeros(L, device=dev, dtype=torch.float64).index_add_(0, lid[ok], g[ok])
+        gmin = 0.01 * ssum / cnt.clamp(min=1.0)
+        wgt = torch.where(ok, torch.maximum(g, gmin[lid]), torch.zeros_like(g))   # the /max and /sum factors cancel
+        order = torch.argsort(torch.where(ok, leaf_of, torch.full_like(leaf_of, L)), stable=True)
+        cum = torch.cumsum(wgt[order], 0)
+        seg_end = torch.cumsum(cnt.long(), 0)                                      # pixels of leaves 0..l
+        seg_beg = seg_end - cnt.long()
+        tot_before = torch.where(seg_beg > 0, cum[(seg_beg - 1).clamp(min=0)], torch.zeros_like(cum[:1]).expand(L))
+        tot = cum[(seg_end - 1).clamp(min=0)] - tot_before
+        # per-leaf counts (reference: n1 = int(n * (1 - rand)) weighted, n2 = n - n1 uniform)
+        allp = torch.from_numpy(np.concatenate(plans, 0)).to(dev).long()          # [L,5] n, r0, r1, c0, c1
+        n_all = allp[:, 0]
+        n1 = torch.floor(n_all.double() * (1.0 - rand)).long()
+        n1 = torch.where(cnt > 0, n1, torch.zeros_like(n1))   # (a leaf whose integer block is empty only gets uniform picks)
+        n2 = n_all - n1
+        img_of_leaf = bx[:, 0]
+        leaf_local = torch.arange(L, device=dev) - torch.as_tensor(base[:-1], device=dev)[img_of_leaf]
+        # weighted picks
+        i1 = torch.repeat_interleave(torch.arange(L, device=dev), n1)
+        u = torch.rand(i1.shape[0], device=dev, dtype=torch.float64)
+        target = tot_before[i1] + u * tot[i1]
+        pos = torch.searchsorted(cum, target, right=True)
+        pos = torch.minimum(torch.maximum(pos, seg_beg[i1]), seg_end[i1] - 1)
+        flat = order[pos]
+        pr = (flat // W) % H
+        pc = flat % W
+        pix1 = torch.stack([img_of_leaf[i1], pr, pc], 1)
+        # uniform picks (same integer ranges as the non-prob sampler)
+        i2 = torch.repeat_interleave(torch.arange(L, device=dev), n2)
+        xs = allp[i2, 1] + torch.floor(torch.rand(i2.shape[0], device=dev, dtype=torch.float64) * (allp[i2, 2] - allp[i2, 1])).long()
+        ys = allp[i2, 3] + torch.floor(torch.rand(i2.shape[0], device=dev, dtype=torch.float64) * (allp[i2, 4] - allp[i2, 3])).long()
+        pix2 = torch.stack([img_of_leaf[i2], xs, ys], 1)
+        pix = torch.cat([pix1, pix2], 0)
+        li = torch.cat([i1, i2], 0)
+        tags = torch.stack([img_of_leaf[li], leaf_local[li]], 1)
+        perm = torch.randperm(pix.shape[0], device=dev)
+        pix, tags = pix[perm], tags[perm]
+        self._tags_i32 = tags.to(torch.int32)
+        self.result_leaf_id = self._tags_i32.float()
         self.result_pix = pix
         return pix
 

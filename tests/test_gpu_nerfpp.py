@@ -207,3 +207,32 @@ def test_pp_quadtree_on_device(fn, golden_dir):
         mgr.adjust_tree_multiThread(rgb, torch.from_numpy(g[f'r{rnd}_pred']).cuda(), thres=0.012)
         for ti in range(len(samplers)):
             assert np.array_equal(mgr.leaves(ti), g[f'r{rnd}_after_t{ti}']), (rnd, ti)
+
+
+def test_pp_prob_picks_on_device(fn, golden_dir):
+    """The vectorised prob=True sampler runs on the GPU and feeds the same gather / tag plumbing."""
+    g = np.load(os.path.join(golden_dir, 'g12_pp_tree.npz'))
+    H, W = int(g['H']), int(g['W'])
+    imgs, rays_d = g['images'], g['rays_d']
+
+    class RS:
+        pass
+    samplers = []
+    for i in range(imgs.shape[0]):
+        rs = RS()
+        rs.H, rs.W = H, W
+        rs.img = imgs[i].reshape(-1, 3)
+        rs.rays_o = np.zeros((H * W, 3), dtype=np.float32)
+        rs.rays_d = rays_d[i].reshape(-1, 3)
+        samplers.append(rs)
+    mgr = fn.nerfpp.QuadTreeManager(samplers, mseThres=0.0, max_depth=2, device='cuda', sharp_imgs=list(g['sharp']))
+    torch.manual_seed(3)
+    o, d, rgb = mgr.gen_rays_v3_multiThread(down_scale=1, prob=True, rand=0.5, compat_rng=False)
+    n = imgs.shape[0] * H * W
+    assert o.shape == (n, 3) and d.is_cuda and rgb.shape == (n, 3)
+    tags = mgr.result_leaf_tag.cpu().numpy()
+    pix = mgr.result_pix.cpu().numpy()
+    assert np.allclose(rgb.cpu().numpy(), imgs[pix[:, 0], pix[:, 1], pix[:, 2]])
+    for i in range(imgs.shape[0]):
+        plan = mgr.leaf_plan(i, 1.0)
+        assert np.array_equal(np.bincount(tags[tags[:, 0] == i, 1], minlength=plan.shape[0]), plan[:, 0])

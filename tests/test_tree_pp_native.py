@@ -46,3 +46,49 @@ def test_prob_picks_and_mean_criterion(golden_dir):
         mgr.adjust_tree_from_sumcount(sums, counts, 0.012)
         for ti in range(n):
             assert np.array_equal(mgr.leaves(ti), g[f'r{rnd}_after_t{ti}']), (rnd, ti)
+
+
+def test_prob_picks_vectorised_distribution():
+    """the vectorised (device-capable) prob=True sampler draws from the same per-leaf distribution as
+    image_process.py:58-93 (clip(var + 1e-6, 0.01 mean_leaf, max_leaf), normalised over the leaf's block), keeps the
+    reference's per-leaf counts (int(n (1-rand)) weighted + the rest uniform) and tags every pick with its leaf."""
+    from fastnerf.tree import QuadTreeManager
+    from fastnerf.image_process import ImageProcessor
+    rng = np.random.RandomState(5)
+    H = W = 16
+    imgs = rng.rand(2, H, W, 3).astype(np.float32)
+    sharp = [np.where(rng.rand(H, W) < 0.3, 0.0, rng.rand(H, W) * 4.0) for _ in range(2)]   # many exact zeros: the clip floor matters
+    poses = np.tile(np.eye(4)[None, :3, :4], (2, 1, 1)).astype(np.float32)
+    mgr = QuadTreeManager(H, W, np.eye(3), imgs, poses, 0.0, 2, device='cpu', sharp_imgs=sharp)
+    mgr.processor = ImageProcessor([imgs[i] for i in range(2)], scale=0, sharp_imgs=sharp)
+    torch.manual_seed(11)
+    hits = np.zeros((2, H, W))
+    rounds = 400
+    for _ in range(rounds):
+        pix = mgr.gen_pixels(down_scale=1, last_epoch=False, compat_rng=False, prob=True, rand=0.0).numpy()
+        tags = mgr._tags_i32.numpy()
+        assert pix.shape == (2 * H * W, 3)
+        np.add.at(hits, (pix[:, 0], pix[:, 1], pix[:, 2]), 1)
+        # every pick lies inside the block of the leaf it is tagged with; per-leaf counts = the leaf plan
+        for i in range(2):
+            boxes = mgr.leaves(i)
+            sel = tags[:, 0] == i
+            b = boxes[tags[sel, 1]]
+            assert (pix[sel, 1] >= np.floor(b[:, 0])).all() and (pix[sel, 1] < np.floor(b[:, 2])).all()
+            assert (pix[sel, 2] >= np.floor(b[:, 1])).all() and (pix[sel, 2] < np.floor(b[:, 3])).all()
+            plan = mgr.leaf_plan(i, 1.0)
+            assert np.array_equal(np.bincount(tags[sel, 1], minlength=plan.shape[0]), plan[:, 0])
+    ip = mgr.processor
+    for i in range(2):
+        for (x0, y0, x1, y1) in mgr.leaves(i):
+            blk = (slice(int(x0), int(x1)), slice(int(y0), int(y1)))
+            p = ip.to_prob_v2(sharp[i][blk])
+            n = hits[i][blk].sum()
+            assert n == rounds * int((x1 - x0) * (y1 - y0))
+            sigma = np.sqrt(n * p * (1 - p)) + 1.0
+            assert (np.abs(hits[i][blk] - n * p) < 5.0 * sigma).all()
+    # mixed mode keeps the split between weighted and uniform picks and the tags
+    pix = mgr.gen_pixels(down_scale=1, last_epoch=False, compat_rng=False, prob=True, rand=0.5)
+    assert pix.shape[0] == 2 * H * W and mgr.result_leaf_id.shape == (2 * H * W, 2)
+    pix = mgr.gen_pixels(down_scale=1, last_epoch=True, compat_rng=False, prob=True, rand=0.5)
+    assert pix.shape[0] == 2 * H * W and (mgr._tags_i32[:, 1] == 0).all()
