@@ -34,12 +34,6 @@ typedef unsigned long long u64;
 #ifndef DW_NST
 #define DW_NST 3   // LDS stages of the dW operand ring (DW_NST - 1 k-steps prefetched)
 #endif
-#ifndef DW_LDS
-#define DW_LDS 1
-#endif
-#ifndef DW_PF
-#define DW_PF 2
-#endif
 #ifndef DW_CFG
 #define DW_CFG 2, 2, 4, 4
 #endif
@@ -896,141 +890,9 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
 }
 
 // =========================================================================================
-// backward: dW = dY^T X.  Operand fragments come straight from the K-fragment tensors (no LDS); every
-// workgroup owns a contiguous range of 64-point tiles and writes one fp32 partial (position order).
+// backward: dW = dY^T X, split over workgroups by point range; every workgroup writes one fp32 partial (position
+// order) and one reduction launch sums them.
 // =========================================================================================
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
-__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
-mlp_bwd_dw_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, int CTo, const uint4* __restrict__ X,
-                       int CTi, const float* __restrict__ dalpha, float* __restrict__ partial_w,
-                       float* __restrict__ partial_b, float* __restrict__ partial_r) {
-  constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wo = wave / WI, wi = wave % WI;
-  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
-  const int64_t t0 = blockIdx.x * per;
-  int64_t t1 = t0 + per;
-  if (t1 > ntiles) t1 = ntiles;
-
-  f32x16 acc[TO][TI];
-#pragma unroll
-  for (int a = 0; a < TO; ++a)
-#pragma unroll
-    for (int b = 0; b < TI; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float bsum[TO], rsum[TI];
-#pragma unroll
-  for (int a = 0; a < TO; ++a) bsum[a] = 0.f;
-#pragma unroll
-  for (int b = 0; b < TI; ++b) rsum[b] = 0.f;
-
-  const int64_t nq = (t1 > t0) ? (t1 - t0) * 4 : 0;   // k-steps of 16 points
-  uint4 ah0[TO], al0[TO], xh0[TI], xl0[TI], ah1[TO], al1[TO], xh1[TI], xl1[TI];
-  auto ld = [&](uint4 (&ah)[TO], uint4 (&al)[TO], uint4 (&xh)[TI], uint4 (&xl)[TI], int64_t q) {
-    const int64_t tile = t0 + (q >> 2);
-    const int ks = (int)(q & 3);
-    const uint4* pa = dY + ((tile * CTo + wo * TO) * 4 + ks) * 128 + lane;
-    const uint4* px = X + ((tile * CTi + wi * TI) * 4 + ks) * 128 + lane;
-#pragma unroll
-    for (int i = 0; i < TO; ++i) { ah[i] = pa[i * 512]; al[i] = pa[i * 512 + 64]; }
-#pragma unroll
-    for (int j = 0; j < TI; ++j) { xh[j] = px[j * 512]; xl[j] = px[j * 512 + 64]; }
-  };
-  auto mm = [&](const uint4 (&ah)[TO], const uint4 (&al)[TO], const uint4 (&xh)[TI], const uint4 (&xl)[TI], int64_t q) {
-#pragma unroll
-    for (int i = 0; i < TO; ++i)
-#pragma unroll
-      for (int j = 0; j < TI; ++j) acc[i][j] = bmfma(ah[i], xh[j], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < TO; ++i)
-#pragma unroll
-      for (int j = 0; j < TI; ++j) acc[i][j] = bmfma(ah[i], xl[j], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < TO; ++i)
-#pragma unroll
-      for (int j = 0; j < TI; ++j) acc[i][j] = bmfma(al[i], xh[j], acc[i][j]);
-    if (BIAS && wi == wo % WI) {
-#pragma unroll
-      for (int i = 0; i < TO; ++i) {
-        float v[8];
-        unpk8(ah[i], al[i], v);
-        bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      }
-    }
-    if (RANK1 && wo == (wi + 1) % WO) {
-      const float4* dp = reinterpret_cast<const float4*>(dalpha + (t0 + (q >> 2)) * 64 + (q & 3) * 16 + (lane >> 5) * 8);
-      const float4 d0 = dp[0], d1 = dp[1];
-      const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-      for (int j = 0; j < TI; ++j) {
-        float v[8];
-        unpk8(xh[j], xl[j], v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rsum[j] = fmaf(da[e], v[e], rsum[j]);
-      }
-    }
-  };
-#if DW_PF == 3
-  uint4 ah2[TO], al2[TO], xh2[TI], xl2[TI];
-  if (nq > 0) {
-    ld(ah0, al0, xh0, xl0, 0);
-    if (nq > 1) ld(ah1, al1, xh1, xl1, 1);
-#pragma unroll 1
-    for (int64_t q = 0; q < nq; q += 3) {   // two k-steps of operands in flight behind the one being multiplied
-      if (q + 2 < nq) ld(ah2, al2, xh2, xl2, q + 2);
-      mm(ah0, al0, xh0, xl0, q);
-      if (q + 1 < nq) {
-        if (q + 3 < nq) ld(ah0, al0, xh0, xl0, q + 3);
-        mm(ah1, al1, xh1, xl1, q + 1);
-      }
-      if (q + 2 < nq) {
-        if (q + 4 < nq) ld(ah1, al1, xh1, xl1, q + 4);
-        mm(ah2, al2, xh2, xl2, q + 2);
-      }
-    }
-  }
-#else
-  if (nq > 0) {
-    ld(ah0, al0, xh0, xl0, 0);
-#pragma unroll 1
-    for (int64_t q = 0; q < nq; q += 2) {
-      ld(ah1, al1, xh1, xl1, q + 1);
-      mm(ah0, al0, xh0, xl0, q);
-      if (q + 2 < nq) ld(ah0, al0, xh0, xl0, q + 2);
-      mm(ah1, al1, xh1, xl1, q + 1);
-    }
-  }
-#endif
-  float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
-#pragma unroll
-  for (int i = 0; i < TO; ++i)
-#pragma unroll
-    for (int j = 0; j < TI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = (wo * TO + i) * 32 + bcrow(r, lane);
-        const int c = (wi * TI + j) * 32 + (lane & 31);
-        pw[(int64_t)o * KI + c] = acc[i][j][r];
-      }
-  if (BIAS && wi == wo % WI) {
-#pragma unroll
-    for (int i = 0; i < TO; ++i) {
-      const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      if (lane < 32) partial_b[(int64_t)blockIdx.x * NO + (wo * TO + i) * 32 + lane] = s;
-    }
-  }
-  if (RANK1 && wo == (wi + 1) % WO) {
-#pragma unroll
-    for (int j = 0; j < TI; ++j) {
-      const float s = rsum[j] + __shfl_xor(rsum[j], 32, 64);
-      if (lane < 32) partial_r[(int64_t)blockIdx.x * KI + (wi * TI + j) * 32 + lane] = s;
-    }
-  }
-}
-
 // one k-step (16 points) of a dW job from an LDS stage: fragments, 3-term MFMAs, bias / rank-1 side sums
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 bmfma4(const u32x4& a, const u32x4& b, f32x16 c) {
@@ -1099,8 +961,8 @@ __device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&
   }
 }
 
-// LDS-staged variant: every operand byte is fetched from HBM exactly once per workgroup (the direct-from-global
-// variant above lets the two waves that share an operand tile both miss in L2: PMC showed 1.7x the algorithmic fetch
+// Every operand byte is fetched from HBM exactly once per workgroup (a first version that loaded fragments straight
+// from global let the two waves that share an operand tile both miss in L2: PMC showed 1.7x the algorithmic fetch
 // bytes).  Per k-step of 16 points the (CTO + CTI) operand tiles (2 KiB each: hi + lo plane) are copied by LDS-DMA
 // (global_load_lds_dwordx4, 1 KiB per wave instruction) into a ring of three stages, two k-steps ahead of the MFMAs;
 // the hand-over is a raw s_barrier behind a counted vmcnt wait so that the newest stage stays in flight across it.
@@ -1316,7 +1178,6 @@ static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, cons
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
   float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
-#if DW_LDS
   FN_CHECK_ARG(CTo == WO * TO && CTi == WI * TI, "dW job shape");
   constexpr int lds = DW_NST * (WO * TO + WI * TI) * 128 * 16;
   auto kern = mlp_bwd_dw_lds_bf16_kernel<WO, WI, TO, TI, BIAS, RANK1>;
@@ -1326,10 +1187,6 @@ static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, cons
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, ntiles, dY, X, dalpha, pw, pb, pr);
-#else
-  hipLaunchKernelGGL((mlp_bwd_dw_bf16_kernel<WO, WI, TO, TI, BIAS, RANK1>), dim3(nwg), dim3(WO * WI * 64), 0, st, P,
-                     ntiles, dY, CTo, X, CTi, dalpha, pw, pb, pr);
-#endif
   FN_LAUNCH_CHECK();
   return 0;
 }
