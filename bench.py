@@ -154,16 +154,17 @@ def main():
         except Exception:
             pass
         if split:
-            # every algorithmic multiply-add is issued as 3 bf16 MFMA terms (hi*hi + hi*lo + lo*hi): price the
-            # matrix work actually executed against the dense bf16 MFMA peak
-            peak, executed = BF16_MFMA_PEAK_TFLOPS, 3.0 * achieved
+            # every algorithmic multiply-add is issued as 3 bf16 MFMA terms (hi*hi + hi*lo + lo*hi), so the roofline of
+            # the algorithmic FLOPs is the dense bf16 MFMA peak / 3
+            peak = BF16_MFMA_PEAK_TFLOPS / 3.0
         else:
-            peak, executed = FP32_MFMA_PEAK_TFLOPS, achieved
+            peak = FP32_MFMA_PEAK_TFLOPS
         roof = {'bound': 'mfma', 'kernel': kname[5:] + ' (fine pass, 786432 points/launch)',
-                'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
+                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                'peak_note': ('dense bf16 MFMA 2500 TFLOP/s / 3 split terms per product' if split
+                              else 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)'),
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01_pmc_traffic.json)',
-                'avg_launch_ms': ms, 'flop_per_launch': flops, 'algorithmic_tflops': achieved,
-                'mfma_terms_per_product': 3 if split else 1,
+                'avg_launch_ms': ms, 'flop_per_launch': flops, 'mfma_tflops_issued': (3.0 if split else 1.0) * achieved,
                 'hbm_write_GBps': (ops.act_floats(P) * 4 / (ms * 1e-3) / 1e9)}
         del act
 
