@@ -307,6 +307,8 @@ __device__ __forceinline__ void bzero(f32x16 (&acc)[2][NT]) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 }
+// (bzero costs nothing: the compiler folds the zero into the first MFMA of every accumulator as an inline constant;
+// starting the accumulators at the bias instead measured slower -- 64 extra v_mov per layer.)
 // C layout of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int bcrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -344,6 +346,7 @@ struct EpiArgs {
   const void* mask_in;        // MASK: the forward's ReLU sign bits of this tile and layer (one word per thread)
   void* mask_out;             // MOUT: where this tile's sign bits go
   uint2* gsave;               // GSAVE: K-fragment tensor, already offset to the tile
+  const int* hofs;            // optional: this lane's 16 precomputed LDS offsets hoff(bcrow(r), slot) + inslot (rows mt = 0)
 };
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -376,7 +379,7 @@ __device__ __forceinline__ float mask_pop(unsigned& m, float v) {
 //   - LDS: the column pair is one packed 32-bit store per plane and row,
 //   - global: 4 consecutive rows of one column = 8 bytes of a K-fragment element (see the file header),
 //   - sign bits (forward, ReLU layers): 64 per thread and layer, order mt, r, nt.
-template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE>
+template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE, bool HOFS = false>
 __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs& ea, char* Hhi, char* Hlo, int wn,
                                         int lane) {
   asm volatile("" : "+v"(lane));
@@ -405,7 +408,8 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
       if (MOUT) { mo = mask_push(mo, v0); mo = mask_push(mo, v1); }
       if (MASK) { v0 = mask_pop(mi, v0); v1 = mask_pop(mi, v1); }
       split_pair(v0, v1, H[r], L[r]);
-      const int o = hoff(m, slot) + inslot;
+      // (rows m and m + 32 share m & 15, so the second row tile is the first one's offset + 32 rows)
+      const int o = HOFS ? ea.hofs[r] + mt * (32 * 512) : hoff(m, slot) + inslot;
       *reinterpret_cast<unsigned*>(Hhi + o) = H[r];
       *reinterpret_cast<unsigned*>(Hlo + o) = L[r];
     }
@@ -557,6 +561,13 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
   u64* maskw_all = SAVE ? reinterpret_cast<u64*>(act + ba_mask(ntiles)) : nullptr;            // [tile][8][256] u64
   unsigned* maskv_all = SAVE ? reinterpret_cast<unsigned*>(act + ba_maskv(ntiles)) : nullptr;   // [tile][256] u32
 
+  int hofs[16];   // LDS offsets of this lane's epilogue stores (loop invariant; not for BG: that variant has no registers left)
+  if (!BG) {
+    const int n0 = wn * 64 + 2 * (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hofs[r] = hoff(bcrow(r, lane), n0 >> 3) + (n0 & 7) * 2;
+  }
+
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * BTM;
     const int valid = (int)((P - p0) < BTM ? (P - p0) : BTM);
@@ -631,6 +642,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     }
     f32x16 acc[2][2];
     EpiArgs ea{};
+    ea.hofs = hofs;
     // L0
     bzero<2>(acc);
     if (!BG) {
@@ -645,7 +657,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, 0) + tile * 4096);
       ea.mask_out = maskw_all + (tile * 8 + 0) * 256;
     }
-    bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<true, true, false, false, SAVE, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
@@ -672,7 +684,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, l) + tile * 4096);
         ea.mask_out = maskw_all + (tile * 8 + l) * 256;
       }
-      bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+      bepi256<true, true, false, false, SAVE, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
       __syncthreads();
     }
     // alpha head + view-direction encoding
@@ -724,7 +736,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     __syncthreads();
     ea.bias = params + lay.FB;
     if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(ntiles) + tile * 4096);
-    bepi256<true, false, false, false, false, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<true, false, false, false, false, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // view layer: [feat256 | vpe32] -> 128, ReLU
     {
@@ -828,6 +840,13 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
   const u64* maskw_all = reinterpret_cast<const u64*>(act + ba_mask(ntiles));
   const unsigned* maskv_all = reinterpret_cast<const unsigned*>(act + ba_maskv(ntiles));
 
+  int hofs[16];   // LDS offsets of this lane's epilogue stores (loop invariant)
+  {
+    const int n0 = wn * 64 + 2 * (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hofs[r] = hoff(bcrow(r, lane), n0 >> 3) + (n0 & 7) * 2;
+  }
+
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * BTM;
     if (tid < BTM) {
@@ -839,6 +858,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     }
     __syncthreads();
     EpiArgs ea{};
+    ea.hofs = hofs;
     // ---- dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] ---------------------------------------------------
     {
       f32x16 av[2][1];
@@ -863,7 +883,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     bgemm<2, 0>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane);
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(ntiles) + tile * 4096);
-    bepi256<false, false, false, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<false, false, false, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ---------------------------------------------------
     bzero<2>(acc);
@@ -873,7 +893,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     ea.mask_in = maskw_all + (tile * 8 + 7) * 256;
     ea.dalpha4 = Dr;
     ea.wa = params + lay.AW;
-    bepi256<false, false, true, true, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<false, false, true, true, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY_{l-1} = (dY_l . W_l[:, h part]) * [h_{l-1} > 0],  l = 7..1 ---------------------------------
 #pragma unroll 1
@@ -883,7 +903,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
       __syncthreads();
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, l - 1) + tile * 4096);
       ea.mask_in = maskw_all + (tile * 8 + (l - 1)) * 256;
-      bepi256<false, false, true, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+      bepi256<false, false, true, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
       __syncthreads();
     }
   }
