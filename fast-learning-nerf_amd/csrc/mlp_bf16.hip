@@ -368,9 +368,9 @@ __device__ __forceinline__ void split1(float a, unsigned& hi, unsigned& lo) {   
 __device__ __forceinline__ unsigned mask_push(unsigned m, float v) {
   return __builtin_amdgcn_alignbit(m, __float_as_uint(v) + 0x7fffffffu, 31);   // (m << 1) | (v > 0)
 }
-__device__ __forceinline__ float mask_pop(unsigned& m, float v) {
-  const unsigned keep = (unsigned)((int)m >> 31);
-  m <<= 1;
+// k-th pushed value of a full 32-value word sits at bit 31 - k: one signed bit-field extract + one AND
+__device__ __forceinline__ float mask_get(unsigned m, int k, float v) {
+  const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)m, 31 - k, 1);
   return __uint_as_float(__float_as_uint(v) & keep);
 }
 
@@ -406,7 +406,7 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
       }
       if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       if (MOUT) { mo = mask_push(mo, v0); mo = mask_push(mo, v1); }
-      if (MASK) { v0 = mask_pop(mi, v0); v1 = mask_pop(mi, v1); }
+      if (MASK) { v0 = mask_get(mi, 2 * r, v0); v1 = mask_get(mi, 2 * r + 1, v1); }
       split_pair(v0, v1, H[r], L[r]);
       // (rows m and m + 32 share m & 15, so the second row tile is the first one's offset + 32 rows)
       const int o = HOFS ? ea.hofs[r] + mt * (32 * 512) : hoff(m, slot) + inslot;
@@ -483,7 +483,7 @@ __device__ __forceinline__ void bepi128(const f32x16 (&acc)[2][1], const EpiArgs
       float v0 = acc[mt][0][r] + bv, v1 = acc[mt][0][r + 1] + bv;
       if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
       if (MOUT) { mo = mask_push(mo, v0); mo = mask_push(mo, v1); }
-      if (MASK) { v0 = mask_pop(mi, v0); v1 = mask_pop(mi, v1); }
+      if (MASK) { v0 = mask_get(mi, mt * 16 + r, v0); v1 = mask_get(mi, mt * 16 + r + 1, v1); }
       split_pair(v0, v1, H[r >> 1], L[r >> 1]);
       const int o0 = hoff(m, slot) + inslot, o1 = hoff(m + 1, slot) + inslot;
       *reinterpret_cast<unsigned short*>(Hhi + o0) = (unsigned short)H[r >> 1];
