@@ -168,6 +168,30 @@ def main():
                 'hbm_write_GBps': (ops.act_floats(P) * 4 / (ms * 1e-3) / 1e9)}
         del act
 
+    # ---- the same step in the exact-fp32 math mode, for reference (1 GPU only; not `value`) ----------------------
+    alt = None
+    if rank == 0 and world == 1 and ops.get_math() != 'fp32':
+        main_mode = ops.get_math()
+        ops.set_math('fp32')
+        try:
+            torch.manual_seed(0)
+            ktr32, _, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
+            tr32 = fastnerf.run_nerf.Trainer(ktr32, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+            for i in range(2):
+                tr32.step(*batches[i % n_batches])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n32 = 5
+            for i in range(n32):
+                l32, _ = tr32.step(*batches[(2 + i) % n_batches])
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t1) / n32
+            alt = {'math_mode': 'fp32', 'dtype': 'f32', 'value': N_RAYS / dt32, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt32,
+                   'steps': n32, 'frac_of_fp32_mfma_peak': N_RAYS / dt32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            del tr32, ktr32
+        finally:
+            ops.set_math(main_mode)
+
     # ---- inference rays/s (render_path-style, perturb=0, no saved activations), rank 0 only -------------
     infer = None
     if rank == 0:
@@ -206,6 +230,7 @@ def main():
             'step_frac_of_bf16_mfma_peak_x3': 3.0 * step_tflops / BF16_MFMA_PEAK_TFLOPS,
             'roofline': roof,
             'inference': infer,
+            'exact_fp32_mode': alt,
             'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(),
         }
         print(json.dumps(out))
