@@ -1,0 +1,45 @@
+// render.cpp -- host-side sequencing of the fused forward of render_rays (render.py:238-299): one C-ABI call
+// enqueues  coarse sampler -> coarse MLP -> compositing -> [inverse-CDF + merge -> fine MLP -> compositing]
+// on the caller's stream.  No kernels here; every stage is one of the library's own entry points.
+#include <stdint.h>
+#include "../../include/fastnerf.h"
+
+namespace fn { void set_error(const char* fmt, ...); }
+
+extern "C" int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11,
+                                        int lindisp, int perturb, int det, int white_bkgd, const float* t_rand, const float* u,
+                                        const float* noise0, const float* noise1, uint64_t seed0, uint64_t seed1,
+                                        const float* params_c, const float* packed_c, const float* params_f,
+                                        const float* packed_f, float* z0, float* raw0, float* act0, float* rgb0,
+                                        float* disp0, float* acc0, float* w0, float* depth0, float* z1,
+                                        float* z_samples, float* z_std, float* raw1, float* act1, float* rgb1,
+                                        float* disp1, float* acc1, float* w1, float* depth1, fn_stream_t stream) {
+  if ((math_mode != 0 && math_mode != 1) || n < 0 || N_samples < 2 || N_importance < 0) {
+    fn::set_error("fastnerf_render_rays_fwd: bad argument: math_mode in {0,1}, n>=0, N_samples>=2, N_importance>=0");
+    return -1;
+  }
+  if (n == 0) return 0;
+  if (!rays11 || !params_c || !packed_c || !z0 || !raw0 || !rgb0 || !disp0 || !acc0 || !w0 || !depth0) {
+    fn::set_error("fastnerf_render_rays_fwd: null pointer (coarse pass)");
+    return -1;
+  }
+  int rc;
+  auto mlp = [&](int64_t nn, int S, const float* z, const float* params, const float* packed, float* raw, float* act) {
+    return math_mode ? fastnerf_mlp_bf16_fwd(0, nn, S, rays11, z, params, packed, raw, act, stream)
+                     : fastnerf_mlp_fwd_ex(0, nn, S, rays11, z, params, packed, raw, act, stream);
+  };
+  if ((rc = fastnerf_sample_coarse(n, N_samples, rays11, lindisp, perturb, t_rand, seed0, z0, stream))) return rc;
+  if ((rc = mlp(n, N_samples, z0, params_c, packed_c, raw0, act0))) return rc;
+  if ((rc = fastnerf_raw2outputs_fwd(n, N_samples, raw0, z0, rays11, noise0, white_bkgd, rgb0, disp0, acc0, w0, depth0, stream)))
+    return rc;
+  if (N_importance == 0) return 0;
+  if (!params_f || !packed_f || !z1 || !z_samples || !z_std || !raw1 || !rgb1 || !disp1 || !acc1 || !w1 || !depth1) {
+    fn::set_error("fastnerf_render_rays_fwd: null pointer (fine pass)");
+    return -1;
+  }
+  const int S1 = N_samples + N_importance;
+  if ((rc = fastnerf_sample_pdf_merge(n, N_samples, N_importance, z0, w0, det, u, seed1, z1, z_samples, z_std, stream)))
+    return rc;
+  if ((rc = mlp(n, S1, z1, params_f, packed_f, raw1, act1))) return rc;
+  return fastnerf_raw2outputs_fwd(n, S1, raw1, z1, rays11, noise1, white_bkgd, rgb1, disp1, acc1, w1, depth1, stream);
+}

@@ -209,6 +209,46 @@ def raw2outputs_fwd(raw, z, rays11, noise=None, white_bkgd=False):
     return rgb, disp, acc, weights, depth
 
 
+def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N_importance, lindisp=False, perturb=False,
+                    det=True, white_bkgd=False, t_rand=None, u=None, noise0=None, noise1=None, seed0=0, seed1=0, save=False):
+    """One C-ABI call for the whole forward of render_rays (render.py:238-299).  Returns a dict of the tensors the
+    step-by-step ops would have produced (same kernels, same results).  params_f / packed_f may be None when
+    N_importance == 0."""
+    require_gpu(rays11, params_c, packed_c, params_f, packed_f, t_rand, u, noise0, noise1)
+    n = rays11.shape[0]
+    dev = rays11.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    split = _split(0)
+    tag = 'bf16x3' if split else 'fp32'
+    assert getattr(packed_c, '_fn_math', None) == tag and (packed_f is None or getattr(packed_f, '_fn_math', None) == tag), \
+        'packed weights were not produced by mlp_pack under the current math mode'
+    if t_rand is not None:
+        t_rand = _f32(t_rand)
+        assert t_rand.shape == (n, N_samples)
+    if u is not None:
+        u = _f32(u)
+        assert u.shape == (n, N_importance)
+    o = {'z0': torch.empty(n, N_samples, **f32), 'raw0': torch.empty(n, N_samples, 4, **f32),
+         'act0': torch.empty(act_floats(n * N_samples), **f32) if save else None,
+         'rgb0': torch.empty(n, 3, **f32), 'disp0': torch.empty(n, **f32), 'acc0': torch.empty(n, **f32),
+         'w0': torch.empty(n, N_samples, **f32), 'depth0': torch.empty(n, **f32)}
+    S1 = N_samples + N_importance
+    if N_importance > 0:
+        o.update({'z1': torch.empty(n, S1, **f32), 'z_samples': torch.empty(n, N_importance, **f32), 'z_std': torch.empty(n, **f32),
+                  'raw1': torch.empty(n, S1, 4, **f32), 'act1': torch.empty(act_floats(n * S1), **f32) if save else None,
+                  'rgb1': torch.empty(n, 3, **f32), 'disp1': torch.empty(n, **f32), 'acc1': torch.empty(n, **f32),
+                  'w1': torch.empty(n, S1, **f32), 'depth1': torch.empty(n, **f32)})
+    g = o.get
+    check(lib().fastnerf_render_rays_fwd(
+        1 if split else 0, n, int(N_samples), int(N_importance), ptr(rays11), int(bool(lindisp)),
+        int(bool(perturb) or t_rand is not None), int(bool(det)), int(bool(white_bkgd)), ptr(t_rand), ptr(u), ptr(noise0), ptr(noise1),
+        int(seed0), int(seed1), ptr(params_c), ptr(packed_c), ptr(params_f), ptr(packed_f),
+        ptr(o['z0']), ptr(o['raw0']), ptr(o['act0']), ptr(o['rgb0']), ptr(o['disp0']), ptr(o['acc0']), ptr(o['w0']), ptr(o['depth0']),
+        ptr(g('z1')), ptr(g('z_samples')), ptr(g('z_std')), ptr(g('raw1')), ptr(g('act1')), ptr(g('rgb1')), ptr(g('disp1')),
+        ptr(g('acc1')), ptr(g('w1')), ptr(g('depth1')), stream()), 'fastnerf_render_rays_fwd')
+    return o
+
+
 def raw2outputs_bwd(raw, z, rays11, g_rgb, noise=None, white_bkgd=False, draw=None):
     require_gpu(raw, z, rays11, g_rgb, noise)
     n, S = z.shape

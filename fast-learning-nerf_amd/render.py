@@ -55,31 +55,28 @@ class _Workspace:
 def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, perturb, white_bkgd, t_rand, u, noise0,
                   noise1, save, packed_c=None, packed_f=None):
     """The fused forward.  Returns (outputs dict, saved-for-backward dict)."""
-    n = rays11.shape[0]
-    dev = rays11.device
     pc = packed_c if packed_c is not None else net_c.packed()
-    z0 = ops.sample_coarse(rays11, N_samples, lindisp=lindisp, perturb=perturb, t_rand=t_rand,
-                           seed=_next_seed() if (perturb and t_rand is None) else 0)
-    act0 = torch.empty(ops.act_floats(n * N_samples), device=dev, dtype=torch.float32) if save else None
-    raw0 = ops.mlp_fwd(rays11, z0, net_c.flat, pc[0], act=act0)
-    rgb0, disp0, acc0, w0, depth0 = ops.raw2outputs_fwd(raw0, z0, rays11, noise0, white_bkgd)
-    out = {}
-    saved = {'rays11': rays11, 'z0': z0, 'raw0': raw0, 'act0': act0, 'noise0': noise0, 'white': white_bkgd,
-             'net_c': net_c, 'net_f': None, 'pc': pc}
+    fine = pf = None
     if N_importance > 0:
         fine = net_f if net_f is not None else net_c
         pf = packed_f if packed_f is not None else (fine.packed() if fine is not net_c else pc)
-        z1, z_samples, z_std = ops.sample_pdf_merge(z0, w0, N_importance, det=(perturb == 0.), u=u,
-                                                    seed=_next_seed() if (perturb and u is None) else 0)
-        S1 = N_samples + N_importance
-        act1 = torch.empty(ops.act_floats(n * S1), device=dev, dtype=torch.float32) if save else None
-        raw1 = ops.mlp_fwd(rays11, z1, fine.flat, pf[0], act=act1)
-        rgb1, disp1, acc1, w1, depth1 = ops.raw2outputs_fwd(raw1, z1, rays11, noise1, white_bkgd)
-        out.update(rgb_map=rgb1, disp_map=disp1, acc_map=acc1, raw=raw1, rgb0=rgb0, disp0=disp0, acc0=acc0,
-                   z_std=z_std, weights=w1, z_vals=z1, depth_map=depth1, z_samples=z_samples, weights0=w0, z0=z0)
-        saved.update(z1=z1, raw1=raw1, act1=act1, noise1=noise1, net_f=fine, pf=pf)
+    # one C-ABI call enqueues sampler -> MLP -> compositing [-> sample_pdf + merge -> MLP -> compositing]
+    o = ops.render_rays_fwd(rays11, net_c.flat, pc[0], None if fine is None else fine.flat, None if pf is None else pf[0],
+                            N_samples, N_importance, lindisp=lindisp, perturb=perturb, det=(perturb == 0.),
+                            white_bkgd=white_bkgd, t_rand=t_rand, u=u, noise0=noise0, noise1=noise1,
+                            seed0=_next_seed() if (perturb and t_rand is None) else 0,
+                            seed1=_next_seed() if (N_importance > 0 and perturb and u is None) else 0, save=save)
+    out = {}
+    saved = {'rays11': rays11, 'z0': o['z0'], 'raw0': o['raw0'], 'act0': o['act0'], 'noise0': noise0, 'white': white_bkgd,
+             'net_c': net_c, 'net_f': None, 'pc': pc}
+    if N_importance > 0:
+        out.update(rgb_map=o['rgb1'], disp_map=o['disp1'], acc_map=o['acc1'], raw=o['raw1'], rgb0=o['rgb0'], disp0=o['disp0'],
+                   acc0=o['acc0'], z_std=o['z_std'], weights=o['w1'], z_vals=o['z1'], depth_map=o['depth1'],
+                   z_samples=o['z_samples'], weights0=o['w0'], z0=o['z0'])
+        saved.update(z1=o['z1'], raw1=o['raw1'], act1=o['act1'], noise1=noise1, net_f=fine, pf=pf)
     else:
-        out.update(rgb_map=rgb0, disp_map=disp0, acc_map=acc0, raw=raw0, weights=w0, z_vals=z0, depth_map=depth0)
+        out.update(rgb_map=o['rgb0'], disp_map=o['disp0'], acc_map=o['acc0'], raw=o['raw0'], weights=o['w0'], z_vals=o['z0'],
+                   depth_map=o['depth0'])
     return out, saved
 
 

@@ -147,6 +147,20 @@ int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const
 int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                           const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
 
+/* ---- fused forward of render_rays (render.py:238-299): coarse sampler -> coarse MLP -> compositing ->
+ * [sample_pdf + merge -> fine MLP -> compositing], enqueued by one call on `stream`.  math_mode 0 = exact fp32,
+ * 1 = split-bf16; packed_* must come from the matching pack entry point; act0 / act1 == NULL: inference.  perturb /
+ * t_rand / seed0 as fastnerf_sample_coarse, det / u / seed1 as fastnerf_sample_pdf_merge, noise* as
+ * fastnerf_raw2outputs_fwd.  N_importance == 0: coarse pass only (the *_f / *1 arguments are ignored).  All buffers
+ * are caller-owned device memory with the shapes of the individual entry points. */
+int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11, int lindisp,
+                             int perturb, int det, int white_bkgd, const float* t_rand, const float* u,
+                             const float* noise0, const float* noise1, uint64_t seed0, uint64_t seed1,
+                             const float* params_c, const float* packed_c, const float* params_f, const float* packed_f,
+                             float* z0, float* raw0, float* act0, float* rgb0, float* disp0, float* acc0, float* w0,
+                             float* depth0, float* z1, float* z_samples, float* z_std, float* raw1, float* act1,
+                             float* rgb1, float* disp1, float* acc1, float* w1, float* depth1, fn_stream_t stream);
+
 /* ---- nerf++-ours additions ------------------------------------------- */
 /* get_rays_single_image (nerf_sample_ray_split.py:10-34): intrinsics_host / c2w_host are 4x4 row-major
  * doubles; rays_o / rays_d [H*W,3]. */
