@@ -43,3 +43,45 @@ extern "C" int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples,
   if ((rc = mlp(n, S1, z1, params_f, packed_f, raw1, act1))) return rc;
   return fastnerf_raw2outputs_fwd(n, S1, raw1, z1, rays11, noise1, white_bkgd, rgb1, disp1, acc1, w1, depth1, stream);
 }
+
+// Backward of the same chain (autograd of render.py:238-299 w.r.t. the network parameters; sample positions are
+// detached in the reference, so the coarse net only sees d(loss)/d(rgb0)): compositing backward -> MLP backward for the
+// fine pass (into grads_f) and the coarse pass (into grads_c).  draw_ws: n * (N_samples + N_importance) * 4 floats.
+extern "C" int fastnerf_render_rays_bwd(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11,
+                                        int white_bkgd, const float* g_rgb, const float* g_rgb0, const float* noise0,
+                                        const float* noise1, const float* z0, const float* raw0, const float* act0,
+                                        const float* z1, const float* raw1, const float* act1, const float* params_c,
+                                        const float* packed_bwd_c, const float* params_f, const float* packed_bwd_f,
+                                        float* draw_ws, float* dact_ws, float* partial_ws, float* grads_c, float* grads_f,
+                                        fn_stream_t stream) {
+  if ((math_mode != 0 && math_mode != 1) || n <= 0 || N_samples < 2 || N_importance < 0) {
+    fn::set_error("fastnerf_render_rays_bwd: bad argument: math_mode in {0,1}, n>0, N_samples>=2, N_importance>=0");
+    return -1;
+  }
+  if (!rays11 || !z0 || !raw0 || !act0 || !params_c || !packed_bwd_c || !draw_ws || !dact_ws || !partial_ws || !grads_c) {
+    fn::set_error("fastnerf_render_rays_bwd: null pointer (coarse pass)");
+    return -1;
+  }
+  int rc;
+  auto mlp = [&](int S, const float* act, const float* params, const float* packed, float* grads) {
+    return math_mode ? fastnerf_mlp_bf16_bwd(0, n, S, draw_ws, act, params, packed, dact_ws, partial_ws, grads, stream)
+                     : fastnerf_mlp_bwd_ex(0, n, S, draw_ws, act, params, packed, dact_ws, partial_ws, grads, stream);
+  };
+  const float* g_coarse = g_rgb;
+  if (N_importance > 0) {
+    if (!g_rgb || !g_rgb0 || !z1 || !raw1 || !act1 || !params_f || !packed_bwd_f || !grads_f) {
+      fn::set_error("fastnerf_render_rays_bwd: null pointer (fine pass)");
+      return -1;
+    }
+    const int S1 = N_samples + N_importance;
+    if ((rc = fastnerf_raw2outputs_bwd(n, S1, raw1, z1, rays11, noise1, white_bkgd, g_rgb, draw_ws, stream))) return rc;
+    if ((rc = mlp(S1, act1, params_f, packed_bwd_f, grads_f))) return rc;
+    g_coarse = g_rgb0;
+  }
+  if (!g_coarse) {
+    fn::set_error("fastnerf_render_rays_bwd: null gradient");
+    return -1;
+  }
+  if ((rc = fastnerf_raw2outputs_bwd(n, N_samples, raw0, z0, rays11, noise0, white_bkgd, g_coarse, draw_ws, stream))) return rc;
+  return mlp(N_samples, act0, params_c, packed_bwd_c, grads_c);
+}

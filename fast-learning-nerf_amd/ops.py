@@ -249,6 +249,24 @@ def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N
     return o
 
 
+def render_rays_bwd(rays11, white_bkgd, g_rgb, g_rgb0, noise0, noise1, z0, raw0, act0, z1, raw1, act1, params_c, packed_bwd_c,
+                    params_f, packed_bwd_f, draw_ws, dact_ws, partial, grads_c, grads_f, N_samples, N_importance):
+    """One C-ABI call for the backward of render_rays w.r.t. the parameters of the (distinct) coarse / fine nets."""
+    require_gpu(rays11, g_rgb, g_rgb0, z0, raw0, act0, z1, raw1, act1, params_c, packed_bwd_c, params_f, packed_bwd_f, draw_ws,
+                dact_ws, partial, grads_c, grads_f)
+    n = rays11.shape[0]
+    S1 = N_samples + N_importance
+    tag = 'bf16x3' if _split(0) else 'fp32'
+    assert getattr(packed_bwd_c, '_fn_math', None) == tag and (packed_bwd_f is None or getattr(packed_bwd_f, '_fn_math', None) == tag), \
+        'packed weights were not produced by mlp_pack under the current math mode'
+    assert draw_ws.numel() >= n * S1 * 4 and dact_ws.numel() >= dact_floats(n * S1)
+    check(lib().fastnerf_render_rays_bwd(
+        1 if _split(0) else 0, n, int(N_samples), int(N_importance), ptr(rays11), int(bool(white_bkgd)), ptr(g_rgb), ptr(g_rgb0),
+        ptr(noise0), ptr(noise1), ptr(z0), ptr(raw0), ptr(act0), ptr(z1), ptr(raw1), ptr(act1), ptr(params_c), ptr(packed_bwd_c),
+        ptr(params_f), ptr(packed_bwd_f), ptr(draw_ws), ptr(dact_ws), ptr(partial), ptr(grads_c), ptr(grads_f), stream()),
+        'fastnerf_render_rays_bwd')
+
+
 def raw2outputs_bwd(raw, z, rays11, g_rgb, noise=None, white_bkgd=False, draw=None):
     require_gpu(raw, z, rays11, g_rgb, noise)
     n, S = z.shape

@@ -90,29 +90,32 @@ def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None):
     out_c = out_c if out_c is not None else net_c.flat_grad
     if net_f is not None and net_f is not net_c:
         out_f = out_f if out_f is not None else net_f.flat_grad
-    if net_f is not None:
-        n, S1 = saved['z1'].shape
-        if g_rgb is None:
-            g_rgb = torch.zeros(n, 3, device=dev)
-        draw1 = ops.raw2outputs_bwd(saved['raw1'], saved['z1'], rays11, g_rgb, saved['noise1'], saved['white'])
-        dact = _Workspace.dact(dev, ops.dact_floats(n * S1))
-        if net_f is net_c:
-            gtmp = torch.empty_like(out_c)
-            ops.mlp_bwd(draw1, saved['act1'], net_f.flat, saved['pf'][1], dact, partial, gtmp)
-        else:
-            ops.mlp_bwd(draw1, saved['act1'], net_f.flat, saved['pf'][1], dact, partial, out_f)
-            gtmp = None
-        g_c = g_rgb0
-    else:
-        g_c, gtmp = g_rgb, None
     n, S0 = saved['z0'].shape
-    if g_c is None:
-        g_c = torch.zeros(n, 3, device=dev)
+    if net_f is None or net_f is not net_c:
+        # one C-ABI call: compositing backward + MLP backward for the fine and the coarse pass
+        Ni = 0 if net_f is None else saved['z1'].shape[1] - S0
+        g_a = g_rgb if g_rgb is not None else torch.zeros(n, 3, device=dev)
+        g_b = (g_rgb0 if g_rgb0 is not None else torch.zeros(n, 3, device=dev)) if Ni > 0 else None
+        ws = _Workspace.dact(dev, ops.dact_floats(n * (S0 + Ni)) + n * (S0 + Ni) * 4)
+        draw_ws = ws[ops.dact_floats(n * (S0 + Ni)):]
+        ops.render_rays_bwd(rays11, saved['white'], g_a, g_b, saved['noise0'], saved.get('noise1'), saved['z0'], saved['raw0'],
+                            saved['act0'], saved.get('z1'), saved.get('raw1'), saved.get('act1'), net_c.flat, saved['pc'][1],
+                            None if Ni == 0 else net_f.flat, None if Ni == 0 else saved['pf'][1], draw_ws, ws, partial, out_c,
+                            out_f if Ni > 0 else None, S0, Ni)
+        return
+    # one shared network for both passes (N_importance > 0 without network_fine): accumulate the two gradients
+    n, S1 = saved['z1'].shape
+    if g_rgb is None:
+        g_rgb = torch.zeros(n, 3, device=dev)
+    draw1 = ops.raw2outputs_bwd(saved['raw1'], saved['z1'], rays11, g_rgb, saved['noise1'], saved['white'])
+    dact = _Workspace.dact(dev, ops.dact_floats(n * S1))
+    gtmp = torch.empty_like(out_c)
+    ops.mlp_bwd(draw1, saved['act1'], net_f.flat, saved['pf'][1], dact, partial, gtmp)
+    g_c = g_rgb0 if g_rgb0 is not None else torch.zeros(n, 3, device=dev)
     draw0 = ops.raw2outputs_bwd(saved['raw0'], saved['z0'], rays11, g_c, saved['noise0'], saved['white'])
     dact = _Workspace.dact(dev, ops.dact_floats(n * S0))
     ops.mlp_bwd(draw0, saved['act0'], net_c.flat, saved['pc'][1], dact, partial, out_c)
-    if gtmp is not None:
-        out_c.add_(gtmp)
+    out_c.add_(gtmp)
 
 
 def _grad_views(flat):

@@ -161,6 +161,17 @@ int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples, int N_impo
                              float* depth0, float* z1, float* z_samples, float* z_std, float* raw1, float* act1,
                              float* rgb1, float* disp1, float* acc1, float* w1, float* depth1, fn_stream_t stream);
 
+/* Backward of the same chain w.r.t. the network parameters (what loss.backward() does for this path,
+ * run_nerf.py:493): fine pass into grads_f, coarse pass into grads_c (sample positions are detached, so the coarse net
+ * only sees g_rgb0).  Two distinct nets when N_importance > 0.  draw_ws: n*(N_samples+N_importance)*4 floats;
+ * dact_ws / partial_ws as for the mlp_bwd entry points. */
+int fastnerf_render_rays_bwd(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11, int white_bkgd,
+                             const float* g_rgb, const float* g_rgb0, const float* noise0, const float* noise1,
+                             const float* z0, const float* raw0, const float* act0, const float* z1, const float* raw1,
+                             const float* act1, const float* params_c, const float* packed_bwd_c, const float* params_f,
+                             const float* packed_bwd_f, float* draw_ws, float* dact_ws, float* partial_ws, float* grads_c,
+                             float* grads_f, fn_stream_t stream);
+
 /* ---- nerf++-ours additions ------------------------------------------- */
 /* get_rays_single_image (nerf_sample_ray_split.py:10-34): intrinsics_host / c2w_host are 4x4 row-major
  * doubles; rays_o / rays_d [H*W,3]. */
