@@ -81,6 +81,7 @@ def main():
     from oracle import nerf_oracle as O
     rank, world, local = parallel.init_from_env('cuda')
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    local = local % max(1, torch.cuda.device_count())   # (only differs in single-GPU plumbing tests of the N>1 path)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 

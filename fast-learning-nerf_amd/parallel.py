@@ -24,8 +24,10 @@ def init_from_env(device_type=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         use_cuda = torch.cuda.is_available() if device_type is None else device_type == 'cuda'
         if use_cuda:
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend='nccl' if use_cuda else 'gloo', rank=rk, world_size=world)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        # FASTNERF_DIST_BACKEND=gloo: plumbing tests of the multi-process path on a box with fewer GPUs than ranks
+        backend = os.environ.get('FASTNERF_DIST_BACKEND', 'nccl' if use_cuda else 'gloo')
+        dist.init_process_group(backend=backend, rank=rk, world_size=world)
     return rk, world, local
 
 

@@ -1,0 +1,29 @@
+"""The N>1 path of bench.py end to end on the GPU: two ranks launched exactly as the driver launches them (torch.distributed.run,
+127.0.0.1 rendezvous), sharded rays, gradient all-reduce, barrier-bracketed timing, rank-0 JSON.  On a 1-GPU box the two
+ranks share the device and the collective backend is gloo (FASTNERF_DIST_BACKEND); on a multi-GPU box this is RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks():
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env['FASTNERF_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly one JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == 'weak' and j['value'] > 0
+    assert j['config']['parallelism'] == 'dp2' and j['cpu_baseline'] is None
+    assert all(abs(x) < 1.0 for x in j['final_loss'])
