@@ -8,7 +8,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libfastnerf.so')
+LIB_PATH = os.environ.get('FASTNERF_LIB') or os.path.join(HERE, 'libfastnerf.so')   # FASTNERF_LIB: tuning builds
 
 P = C.c_void_p
 I = C.c_int

@@ -27,15 +27,19 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
+    if not force and not _stale() and not os.environ.get('FASTNERF_VARIANT'):
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     extra = os.environ.get('FASTNERF_CFLAGS', '').split()   # tuning experiments, e.g. -DTM=128
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    variant = os.environ.get('FASTNERF_VARIANT')   # tuning builds: variants/<name>.so, loaded with FASTNERF_LIB=...
+    bdir = os.path.join(HERE, 'build', variant) if variant else os.path.join(HERE, 'build')
+    lib = os.path.join(HERE, 'variants', variant + '.so') if variant else LIB
+    os.makedirs(bdir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, 'build', src + '.o')
+        obj = os.path.join(bdir, src + '.o')
         objs.append(obj)
         cmd = [hipcc] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
@@ -46,12 +50,12 @@ def build(force=False, verbose=False):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f'hipcc failed on {src}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         sys.stderr.write(r.stdout.decode())
         raise RuntimeError('link failed')
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':

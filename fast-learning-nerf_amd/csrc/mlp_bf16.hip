@@ -37,8 +37,31 @@ typedef unsigned long long u64;
 #ifndef DW_CFG
 #define DW_CFG 2, 2, 4, 4
 #endif
+#ifndef BF_PRIO
+#define BF_PRIO 1   // s_setprio level of a wave inside the k-loops (0: none); +1..2 % with two workgroups per CU
+#endif
+#ifndef BF_PRE_FWD
+#define BF_PRE_FWD 0   // forward: next layer's first weight fragments loaded ahead of the epilogue (measured -1 %: spills)
+#endif
+#ifndef BF_PRE_DX
+#define BF_PRE_DX 1    // dX: same (measured +1 %)
+#endif
+#ifndef BF_PF
+#define BF_PF 2   // weight fragments two k-steps ahead in the fwd / dX k-loops (1: one ahead)
+#endif
 #define BTM 64
 #define BNTHR 256
+#ifdef BF_TRACE   // tuning builds only: per-wave s_memtime stamps of the forward's phases (tools/trace_fwd.py)
+#define TR_NEV 40
+#define TR_NBLK 512
+__device__ long long g_trace[TR_NBLK * 4 * TR_NEV];
+#define TR(e) do { if (trace_on && lane == 0) g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + (e)] = clock64(); } while (0)
+extern "C" int fastnerf_debug_trace(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(long long) * n);
+}
+#else
+#define TR(e)
+#endif
 #define BLDS_BYTES (2 * BTM * 256 * 2 + 2 * BTM * 64 * 2)   // 81920
 
 static int b_num_cus() {
@@ -226,11 +249,29 @@ __device__ __forceinline__ f32x16 bmfma(const uint4& a, const uint4& b, f32x16 c
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Weight fragments of the first two k-steps of the NEXT k-loop, loaded before the epilogue in front of it: the
+// epilogue's global stores (saved tensors) are then YOUNGER than these loads, so the k-loop's first vmcnt waits do
+// not have to drain them (vmcnt retires in order; a k-loop that starts behind 16 KiB of stores per wave measured
+// +30 %: 11.5 k vs 8.9 k ticks, tools/trace_fwd.py).
+template <int NT>
+struct BPre { uint4 h0[NT], l0[NT], h1[NT], l1[NT]; };
+template <int NT>
+__device__ __forceinline__ void bprefetch(BPre<NT>& p, const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const uint4* q = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128 + lane;
+    p.h0[nt] = q[0]; p.l0[nt] = q[64]; p.h1[nt] = q[128]; p.l1[nt] = q[192];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // accumulate nks (even) k-steps of 16.  A planes in LDS (H layout or E layout); B packed in global.
+// PRE: the fragments of k-steps 0 and 1 are already in *pre (needs nks >= 4).
 // AMODE: 0 = H planes, 1 = E planes, 2 = X2 block (pass Ahi = Hhi + X2_HI_OFF, Alo = Hhi + X2_LO_OFF)
-template <int NT, int AMODE>
+template <int NT, int AMODE, bool PRE = false>
 __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, const char* Alo, int a_ks0, int nks,
-                                      const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane) {
+                                      const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane,
+                                      const BPre<NT>* pre = nullptr) {
   asm volatile("" : "+v"(lane));
   const int lrow = lane & 31, kb = lane >> 5;
   auto aoff = [&](int mt, int ks) {
@@ -268,11 +309,20 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bmfma(al[mt], bh[nt], acc[mt][nt]);
   };
   uint4 ah0[2], al0[2], ah1[2], al1[2], bh0[NT], bl0[NT], bh1[NT], bl1[NT];
+#if BF_PRIO
+  __builtin_amdgcn_s_setprio(BF_PRIO);
+#endif
 #if BF_PF == 2
   // weights two k-steps ahead (four register sets), activations one ahead; nks % 4 == 0 except the 2-step segments
   if (nks >= 4) {
     uint4 bh2[NT], bl2[NT], bh3[NT], bl3[NT];
-    ldB(bh0, bl0, 0); ldB(bh1, bl1, 1); ldA(ah0, al0, 0);
+    if (PRE) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { bh0[nt] = pre->h0[nt]; bl0[nt] = pre->l0[nt]; bh1[nt] = pre->h1[nt]; bl1[nt] = pre->l1[nt]; }
+    } else {
+      ldB(bh0, bl0, 0); ldB(bh1, bl1, 1);
+    }
+    ldA(ah0, al0, 0);
 #pragma unroll 1
     for (int ks = 0; ks < nks; ks += 4) {
       ldB(bh2, bl2, ks + 2); ldA(ah1, al1, ks + 1);
@@ -285,6 +335,9 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
       if (ks + 4 < nks) { ldB(bh1, bl1, ks + 5); ldA(ah0, al0, ks + 4); }
       mm(ah1, al1, bh3, bl3);
     }
+#if BF_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return;
   }
 #endif
@@ -296,6 +349,9 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
     if (ks + 2 < nks) { ldB(bh0, bl0, ks + 2); ldA(ah0, al0, ks + 2); }
     mm(ah1, al1, bh1, bl1);
   }
+#if BF_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 template <int NT>
@@ -312,9 +368,6 @@ __device__ __forceinline__ void bzero(f32x16 (&acc)[2][NT]) {
 // C layout of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int bcrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-#ifndef BF_PF
-#define BF_PF 2   // weight fragments two k-steps ahead in the fwd / dX k-loops (1: one ahead)
-#endif
 #ifndef BF_NT
 #define BF_NT 1   // non-temporal stores for the saved tensors (streamed once, read by dW much later)
 #endif
@@ -330,6 +383,9 @@ __device__ __forceinline__ void gstore8(uint2* p, const uint2& v) {   // 8-byte 
 #define BF_W16 1
 #endif
 __device__ __forceinline__ void gstore16(uint4* p, const uint4& v) {
+#ifdef BF_ABL_NOSTORE   // ablation builds (tools/trace_fwd.py): what do the saved-tensor stores cost the k-loop?
+  if (v.x != 0x12345678u) return;
+#endif
 #if BF_NT
   typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
   const u32x4s t = {v.x, v.y, v.z, v.w};
@@ -347,7 +403,23 @@ struct EpiArgs {
   void* mask_out;             // MOUT: where this tile's sign bits go
   uint2* gsave;               // GSAVE: K-fragment tensor, already offset to the tile
   const int* hofs;            // optional: this lane's 16 precomputed LDS offsets hoff(bcrow(r), slot) + inslot (rows mt = 0)
+  // this lane's bias / rank-1 weights / sign words, loaded by bepi*_preload BEFORE the k-loop so that their
+  // latency is not paid at the head of the epilogue
+  float r_b0, r_b1, r_wa0, r_wa1;
+  uint2 r_min2;
 };
+template <bool BIAS, bool MASK, bool RANK1>
+__device__ __forceinline__ void bepi256_preload(EpiArgs& ea, int wn, int lane) {
+  const int n0 = wn * 64 + 2 * (lane & 31);
+  if (BIAS) { ea.r_b0 = ea.bias[n0]; ea.r_b1 = ea.bias[n0 + 1]; }
+  if (RANK1) { ea.r_wa0 = ea.wa[n0]; ea.r_wa1 = ea.wa[n0 + 1]; }
+  if (MASK) ea.r_min2 = reinterpret_cast<const uint2*>(ea.mask_in)[wn * 64 + lane];
+}
+template <bool BIAS, bool MASK>
+__device__ __forceinline__ void bepi128_preload(EpiArgs& ea, int wn, int lane) {
+  if (BIAS) ea.r_b0 = ea.bias[wn * 32 + (lane & 31)];
+  if (MASK) ea.r_min2.x = reinterpret_cast<const unsigned*>(ea.mask_in)[wn * 64 + lane];
+}
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -386,10 +458,10 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
   const int j = lane & 31, half = lane >> 5;
   const int n0 = wn * 64 + 2 * j;
   float b0 = 0.f, b1 = 0.f, wa0 = 0.f, wa1 = 0.f;
-  if (BIAS) { b0 = ea.bias[n0]; b1 = ea.bias[n0 + 1]; }
-  if (RANK1) { wa0 = ea.wa[n0]; wa1 = ea.wa[n0 + 1]; }
+  if (BIAS) { b0 = ea.r_b0; b1 = ea.r_b1; }
+  if (RANK1) { wa0 = ea.r_wa0; wa1 = ea.r_wa1; }
   uint2 min2 = make_uint2(0u, 0u), mout2 = make_uint2(0u, 0u);
-  if (MASK) min2 = reinterpret_cast<const uint2*>(ea.mask_in)[wn * 64 + lane];
+  if (MASK) min2 = ea.r_min2;
   const int slot = n0 >> 3, inslot = (n0 & 7) * 2;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -470,9 +542,9 @@ __device__ __forceinline__ void bepi128(const f32x16 (&acc)[2][1], const EpiArgs
   asm volatile("" : "+v"(lane));
   const int j = lane & 31, half = lane >> 5;
   const int n = wn * 32 + j;
-  const float bv = BIAS ? ea.bias[n] : 0.f;
+  const float bv = BIAS ? ea.r_b0 : 0.f;
   unsigned mi = 0u, mo = 0u;
-  if (MASK) mi = reinterpret_cast<const unsigned*>(ea.mask_in)[wn * 64 + lane];
+  if (MASK) mi = ea.r_min2.x;
   const int slot = n >> 3, inslot = (n & 7) * 2;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -576,6 +648,15 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     if (pp >= P) pp = P - 1;
     const int64_t ray = pp / S;
     const float* rr = rays + ray * 11;
+#ifdef BF_TRACE
+    const bool trace_on = blockIdx.x < TR_NBLK && tile == (int64_t)blockIdx.x + 4 * (int64_t)gridDim.x;
+    TR(0);
+    if (trace_on && lane == 0) {
+      g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 38] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+      g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 39] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
+      g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 36] = wall_clock64();                      // 100 MHz
+    }
+#endif
     // store one PE channel at row pm: E planes (c < 64) or the X2 block (c >= 64), and (SAVE, stage) the K-fragment
     // staging copy that aliases the head of H
     auto est = [&](int c, float v, bool stage = true) {
@@ -643,7 +724,11 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     f32x16 acc[2][2];
     EpiArgs ea{};
     ea.hofs = hofs;
+    constexpr bool PRE = !BG && (BF_PF == 2) && BF_PRE_FWD;   // (the background variant has no registers to spare)
+    BPre<2> pre;
     // L0
+    ea.bias = params + lay.LB[0];
+    bepi256_preload<true, false, false>(ea, wn, lane);
     bzero<2>(acc);
     if (!BG) {
       bgemm<2, 1>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 4, 0, wn * 2, lane);
@@ -652,20 +737,23 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       bgemm<2, 2>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, pk + boff.off[0], 6, 4, wn * 2, lane);
     }
     if (SAVE || BG) __syncthreads();   // staging copy / X2 block read out before H is written
-    ea.bias = params + lay.LB[0];
     if (SAVE) {
       ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, 0) + tile * 4096);
       ea.mask_out = maskw_all + (tile * 8 + 0) * 256;
     }
+    if (PRE) bprefetch<2>(pre, pk + boff.off[1], 16, 0, wn * 2, lane);
     bepi256<true, true, false, false, SAVE, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
+      TR(4 * l);
+      ea.bias = params + lay.LB[l];
+      bepi256_preload<true, false, false>(ea, wn, lane);
       bzero<2>(acc);
       const uint4* B = pk + boff.off[l];
       if (l == 5) {
         if (!BG) {
-          bgemm<2, 1>(acc, Ehi, Elo, 0, 4, B, 20, 0, wn * 2, lane);
+          bgemm<2, 1, PRE>(acc, Ehi, Elo, 0, 4, B, 20, 0, wn * 2, lane, &pre);
           bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 20, 4, wn * 2, lane);
         } else {
           bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 22, 6, wn * 2, lane);
@@ -676,17 +764,24 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
           bgemm<2, 2>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, B, 22, 4, wn * 2, lane);
         }
       } else {
-        bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane);
+        bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane, &pre);
       }
+      TR(4 * l + 1);
       __syncthreads();
-      ea.bias = params + lay.LB[l];
+      TR(4 * l + 2);
       if (SAVE) {
         ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, l) + tile * 4096);
         ea.mask_out = maskw_all + (tile * 8 + l) * 256;
       }
+      if (PRE) {   // layer l + 1 (layer 5 starts with its skip-input segment), after layer 7 the feature layer
+        const int ln = l + 1;
+        bprefetch<2>(pre, pk + boff.off[ln], ln == 5 ? 20 : 16, 0, wn * 2, lane);
+      }
       bepi256<true, true, false, false, SAVE, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
+      TR(4 * l + 3);
       __syncthreads();
     }
+    TR(32);
     // alpha head + view-direction encoding
     float alpha_val;
     {
@@ -730,22 +825,27 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         estv(6 + 6 * k + dim, cosf(a));
       }
     }
+    TR(33);
     // feature layer (no ReLU)
-    bzero<2>(acc);
-    bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane);
-    __syncthreads();
     ea.bias = params + lay.FB;
+    bepi256_preload<true, false, false>(ea, wn, lane);
+    bzero<2>(acc);
+    bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane, &pre);
+    __syncthreads();
     if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(ntiles) + tile * 4096);
+    BPre<1> prev;
+    if (PRE) bprefetch<1>(prev, pk + boff.off[9], 18, 0, wn, lane);
     bepi256<true, false, false, false, false, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // view layer: [feat256 | vpe32] -> 128, ReLU
     {
       f32x16 av[2][1];
+      ea.bias = params + lay.VB;
+      bepi128_preload<true, false>(ea, wn, lane);
       bzero<1>(av);
-      bgemm<1, 0>(av, Hhi, Hlo, 0, 16, pk + boff.off[9], 18, 0, wn, lane);
+      bgemm<1, 0, PRE>(av, Hhi, Hlo, 0, 16, pk + boff.off[9], 18, 0, wn, lane, &prev);
       bgemm<1, 1>(av, Ehi, Elo, 0, 2, pk + boff.off[9], 18, 16, wn, lane);
       __syncthreads();
-      ea.bias = params + lay.VB;
       if (SAVE) {
         ea.gsave = reinterpret_cast<uint2*>(act + ba_hv(ntiles) + tile * 2048);
         ea.mask_out = maskv_all + tile * 256;
@@ -779,6 +879,10 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
       }
     }
+    TR(34);
+#ifdef BF_TRACE
+    if (trace_on && lane == 0) g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 37] = wall_clock64();
+#endif
     __syncthreads();
   }
 }
@@ -794,6 +898,9 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
   const int64_t P = n * S;
   const int64_t ntiles = (P + BTM - 1) / BTM;
   int grid = b_num_cus() * 2;
+#ifdef BF_TRACE
+  if (getenv("BF_ONE_WG")) grid = b_num_cus();
+#endif
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {
@@ -859,12 +966,17 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     __syncthreads();
     EpiArgs ea{};
     ea.hofs = hofs;
+    constexpr bool PRE = (BF_PF == 2) && BF_PRE_DX;
+    BPre<2> pre;
     // ---- dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] ---------------------------------------------------
     {
       f32x16 av[2][1];
       const int n = wn * 32 + (lane & 31);
       const float* wr = params + lay.RW;
       const float w0 = wr[n], w1 = wr[128 + n], w2 = wr[256 + n];
+      ea.mask_in = maskv_all + tile * 256;
+      bepi128_preload<false, true>(ea, wn, lane);
+      if (PRE) bprefetch<2>(pre, pkt + boff.off[0], 8, 0, wn * 2, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -872,7 +984,6 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
           const float4 d = *reinterpret_cast<const float4*>(Dr + (mt * 32 + bcrow(r, lane)) * 4);
           av[mt][0][r] = fmaf(d.z, w2, fmaf(d.y, w1, d.x * w0));
         }
-      ea.mask_in = maskv_all + tile * 256;
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_yv(ntiles) + tile * 2048);
       bepi128<false, false, true, false, true>(av, ea, Hhi, Hlo, wn, lane);
     }
@@ -880,29 +991,34 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     f32x16 acc[2][2];
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ----------------------------------------------------------
     bzero<2>(acc);
-    bgemm<2, 0>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane);
+    bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane, &pre);
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(ntiles) + tile * 4096);
+    if (PRE) bprefetch<2>(pre, pkt + boff.off[1], 16, 0, wn * 2, lane);
     bepi256<false, false, false, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ---------------------------------------------------
-    bzero<2>(acc);
-    bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane);
-    __syncthreads();
-    ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, 7) + tile * 4096);
     ea.mask_in = maskw_all + (tile * 8 + 7) * 256;
     ea.dalpha4 = Dr;
     ea.wa = params + lay.AW;
+    bepi256_preload<false, true, true>(ea, wn, lane);
+    bzero<2>(acc);
+    bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane, &pre);
+    __syncthreads();
+    ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, 7) + tile * 4096);
+    if (PRE) bprefetch<2>(pre, pkt + boff.off[2], 16, 0, wn * 2, lane);
     bepi256<false, false, true, true, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY_{l-1} = (dY_l . W_l[:, h part]) * [h_{l-1} > 0],  l = 7..1 ---------------------------------
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
+      ea.mask_in = maskw_all + (tile * 8 + (l - 1)) * 256;
+      bepi256_preload<false, true, false>(ea, wn, lane);
       bzero<2>(acc);
-      bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane);
+      bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane, &pre);
       __syncthreads();
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, l - 1) + tile * 4096);
-      ea.mask_in = maskw_all + (tile * 8 + (l - 1)) * 256;
+      if (PRE && l > 1) bprefetch<2>(pre, pkt + boff.off[10 - l], 16, 0, wn * 2, lane);
       bepi256<false, false, true, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
       __syncthreads();
     }
