@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(512, 1) k(long long* out, int it_m, int it_v, 
   unsigned c = threadIdx.x | 0x3f800000u;
   __syncthreads();
   const long long t0 = clock64();
-  if ((w < 4) != (swap != 0)) {
+  if (swap != 2 && (w < 4) != (swap != 0)) {
     for (int it = 0; it < it_m; ++it) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -68,8 +68,8 @@ void run(long long* out, long long* h, int it_m, int it_v, int swap, int sw, dou
   (void)hipDeviceSynchronize();
   (void)hipMemcpy(h, out, 256 * 8 * 2 * 8, hipMemcpyDeviceToHost);
   tm = tv = 0;
-  for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) (((w < 4) != (swap != 0)) ? tm : tv) += (double)h[(b * 8 + w) * 2];
-  tm /= 1024; tv /= 1024;
+  for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) ((swap != 2 && (w < 4) != (swap != 0)) ? tm : tv) += (double)h[(b * 8 + w) * 2];
+  tm /= 1024; tv /= (swap == 2 ? 2048 : 1024);
 }
 
 template <int KIND>
@@ -87,7 +87,9 @@ void all(long long* out, long long* h) {
     printf(" %s: %5.1f clk/MFMA, partner VALU per MFMA %5.2f |", swap ? "VALU older" : "matrix older", tm / NM, during / (tv > tm ? NM : NM * tv / tm));
   }
   run<KIND>(out, h, M, 0, 0, 1, tm, d);
-  printf(" same wave 16/MFMA: +%5.2f clk/VALU\n", (tm / NM - tm0 / NM) / 16);
+  printf(" same wave 16/MFMA: +%5.2f clk/VALU |", (tm / NM - tm0 / NM) / 16);
+  run<KIND>(out, h, 0, V, 2, 0, d, tv);   // swap == 2: BOTH waves of a SIMD run the VALU stream
+  printf(" two VALU waves: %5.2f clk/VALU each\n", tv / NV);
 }
 
 int main() {

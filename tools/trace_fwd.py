@@ -29,7 +29,9 @@ l.fastnerf_debug_trace.restype = C.c_int
 l.fastnerf_debug_trace.argtypes = [C.c_void_p, C.c_int]
 rc = l.fastnerf_debug_trace(buf.ctypes.data, buf.size)
 assert rc == 0, rc
-t = buf.reshape(NBLK, 4, NEV)
+W = int(os.environ.get('TR_WAVES', '8'))   # waves per workgroup: 8 (128-point kernel) or 4 (BF_T128=0 builds)
+NBLK = 2048 // W
+t = buf.reshape(NBLK, W, NEV)
 os.makedirs('gpurun_out', exist_ok=True)
 np.save('gpurun_out/trace_%s%s.npy' % ('save' if save else 'inf', '_1wg' if os.environ.get('BF_ONE_WG') else ''), t)
 ev = t[:, :, :36].astype(np.float64)
@@ -47,23 +49,25 @@ print('whole tile: mean %.0f   layers 1..7: %.0f   PE+L0: %.0f   heads+feature+v
 wall = (t[:, :, 37] - t[:, :, 36]).astype(np.float64)
 m = wall > 0
 print('shader clock during the traced tile: %.3f GHz (s_memtime ticks per 10 ns wall tick / 10)' % ((tile[m] / wall[m]).mean() / 10))
-# pair the workgroups by CU
-hw = t[:, 0, 38]; xcc = t[:, 0, 39] & 15
-cu = (hw >> 8) & 15; se = (hw >> 13) & 7; sh = (hw >> 12) & 1
-key = xcc * 1000 + se * 100 + sh * 50 + cu
-pairs = {}
-for b in range(NBLK):
-    pairs.setdefault(int(key[b]), []).append(b)
-sizes = np.bincount([len(v) for v in pairs.values()])
-print('workgroups per CU key histogram', sizes)
-# phase offset: start of layer-3 k-loop of WG a vs WG b on the same CU, modulo the layer period
-offs = []
-for v in pairs.values():
-    if len(v) == 2:
-        a, b = v
-        per = (ev[a, 0, 16] - ev[a, 0, 12])
-        d = (ev[b, 0, 12] - ev[a, 0, 12]) % per
-        offs.append(d / per)
-offs = np.array(offs)
-print('pairs %d: phase offset of the second WG within the first one\'s layer period: histogram (10 bins)' % len(offs), np.histogram(offs, bins=10, range=(0, 1))[0])
-print('example WG 0 wave 0 stamps (relative):', (ev[0, 0, :36] - ev[0, 0, 0]).astype(np.int64))
+if W == 4:
+    # pair the workgroups by CU
+    hw = t[:, 0, 38]; xcc = t[:, 0, 39] & 15
+    cu = (hw >> 8) & 15; se = (hw >> 13) & 7; sh = (hw >> 12) & 1
+    key = xcc * 1000 + se * 100 + sh * 50 + cu
+    pairs = {}
+    for b in range(NBLK):
+        pairs.setdefault(int(key[b]), []).append(b)
+    sizes = np.bincount([len(v) for v in pairs.values()])
+    print('workgroups per CU key histogram', sizes)
+    # phase offset: start of layer-3 k-loop of WG a vs WG b on the same CU, modulo the layer period
+    offs = []
+    for v in pairs.values():
+        if len(v) == 2:
+            a, b = v
+            per = (ev[a, 0, 16] - ev[a, 0, 12])
+            d = (ev[b, 0, 12] - ev[a, 0, 12]) % per
+            offs.append(d / per)
+    offs = np.array(offs)
+    print('pairs %d: phase offset of the second WG within the first one\'s layer period: histogram (10 bins)' % len(offs), np.histogram(offs, bins=10, range=(0, 1))[0])
+    print('example WG 0 wave 0 stamps (relative):', (ev[0, 0, :36] - ev[0, 0, 0]).astype(np.int64))
+
