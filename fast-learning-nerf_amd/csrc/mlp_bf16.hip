@@ -34,6 +34,9 @@ typedef unsigned long long u64;
 #ifndef DW_NST
 #define DW_NST 3   // LDS stages of the dW operand ring (DW_NST - 1 k-steps prefetched)
 #endif
+#ifndef DW_AUX
+#define DW_AUX 2   // cache-policy bits of the dW operand DMA (saved tensors are read exactly once)
+#endif
 #ifndef DW_CFG
 #define DW_CFG 2, 2, 4, 4
 #endif
@@ -1151,7 +1154,7 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
         const uint4* src = (ct < CTO) ? dY + ((tile * CTO + ct) * 4 + ks) * 128 + half * 64 + lane
                                       : X + ((tile * CTI + (ct - CTO)) * 4 + ks) * 128 + half * 64 + lane;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, DW_AUX);
       }
     }
   };
