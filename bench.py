@@ -167,6 +167,12 @@ def main():
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01_pmc_traffic.json)',
                 'avg_launch_ms': ms, 'flop_per_launch': flops, 'mfma_tflops_issued': (3.0 if split else 1.0) * achieved,
                 'hbm_write_GBps': (ops.act_floats(P) * 4 / (ms * 1e-3) / 1e9)}
+        if split:
+            # tools/micro/mfma_power.hip on the bench box: a saturated v_mfma_f32_32x32x16_bf16 stream (32.0 clk per
+            # MFMA and SIMD) holds 2.24-2.38 GHz on constant operands but only 1.79 GHz = 1871 TFLOP/s on uniform(-1,1)
+            # bf16 data (power management); the kernel itself runs at 1.67 GHz (profiles/r01_sq_counters.md)
+            roof['peak_measured_real_data'] = 1871.0 / 3.0
+            roof['frac_of_measured_peak'] = achieved / (1871.0 / 3.0)
         del act
 
     # ---- the same step in the exact-fp32 math mode, for reference (1 GPU only; not `value`) ----------------------
