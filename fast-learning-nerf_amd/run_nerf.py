@@ -256,6 +256,9 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
     dev = torch.device(device)
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
     kw_train, kw_test, start_epoch, global_iter, grad_vars, optimizer = create_nerf(args, device=dev)
+    bds_dict = {'near': near, 'far': far}   # run_nerf.py:267-272: the bounds travel in both kwargs dicts
+    kw_train.update(bds_dict)
+    kw_test.update(bds_dict)
     trainer = Trainer(kw_train, H, W, K, near, far, lrate=args.lrate, lrate_decay=args.lrate_decay)
     trainer.global_iter = global_iter
     if len(optimizer.state_dict()['state']) > 0:   # create_nerf restored a checkpoint (ours or the reference's)
