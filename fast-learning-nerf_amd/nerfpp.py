@@ -205,6 +205,43 @@ def sample_pdf(bins, weights, N_samples, det=False):
     raise NotImplementedError('use ops.pp_sample_pdf_merge (sampler + sort-merge in one kernel)')
 
 
+def render_single_image(models, ray_sampler, chunk_size):
+    """ddp_test_nerf.py:126-227: one whole image through every cascade level with deterministic depths (uniform
+    foreground steps from `min_depth` to the unit sphere, uniform inverse-depth background steps, `sample_pdf(det=True)`
+    + sort-merge for the finer levels), in chunks of `chunk_size` rays.  `models` = {'cascade_level', 'cascade_samples',
+    'net_<m>'}; `ray_sampler` has H, W and get_all() -> {'ray_o', 'ray_d', 'min_depth', ...} ([H*W, .] tensors).
+    Returns one OrderedDict per level with every output of NerfNet.forward except the weights, reshaped to [H, W, -1]
+    on the host, like the reference."""
+    ray_batch = ray_sampler.get_all()
+    dev = models['net_0'].nerf_net.flat.device if hasattr(models['net_0'], 'nerf_net') else models['net_0'].flat.device
+    ro_all, rd_all, md_all = (torch.as_tensor(ray_batch[k]).to(dev).float() for k in ('ray_o', 'ray_d', 'min_depth'))
+    levels = models['cascade_level']
+    merged = [OrderedDict() for _ in range(levels)]
+    with torch.no_grad():
+        for s in range(0, ro_all.shape[0], chunk_size):
+            ray_o, ray_d, fg_near = ro_all[s:s + chunk_size], rd_all[s:s + chunk_size], md_all[s:s + chunk_size]
+            fg_far = intersect_sphere(ray_o, ray_d)
+            ret = fg_z = bg_z = None
+            for m in range(levels):
+                net = models['net_{}'.format(m)]
+                N = models['cascade_samples'][m]
+                if m == 0:
+                    step = (fg_far - fg_near) / (N - 1)
+                    fg_z = torch.stack([fg_near + i * step for i in range(N)], dim=-1)          # :150-153
+                    bg_z = torch.linspace(0., 1., N, device=dev).expand(ray_o.shape[0], N).contiguous()
+                else:
+                    fg_z, _ = ops.pp_sample_pdf_merge(fg_z, ret['fg_weights'].contiguous(), N, det=True)   # :164-178
+                    bg_z, _ = ops.pp_sample_pdf_merge(bg_z, ret['bg_weights'].contiguous(), N, det=True)
+                ret = net(ray_o, ray_d, fg_far, fg_z, bg_z)
+                for key, val in ret.items():
+                    if key not in ('fg_weights', 'bg_weights') and torch.is_tensor(val):
+                        merged[m].setdefault(key, []).append(val.cpu())
+    for m in range(levels):
+        for key in merged[m]:
+            merged[m][key] = torch.cat(merged[m][key], dim=0).reshape(ray_sampler.H, ray_sampler.W, -1)
+    return merged
+
+
 class CascadeTrainer:
     """Fused train_step batch of ddp_train_nerf.py:347-404 over `cascade_samples` levels, each level
     with its own net + Adam (no LR decay in this fork), gradients all-reduced when world_size > 1."""
