@@ -43,6 +43,9 @@ typedef unsigned long long u64;
 #ifndef BF_PRIO
 #define BF_PRIO 1   // s_setprio level of a wave inside the k-loops (0: none); +1..2 % with two workgroups per CU
 #endif
+#ifndef BF_BUFLD
+#define BF_BUFLD 1   // weight fragments via buffer_load_dwordx4 (scalar offsets) instead of 64-bit vector pointers
+#endif
 #ifndef BF_PRE_FWD
 #define BF_PRE_FWD 0   // forward: next layer's first weight fragments loaded ahead of the epilogue (measured -1 %: spills)
 #endif
@@ -277,14 +280,27 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
                                       const BPre<NT>* pre = nullptr) {
   asm volatile("" : "+v"(lane));
   const int lrow = lane & 31, kb = lane >> 5;
+  // slot ^ swz = (2K + kb) ^ swz = 2K ^ (kb ^ swz): the lane part (ysw, arow) is loop invariant, 2K is uniform, so a
+  // k-step's LDS offset costs one v_xor (SGPR operand) + one v_lshl_add; the row tile is an immediate offset
+  const int ysw = kb ^ (AMODE == 1 ? ((lrow >> 1) & 7) : (AMODE == 2 ? ((lrow >> 2) & 3) : (lrow & 15)));
+  const int arow = lrow * (AMODE == 1 ? 128 : (AMODE == 2 ? 64 : 512));
   auto aoff = [&](int mt, int ks) {
-    const int m = mt * 32 + lrow;
-    const int slot = (a_ks0 + ks) * 2 + kb;
-    return AMODE == 1 ? eoff(m, slot) : (AMODE == 2 ? x2off(m, slot) : hoff(m, slot));
+    return arow + (((2 * (a_ks0 + ks)) ^ ysw) << 4) + mt * (32 * (AMODE == 1 ? 128 : (AMODE == 2 ? 64 : 512)));
   };
+  // weight fragments through buffer loads: resource = this layer's packed block (uniform), VGPR offset = lane * 16
+  // (loop invariant), the (column tile, k-step, plane) part is a scalar offset -> no vector address arithmetic
+#if BF_BUFLD
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Bp), 0, 0x7fffffff, 0x00020000);
+  const int bvofs = lane * 16;
+  int bsofs[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsofs[nt] = ((nt0 + nt) * KS + b_ks0) * 2048;
+#else
   const uint4* bptr[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128 + lane;
+  for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128;
+  const unsigned blane = (unsigned)lane;
+#endif
   auto ldA = [&](uint4 (&ah)[2], uint4 (&al)[2], int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -295,7 +311,15 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
   };
   auto ldB = [&](uint4 (&bh)[NT], uint4 (&bl)[NT], int ks) __attribute__((always_inline)) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { bh[nt] = bptr[nt][ks * 128]; bl[nt] = bptr[nt][ks * 128 + 64]; }
+    for (int nt = 0; nt < NT; ++nt) {
+#if BF_BUFLD
+      typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+      bh[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048, 0));
+      bl[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048 + 1024, 0));
+#else
+      bh[nt] = (bptr[nt] + ks * 128)[blane]; bl[nt] = (bptr[nt] + ks * 128 + 64)[blane];
+#endif
+    }
   };
   auto mm = [&](const uint4 (&ah)[2], const uint4 (&al)[2], const uint4 (&bh)[NT], const uint4 (&bl)[NT]) __attribute__((always_inline)) {
 #pragma unroll
