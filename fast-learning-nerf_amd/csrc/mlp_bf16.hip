@@ -722,8 +722,10 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       for (int jj = pq; jj < 30; jj += 4) {
         const int k = jj / 3, dim = jj - 3 * k;
         const float a = fmul(x[dim], (float)(1 << k));
-        est(3 + 6 * k + dim, sinf(a));
-        est(6 + 6 * k + dim, cosf(a));
+        float sa_, ca_;
+        sincosf(a, &sa_, &ca_);   // one range reduction for the pair
+        est(3 + 6 * k + dim, sa_);
+        est(6 + 6 * k + dim, ca_);
       }
     } else {
       const int sidx = (int)(pp - ray * S);
@@ -735,8 +737,10 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const float a = fmul(xq, (float)(1 << k));
-        est(4 + 8 * k + pq, sinf(a));
-        est(8 + 8 * k + pq, cosf(a));
+        float sa_, ca_;
+        sincosf(a, &sa_, &ca_);
+        est(4 + 8 * k + pq, sa_);
+        est(8 + 8 * k + pq, ca_);
       }
       est(60 + pq, sinf(fmul(xq, 128.0f)));
       write_x2(true);
@@ -848,8 +852,10 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       for (int jj = pq; jj < 12; jj += 4) {
         const int k = jj / 3, dim = jj - 3 * k;
         const float a = fmul(v[dim], (float)(1 << k));
-        estv(3 + 6 * k + dim, sinf(a));
-        estv(6 + 6 * k + dim, cosf(a));
+        float sa_, ca_;
+        sincosf(a, &sa_, &ca_);
+        estv(3 + 6 * k + dim, sa_);
+        estv(6 + 6 * k + dim, ca_);
       }
     }
     TR(33);
