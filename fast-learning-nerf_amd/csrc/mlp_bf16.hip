@@ -7,7 +7,8 @@
 // the fp32-MFMA kernels of mlp.hip this moves raw network outputs by ~1e-6 relative and the rendered RGB by
 // 5e-7 (tools/bf16x3_study.py), i.e. fp32 rounding class -- two orders below the 1e-4 parity tolerance.
 //
-// Same network functions as mlp.hip (nerf-ours/model.py:37-63, nerf++-ours/nerf_network.py:70-142); kinds 0/1.
+// Same network functions as mlp.hip (nerf-ours/model.py:37-63, nerf++-ours/nerf_network.py:70-142); kinds 0/1 and the
+// nerf++ background net (kind 2: 4-D inverted-sphere input, 84-channel encoding).
 //
 // Tiling: 64-point tiles, two 256-thread workgroups per CU, wave = 64x64 output block (2x2 MFMA tiles).
 // LDS per workgroup: H as two bf16 planes [64][256] (hi, lo: 32 KiB each) + E planes [64][64] (8 KiB each).

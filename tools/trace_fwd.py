@@ -29,7 +29,7 @@ l.fastnerf_debug_trace.restype = C.c_int
 l.fastnerf_debug_trace.argtypes = [C.c_void_p, C.c_int]
 rc = l.fastnerf_debug_trace(buf.ctypes.data, buf.size)
 assert rc == 0, rc
-W = int(os.environ.get('TR_WAVES', '8'))   # waves per workgroup: 8 (128-point kernel) or 4 (BF_T128=0 builds)
+W = int(os.environ.get('TR_WAVES', '4'))   # waves per workgroup (8 with csrc/experimental/t128.patch applied)
 NBLK = 2048 // W
 t = buf.reshape(NBLK, W, NEV)
 os.makedirs('gpurun_out', exist_ok=True)
