@@ -247,6 +247,50 @@ class Trainer:
         self.adam_t, self.global_iter, self.lr = sd['adam_t'], sd['global_iter'], sd['lr']
 
 
+def load_dataset(args):
+    """The data-loading branch of the reference's train() (run_nerf.py:160-241) for the two dataset types on this path:
+    -> dict(images [n,H,W,3], poses [n,3,4], render_poses, hwf [H,W,focal], K, i_train, i_val, i_test, near, far).
+    `args` needs dataset_type, datadir and the matching options (blender: half_res, testskip, white_bkgd; llff: factor,
+    spherify, llffhold, no_ndc); render_test swaps the render poses for the test poses like the reference."""
+    K = None
+    if args.dataset_type == 'llff':
+        from .load_llff import load_llff_data
+        images, poses, bds, render_poses, i_test = load_llff_data(args.datadir, getattr(args, 'factor', 8), recenter=True,
+                                                                  bd_factor=.75, spherify=getattr(args, 'spherify', False))
+        hwf = poses[0, :3, -1]
+        poses = poses[:, :3, :4]
+        i_test = i_test if isinstance(i_test, list) else [i_test]
+        if getattr(args, 'llffhold', 8) > 0:
+            i_test = np.arange(images.shape[0])[::getattr(args, 'llffhold', 8)]
+        i_val = i_test
+        i_train = np.array([i for i in np.arange(int(images.shape[0])) if (i not in i_test and i not in i_val)])
+        if args.no_ndc:
+            near, far = np.ndarray.min(bds) * .9, np.ndarray.max(bds) * 1.
+        else:
+            near, far = 0., 1.
+    elif args.dataset_type == 'blender':
+        from .load_blender import load_blender_data
+        images, poses, render_poses, hwf, i_split = load_blender_data(args.datadir, getattr(args, 'half_res', False),
+                                                                      getattr(args, 'testskip', 8))
+        i_train, i_val, i_test = i_split
+        near, far = 2., 6.
+        if args.white_bkgd:
+            images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:])
+        else:
+            images = images[..., :3]
+        poses = poses[:, :3, :4]
+    else:
+        raise ValueError('Unknown dataset type {!r} (this build reads blender and llff)'.format(args.dataset_type))
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    if K is None:
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    if getattr(args, 'render_test', False):
+        render_poses = np.array(poses[i_test])
+    return dict(images=images, poses=poses, render_poses=render_poses, hwf=[H, W, focal], K=K, i_train=i_train, i_val=i_val,
+                i_test=i_test, near=near, far=far)
+
+
 def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=print, max_iters_per_epoch=None,
           compat_rng=False):
     """Epoch loop of run_nerf.py:train() (:337-546) on in-memory data: center-crop warm-up, per-epoch

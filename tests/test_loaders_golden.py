@@ -76,3 +76,29 @@ def test_llff_reader(g, loaders, tmp_path):
     # path_zflat: 60-view single-rotation path at z = -0.1 * close depth
     _, _, _, rp, _ = LL.load_llff_data(d, factor=2, path_zflat=True)
     assert rp.shape == (60, 3, 5)
+
+
+def test_load_dataset_branches(g, loaders, tmp_path):
+    """run_nerf.load_dataset = the data branch of the reference's train() (run_nerf.py:160-241)."""
+    import fastnerf
+    LB, LL = loaders
+    d = str(tmp_path / 'blender')
+    for split in ('train', 'val', 'test'):
+        os.makedirs(os.path.join(d, split))
+        imgs, mats = g['blender.%s.imgs' % split], g['blender.%s.mats' % split]
+        frames = []
+        for i in range(imgs.shape[0]):
+            PIL.fromarray(imgs[i], 'RGBA').save(os.path.join(d, split, 'r_%d.png' % i))
+            frames.append({'file_path': './%s/r_%d' % (split, i), 'transform_matrix': mats[i].tolist()})
+        json.dump({'camera_angle_x': float(g['blender.%s.angle' % split]), 'frames': frames},
+                  open(os.path.join(d, 'transforms_%s.json' % split), 'w'))
+    args = fastnerf.run_nerf.make_args(dataset_type='blender', datadir=d, half_res=False, testskip=1, white_bkgd=True)
+    ds = fastnerf.run_nerf.load_dataset(args)
+    rgba = g['blender.out1.imgs']
+    assert np.array_equal(ds['images'], rgba[..., :3] * rgba[..., -1:] + (1. - rgba[..., -1:]))
+    assert ds['poses'].shape == (12, 3, 4) and (ds['near'], ds['far']) == (2., 6.)
+    assert [len(ds[k]) for k in ('i_train', 'i_val', 'i_test')] == [3, 4, 5]
+    H, W, focal = ds['hwf']
+    assert (H, W) == (8, 6) and np.allclose(ds['K'], [[focal, 0, 3.], [0, focal, 4.], [0, 0, 1]])
+    with pytest.raises(ValueError):
+        fastnerf.run_nerf.load_dataset(fastnerf.run_nerf.make_args(dataset_type='deepvoxels', datadir=d))
