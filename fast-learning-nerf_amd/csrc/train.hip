@@ -100,7 +100,9 @@ extern "C" int fastnerf_mse_leafmax(int64_t n, const float* rgb, const float* rg
   FN_CHECK_ARG(n > 0 && rgb && target, "n>0 and non-null rgb/target");
   FN_CHECK_ARG(!(table && !leaf_tag) && (!table || max_leaves > 0), "table needs leaf_tag and max_leaves>0");
   if (loss2) FN_HIP(hipMemsetAsync(loss2, 0, 2 * sizeof(float), fn::S(stream)));
-  int64_t g = (n + 255) / 256;
+  // up to 64 k rays (every training batch) one workgroup does the whole reduction, so the reported losses are
+  // bit-reproducible like the parameters; beyond that the block sums meet in fp32 atomics (last-bit order dependent)
+  int64_t g = (n <= 65536) ? 1 : (n + 255) / 256;
   if (g > 1024) g = 1024;
   const float inv_count = (float)(1.0 / (3.0 * (double)n));
   const float gscale = (float)(2.0 / (3.0 * (double)n) * (double)grad_scale);
