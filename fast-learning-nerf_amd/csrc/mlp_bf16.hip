@@ -24,6 +24,7 @@
 // 256-channel tensors are stored in the wave-permuted channel order q = (n>>6)*64 + (n&1)*32 + ((n&63)>>1)
 // (then every store instruction writes 512 contiguous bytes); the final reduction un-permutes.
 #include <stdlib.h>
+#include <mutex>
 #include "common.h"
 #include "mlp_layout.h"
 
@@ -79,6 +80,46 @@ static int b_num_cus() {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
   if (n <= 0) n = 256;
   return n;
+}
+
+// Dynamic tile scheduling of the persistent forward / dX kernels: the two workgroups of a CU do not run at the same
+// speed (the first-dispatched one wins the arbitration: 198 k vs 243 k cycles per tile, tools/trace_fwd.py), so a static
+// round-robin leaves the slower half ~4 tiles behind at the end.  Every workgroup takes tile blockIdx.x first and then
+// draws tickets from a counter in global memory; the last workgroup to leave resets the counter pair, so a launch never
+// depends on host-side state (graph replay safe).  Concurrent launches (different streams) must not share a pair: the
+// host hands out pairs round-robin from a pool of BSCHED_SLOTS.
+#define BSCHED_SLOTS 64
+static unsigned* b_sched_pair() {
+  static unsigned* pool[16] = {};
+  static unsigned next[16] = {};
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!pool[dev]) {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, BSCHED_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, BSCHED_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    pool[dev] = p;
+  }
+  const unsigned k = next[dev]++ % BSCHED_SLOTS;
+  return pool[dev] + 2 * k;
+}
+// end of a tile: thread 0 draws the next ticket into the LDS word `slot` (a place nobody reads or writes around the
+// tile boundary), the tile's closing barrier publishes it
+__device__ __forceinline__ int64_t b_next_tile(unsigned* sched, volatile int* slot, int tid) {
+  if (tid == 0) *slot = (int)(atomicAdd(sched, 1u) + gridDim.x);
+  __syncthreads();
+  return (int64_t)__builtin_amdgcn_readfirstlane(*slot);
+}
+__device__ __forceinline__ void b_sched_exit(unsigned* sched, int tid) {
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(sched + 1, 1u) == gridDim.x - 1) {   // everybody else has drawn its last (failing) ticket
+      sched[0] = 0u; sched[1] = 0u;
+      __threadfence();
+    }
+  }
 }
 
 __device__ __forceinline__ unsigned bf16_rne(float v) {   // bits of bf16(v), round to nearest even
@@ -648,7 +689,7 @@ template <bool SAVE, bool BG>
 __global__ void __launch_bounds__(BNTHR, 2)
 mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                     const float* __restrict__ params, const uint4* __restrict__ pk, float* __restrict__ raw,
-                    uint4* __restrict__ act, NetLayout lay, BOff boff) {
+                    uint4* __restrict__ act, NetLayout lay, BOff boff, unsigned* __restrict__ sched) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   char* Hhi = bsm;
   char* Hlo = bsm + BTM * 512;
@@ -668,7 +709,12 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     for (int r = 0; r < 16; ++r) hofs[r] = hoff(bcrow(r, lane), n0 >> 3) + (n0 & 7) * 2;
   }
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // scheduler word: the last 8 bytes of the lo plane = columns >= 128 of row 63, which hold stale feature values at the end
+  // of a tile (the rgb head reads columns < 128) and are next written by the following tile's layer-0 epilogue, one
+  // barrier after every thread has read the word
+  volatile int* sched_word = reinterpret_cast<volatile int*>(bsm + 2 * BTM * 512 - 8);
+  int titer = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; ++titer) {
     const int64_t p0 = tile * BTM;
     const int valid = (int)((P - p0) < BTM ? (P - p0) : BTM);
     const int pm = tid >> 2, pq = tid & 3;
@@ -677,7 +723,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     const int64_t ray = pp / S;
     const float* rr = rays + ray * 11;
 #ifdef BF_TRACE
-    const bool trace_on = blockIdx.x < TR_NBLK && tile == (int64_t)blockIdx.x + 4 * (int64_t)gridDim.x;
+    const bool trace_on = blockIdx.x < TR_NBLK && titer == 4;
     TR(0);
     if (trace_on && lane == 0) {
       g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 38] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
@@ -917,8 +963,9 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
 #ifdef BF_TRACE
     if (trace_on && lane == 0) g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 37] = wall_clock64();
 #endif
-    __syncthreads();
+    tile = b_next_tile(sched, sched_word, tid);   // (contains the tile's closing barrier)
   }
+  b_sched_exit(sched, tid);
 }
 
 extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const float* z,
@@ -952,12 +999,14 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
   uint4* a4 = reinterpret_cast<uint4*>(act);
   const dim3 g(grid), b(BNTHR);
   hipStream_t st = fn::S(stream);
+  unsigned* sched = b_sched_pair();
+  FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   if (kind == 2) {
-    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
-    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
   } else {
-    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
-    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O);
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
   }
   FN_LAUNCH_CHECK();
   return 0;
@@ -969,11 +1018,12 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
 __global__ void __launch_bounds__(BNTHR, 2)
 mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* __restrict__ act,
                        const float* __restrict__ params, const uint4* __restrict__ pkt, uint4* __restrict__ dact,
-                       NetLayout lay, BOff boff) {
+                       NetLayout lay, BOff boff, unsigned* __restrict__ sched) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   char* Hhi = bsm;
   char* Hlo = bsm + BTM * 512;
   float* Dr = reinterpret_cast<float*>(bsm + 2 * BTM * 512);   // [64] float4: drgb, dalpha of the tile's rows
+  volatile int* sched_word = reinterpret_cast<volatile int*>(bsm + 2 * BTM * 512 + BTM * 16);   // behind Dr: nobody else's
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -988,7 +1038,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     for (int r = 0; r < 16; ++r) hofs[r] = hoff(bcrow(r, lane), n0 >> 3) + (n0 & 7) * 2;
   }
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = blockIdx.x; tile < ntiles;) {
     const int64_t p0 = tile * BTM;
     if (tid < BTM) {
       const int64_t p = p0 + tid;
@@ -1054,9 +1104,11 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, l - 1) + tile * 4096);
       if (PRE && l > 1) bprefetch<2>(pre, pkt + boff.off[10 - l], 16, 0, wn * 2, lane);
       bepi256<false, false, true, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
-      __syncthreads();
+      if (l > 1) __syncthreads();
     }
+    tile = b_next_tile(sched, sched_word, tid);   // (contains the tile's closing barrier)
   }
+  b_sched_exit(sched, tid);
 }
 
 // =========================================================================================
@@ -1389,8 +1441,10 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
                                hipFuncAttributeMaxDynamicSharedMemorySize, BLDS_BYTES));
     attr_done = true;
   }
+  unsigned* sched = b_sched_pair();
+  FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   hipLaunchKernelGGL(mlp_bwd_dx_bf16_kernel, dim3(grid), dim3(BNTHR), BLDS_BYTES, st, P, draw, act, params,
-                     reinterpret_cast<const uint4*>(packed_bwd), dact, L, OB);
+                     reinterpret_cast<const uint4*>(packed_bwd), dact, L, OB, sched);
   FN_LAUNCH_CHECK();
 
   int nwg = ncu;

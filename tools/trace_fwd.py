@@ -69,5 +69,8 @@ if W == 4:
             offs.append(d / per)
     offs = np.array(offs)
     print('pairs %d: phase offset of the second WG within the first one\'s layer period: histogram (10 bins)' % len(offs), np.histogram(offs, bins=10, range=(0, 1))[0])
+    half = NBLK // 2
+    print('whole tile, first-dispatched half of the grid (older workgroup of each CU): %.0f ticks; second half: %.0f' % (tile[:half].mean(), tile[half:].mean()))
+    print('tile start of the traced (5th) tile relative to the CU partner: second-half workgroups start %.0f ticks later on average' % (ev[half:, 0, 0] - ev[:half, 0, 0]).mean())
     print('example WG 0 wave 0 stamps (relative):', (ev[0, 0, :36] - ev[0, 0, 0]).astype(np.int64))
 
