@@ -257,3 +257,51 @@ def test_large_batch_consistency(fn, weights):
     assert d < 2e-5, d
     ga, gb = out['fp32'][1], out['bf16x3'][1]
     assert (ga - gb).abs().max().item() < 2e-2 * ga.abs().max().item()   # ReLU-mask-flip floor, DESIGN section 4
+
+
+def test_tile_scheduler_back_to_back_and_streams(fn, weights):
+    """The persistent forward / dX kernels draw their tiles from a self-resetting ticket counter (one counter pair per
+    launch from a pool): many launches of very different sizes, back to back and interleaved on two streams, must
+    reproduce the single-launch results bit for bit (a stale or shared counter would skip or repeat tiles)."""
+    old = fn.ops.get_math()
+    fn.ops.set_math('bf16x3')
+    try:
+        flat = flat_of(weights).cuda()
+        pf, pb = fn.ops.mlp_pack(flat)
+        gen = torch.Generator().manual_seed(5)
+        sizes = [(1, 1), (1, 63), (1, 64), (5, 13), (64, 64), (257, 192), (700, 100)]   # (rays, samples): 1 .. 70 000 points
+        cases = []
+        for n, S in sizes:
+            ro = torch.randn(n, 3, generator=gen) * 0.3
+            rd = torch.randn(n, 3, generator=gen)
+            rays = torch.from_numpy(O.make_ray_batch(ro, rd, 2.0, 6.0).numpy()).cuda()
+            z = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, -1).values.cuda()
+            cot = torch.randn(n, S, 4, generator=gen).cuda()
+            act = torch.empty(fn.ops.act_floats(n * S)).cuda()
+            raw = fn.ops.mlp_fwd(rays, z, flat, pf, act=act).clone()
+            dact = torch.empty(fn.ops.dact_floats(n * S)).cuda()
+            partial = torch.empty(fn.ops.mlp_bwd_partial_floats()).cuda()
+            grads = torch.zeros(fn.ops.NET_PARAMS).cuda()
+            fn.ops.mlp_bwd(cot, act, flat, pb, dact, partial, grads)
+            cases.append((rays, z, cot, raw, grads.clone()))
+        torch.cuda.synchronize()
+        order = torch.randint(0, len(cases), (120,), generator=gen).tolist()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        results = []
+        for k, ci in enumerate(order):
+            rays, z, cot, raw_ref, g_ref = cases[ci]
+            with torch.cuda.stream(streams[k & 1]):
+                n, S = z.shape
+                act = torch.empty(fn.ops.act_floats(n * S)).cuda()
+                raw = fn.ops.mlp_fwd(rays, z, flat, pf, act=act)
+                dact = torch.empty(fn.ops.dact_floats(n * S)).cuda()
+                partial = torch.empty(fn.ops.mlp_bwd_partial_floats()).cuda()
+                grads = torch.zeros(fn.ops.NET_PARAMS).cuda()
+                fn.ops.mlp_bwd(cot, act, flat, pb, dact, partial, grads)
+                results.append((ci, raw, grads, act, dact, partial))
+        torch.cuda.synchronize()
+        for ci, raw, grads, *_ in results:
+            assert torch.equal(raw, cases[ci][3]), ci
+            assert torch.equal(grads, cases[ci][4]), ci
+    finally:
+        fn.ops.set_math(old)
