@@ -1434,6 +1434,9 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   const uint4* act = reinterpret_cast<const uint4*>(act_f);
   uint4* dact = reinterpret_cast<uint4*>(dact_f);
   int grid = ncu * 2;
+#ifdef BF_EXPERIMENT
+  if (getenv("FASTNERF_DX_WGS")) grid = atoi(getenv("FASTNERF_DX_WGS"));
+#endif
   if (nt < grid) grid = (int)nt;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1448,6 +1451,9 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   FN_LAUNCH_CHECK();
 
   int nwg = ncu;
+#ifdef BF_EXPERIMENT
+  if (getenv("FASTNERF_DW_WGS")) nwg = atoi(getenv("FASTNERF_DW_WGS"));
+#endif
   if (nt < nwg) nwg = (int)nt;
   BRedTable T;
   T.n = 0;
