@@ -36,6 +36,9 @@ typedef unsigned long long u64;
 #ifndef DW_NST
 #define DW_NST 3   // LDS stages of the dW operand ring (DW_NST - 1 k-steps prefetched)
 #endif
+#ifndef DW_DMA_LATE
+#define DW_DMA_LATE 1   // issue a k-step's operand DMA between its fragment reads and their wait
+#endif
 #ifndef DW_AUX
 #define DW_AUX 2   // cache-policy bits of the dW operand DMA (saved tensors are read exactly once)
 #endif
@@ -1127,9 +1130,11 @@ __device__ __forceinline__ void unpk8v(const u32x4& h, const u32x4& l, float (&o
     o[2 * q + 1] = __uint_as_float(h[q] & 0xffff0000u) + __uint_as_float(l[q] & 0xffff0000u);
   }
 }
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+// `between` runs after the fragment reads have been ISSUED and before they are waited for: the caller puts the DMA issue of
+// a later stage there, so its ~80 issue cycles per piece cover the LDS read latency instead of preceding it.
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, class F>
 __device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&bsum)[TO], float (&rsum)[TI], const uint4* st, int wo,
-                                                 int wi, int lane, const float4& d0, const float4& d1) {
+                                                 int wi, int lane, const float4& d0, const float4& d1, F&& between) {
   constexpr int CTO = WO * TO;
   // The fragment reads are inline asm: for a plain LDS load hipcc inserts s_waitcnt vmcnt(0) while an LDS-DMA is
   // pending (it cannot see that the DMA targets another stage), which would drain the prefetch every k-step.
@@ -1146,6 +1151,7 @@ __device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&
     asm volatile("ds_read_b128 %0, %1" : "=v"(xh[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128) * 16));
     asm volatile("ds_read_b128 %0, %1" : "=v"(xl[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128 + 64) * 16));
   }
+  between();
   // wait for the reads; tying the registers to the wait keeps every consumer behind it
 #pragma unroll
   for (int i = 0; i < TO; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
@@ -1264,9 +1270,14 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
       }
       const int bn = (buf >= 1) ? buf - 1 : DW_NST - 1;   // (buf + DW_NST - 1) % DW_NST: the stage consumed at step q-1
       const int64_t qn = q + DW_NST - 1;
+#if DW_DMA_LATE
+      dw_stage_compute<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, reinterpret_cast<const uint4*>(dsm) + buf * STAGE_U4, wo, wi,
+                                                    lane, d0, d1, [&]() __attribute__((always_inline)) { if (qn < nq) dma_stage(qn, bn); });
+#else
       if (qn < nq) dma_stage(qn, bn);
       dw_stage_compute<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, reinterpret_cast<const uint4*>(dsm) + buf * STAGE_U4, wo, wi,
-                                                    lane, d0, d1);
+                                                    lane, d0, d1, []() {});
+#endif
       // stage q+1 must have landed; the newer ones may stay in flight
       const int64_t newer = (nq - 1 - (q + 1));   // stages issued after q+1 (clamped below)
       if (newer >= DW_NST - 2) wait_stages(DW_NST - 2);
