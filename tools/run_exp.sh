@@ -1,3 +1,4 @@
+# runs ON THE GPU BOX: backward time vs the number of workgroups dX / dW get (-DBF_EXPERIMENT build as variants/exp.so)
 cd $GRAFT_REPO_ROOT
 export FASTNERF_LIB=$PWD/fast-learning-nerf_amd/variants/exp.so
 python tools/time_bwd_parts.py
