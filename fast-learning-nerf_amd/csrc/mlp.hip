@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "mlp_layout.h"
+#include "sched.h"
 
 using namespace fnl;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -397,11 +398,14 @@ template <bool SAVE, bool BG>
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                const float* __restrict__ params, const float* __restrict__ packed, float* __restrict__ raw,
-               float* __restrict__ act, NetLayout lay) {
+               float* __restrict__ act, NetLayout lay, unsigned* __restrict__ sched) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;
   float* Es = smem + LDS_H;
   float* X2 = smem;   // [TM][32], aliases the head of H (BG only)
+  // tile scheduler word (sched.h): the last two floats of H = columns >= 128 of the last row, stale feature values at
+  // the end of a tile and next written by the following tile's layer-0 epilogue, one barrier after everybody read it
+  volatile int* sched_word = reinterpret_cast<volatile int*>(smem + LDS_H - 2);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -412,7 +416,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
   const int dbg = 0;
   stagger_start();
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = blockIdx.x; tile < ntiles;) {
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     unsigned long long* maskw =
@@ -610,8 +614,9 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
       }
     }
-    __syncthreads();  // H / Es are rewritten by the next tile
+    tile = b_next_tile(sched, sched_word, tid);   // closing barrier inside: H / Es are rewritten by the next tile
   }
+  b_sched_exit(sched, tid);
 }
 
 extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const float* z,
@@ -638,12 +643,14 @@ extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays
     attr_done = true;
   }
   hipStream_t st = fn::S(stream);
+  unsigned* sched = b_sched_pair();
+  FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   if (kind == 2) {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
   } else {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay);
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
   }
   FN_LAUNCH_CHECK();
   return 0;
@@ -715,10 +722,11 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __restrict__ act,
                   const float* __restrict__ params, const float* __restrict__ packed_t, float* __restrict__ dact,
-                  NetLayout lay) {
+                  NetLayout lay, unsigned* __restrict__ sched) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;
   float* Es = smem + LDS_H;  // Es[0..127] = dalpha of the tile's rows
+  volatile int* sched_word = reinterpret_cast<volatile int*>(Es + 1024);   // tile scheduler word (sched.h): unused part of Es
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -727,7 +735,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
   const int64_t ntiles = (P + TM - 1) / TM;
   stagger_start();
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = blockIdx.x; tile < ntiles;) {
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     const unsigned long long* maskw =
@@ -797,9 +805,10 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
         if (m < valid)
           store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
       }
-      __syncthreads();   // H is rewritten by the next tile's phase A
     }
+    tile = b_next_tile(sched, sched_word, tid);   // closing barrier inside: H is rewritten by the next tile's phase A
   }
+  b_sched_exit(sched, tid);
 }
 
 // =========================================================================================
@@ -1099,7 +1108,9 @@ extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done = true;
   }
-  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L);
+  unsigned* sched = b_sched_pair();
+  FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
+  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L, sched);
   FN_LAUNCH_CHECK();
 
   // ---- dW jobs: every job writes per-workgroup partials into its own region ------------------

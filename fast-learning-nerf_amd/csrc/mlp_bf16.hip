@@ -24,8 +24,8 @@
 // 256-channel tensors are stored in the wave-permuted channel order q = (n>>6)*64 + (n&1)*32 + ((n&63)>>1)
 // (then every store instruction writes 512 contiguous bytes); the final reduction un-permutes.
 #include <stdlib.h>
-#include <mutex>
 #include "common.h"
+#include "sched.h"
 #include "mlp_layout.h"
 
 using namespace fnl;
@@ -83,46 +83,6 @@ static int b_num_cus() {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
   if (n <= 0) n = 256;
   return n;
-}
-
-// Dynamic tile scheduling of the persistent forward / dX kernels: the two workgroups of a CU do not run at the same
-// speed (the first-dispatched one wins the arbitration: 198 k vs 243 k cycles per tile, tools/trace_fwd.py), so a static
-// round-robin leaves the slower half ~4 tiles behind at the end.  Every workgroup takes tile blockIdx.x first and then
-// draws tickets from a counter in global memory; the last workgroup to leave resets the counter pair, so a launch never
-// depends on host-side state (graph replay safe).  Concurrent launches (different streams) must not share a pair: the
-// host hands out pairs round-robin from a pool of BSCHED_SLOTS.
-#define BSCHED_SLOTS 64
-static unsigned* b_sched_pair() {
-  static unsigned* pool[16] = {};
-  static unsigned next[16] = {};
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!pool[dev]) {
-    unsigned* p = nullptr;
-    if (hipMalloc(&p, BSCHED_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, BSCHED_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    pool[dev] = p;
-  }
-  const unsigned k = next[dev]++ % BSCHED_SLOTS;
-  return pool[dev] + 2 * k;
-}
-// end of a tile: thread 0 draws the next ticket into the LDS word `slot` (a place nobody reads or writes around the
-// tile boundary), the tile's closing barrier publishes it
-__device__ __forceinline__ int64_t b_next_tile(unsigned* sched, volatile int* slot, int tid) {
-  if (tid == 0) *slot = (int)(atomicAdd(sched, 1u) + gridDim.x);
-  __syncthreads();
-  return (int64_t)__builtin_amdgcn_readfirstlane(*slot);
-}
-__device__ __forceinline__ void b_sched_exit(unsigned* sched, int tid) {
-  if (tid == 0) {
-    __threadfence();
-    if (atomicAdd(sched + 1, 1u) == gridDim.x - 1) {   // everybody else has drawn its last (failing) ticket
-      sched[0] = 0u; sched[1] = 0u;
-      __threadfence();
-    }
-  }
 }
 
 __device__ __forceinline__ unsigned bf16_rne(float v) {   // bits of bf16(v), round to nearest even
