@@ -945,6 +945,9 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
 #ifdef BF_TRACE
   if (getenv("BF_ONE_WG")) grid = b_num_cus();
 #endif
+#ifdef BF_EXPERIMENT
+  if (getenv("FASTNERF_FWD_WGS")) grid = atoi(getenv("FASTNERF_FWD_WGS"));
+#endif
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {

@@ -1,6 +1,5 @@
-# runs ON THE GPU BOX: backward time vs the number of workgroups dX / dW get (-DBF_EXPERIMENT build as variants/exp.so)
+# runs ON THE GPU BOX: kernel times vs the number of workgroups the persistent kernels get (-DBF_EXPERIMENT build as variants/exp.so)
 cd $GRAFT_REPO_ROOT
 export FASTNERF_LIB=$PWD/fast-learning-nerf_amd/variants/exp.so
-python tools/time_bwd_parts.py
-for w in 192 128 112 96 64; do FASTNERF_DW_WGS=$w python tools/time_bwd_parts.py; done
-for w in 384 288 256 192; do FASTNERF_DX_WGS=$w python tools/time_bwd_parts.py; done
+for w in 512 480 448 416 384 320 256; do echo -n "fwd_wgs $w: "; FASTNERF_FWD_WGS=$w python tools/time_mlp.py 2>/dev/null | tail -1; done
+for w in 512 448 384; do FASTNERF_DX_WGS=$w python tools/time_bwd_parts.py; done
