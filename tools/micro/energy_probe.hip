@@ -91,6 +91,11 @@ int main() {
     run<0, 0, 72, 0>(out, h, data, sink, wpc, "+ 72 v_fma_f32");
     run<4, 4, 36, 0>(out, h, data, sink, wpc, "+ 4 ds_read + 4 L2 + 36 VALU (inference-like)");
     run<4, 4, 72, 1>(out, h, data, sink, wpc, "+ 4 ds_read + 4 L2 + 72 VALU + 1 store (training-like)");
+    run<4, 2, 36, 0>(out, h, data, sink, wpc, "+ 4 ds_read + 2 L2 + 36 VALU (half the weight bytes)");
+    run<8, 2, 36, 0>(out, h, data, sink, wpc, "+ 8 ds_read + 2 L2 + 36 VALU (128 x 32 wave tile)");
+    run<8, 2, 72, 1>(out, h, data, sink, wpc, "+ 8 ds_read + 2 L2 + 72 VALU + 1 store");
+    run<8, 0, 36, 0>(out, h, data, sink, wpc, "+ 8 ds_read + 36 VALU (weights through LDS)");
+    run<8, 0, 72, 1>(out, h, data, sink, wpc, "+ 8 ds_read + 72 VALU + 1 store (weights through LDS)");
   }
   return 0;
 }
