@@ -55,7 +55,7 @@ def cpu_baseline(seconds_budget=20.0):
     tgt = torch.rand(n, 3, generator=gen)
     times = []
     t_start = time.time()
-    for it in range(6):
+    for it in range(16):   # ~0.8 s per step on 32 cores: 10-15 s of CPU work, bounded by seconds_budget
         t_rand, u = torch.rand(n, N_SAMPLES, generator=gen), torch.rand(n, N_IMPORTANCE, generator=gen)
         t0 = time.time()
         O.train_step(sdc, sdf, opt, rb, tgt, N_SAMPLES, N_IMPORTANCE, True, t_rand=t_rand, u=u)
