@@ -67,6 +67,11 @@ SIGNATURES = {
     'fastnerf_tree_set_leaves': (I, [P, I, I, P, D]),
     'fastnerf_tree_leaf_plan': (I, [P, I, D, I, P]),
     'fastnerf_tree_adjust': (L, [P, P, I, D]),
+    'fastnerf_compact_ws_ints': (L, [L]),
+    'fastnerf_compact_live': (I, [L, P, P, P, P, P]),
+    'fastnerf_mlp_bf16_fwd_live': (I, [I, L, I, P, P, P, P, P, P, P, P]),
+    'fastnerf_mlp_bf16_bwd_live': (I, [I, L, I, P, P, P, P, P, P, P, P, P, P]),
+    'fastnerf_render_rays_bwd_live': (I, [L, I, I, P, I] + [P] * 22 + [P]),
 }
 
 _lib = None

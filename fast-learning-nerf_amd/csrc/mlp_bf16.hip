@@ -60,6 +60,19 @@ typedef unsigned long long u64;
 #ifndef BF_PF
 #define BF_PF 2   // weight fragments two k-steps ahead in the fwd / dX k-loops (1: one ahead)
 #endif
+// Bisection hook for the SLP-vectoriser corruption (tools/slp_bisect.py): what is executed at every
+// k-loop exit, in front of the epilogue.  0: nothing (product); 1: 34 idle wait states (drains the matrix pipe);
+// 2: s_waitcnt vmcnt(0) lgkmcnt(0) (drains every outstanding load, incl. the pre-loaded bias / mask words)
+#ifndef BF_DBG_DRAIN
+#define BF_DBG_DRAIN 0
+#endif
+__device__ __forceinline__ void bdbg_drain() {
+#if BF_DBG_DRAIN == 1
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 1" ::: "memory");
+#elif BF_DBG_DRAIN == 2
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+}
 #define BTM 64
 #define BNTHR 256
 #ifdef BF_TRACE   // tuning builds only: per-wave s_memtime stamps of the forward's phases (tools/trace_fwd.py)
@@ -370,6 +383,7 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
 #if BF_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+    bdbg_drain();
     return;
   }
 #endif
@@ -384,6 +398,7 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
 #if BF_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
+  bdbg_drain();
 }
 
 template <int NT>
@@ -652,7 +667,8 @@ template <bool SAVE, bool BG>
 __global__ void __launch_bounds__(BNTHR, 2)
 mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                     const float* __restrict__ params, const uint4* __restrict__ pk, float* __restrict__ raw,
-                    uint4* __restrict__ act, NetLayout lay, BOff boff, unsigned* __restrict__ sched) {
+                    uint4* __restrict__ act, NetLayout lay, BOff boff, unsigned* __restrict__ sched,
+                    const int* __restrict__ live_idx, const int* __restrict__ live_cnt) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   char* Hhi = bsm;
   char* Hlo = bsm + BTM * 512;
@@ -661,9 +677,14 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Live-list mode (training with exact zero-gradient point compaction): tile-local point j of the launch is point
+  // live_idx[j] of the ray batch and the number of points is a DEVICE value (no host round trip); the saved tensors are
+  // laid out for the capacity P the caller sized them for (nt_lay), only the first ceil(*live_cnt / 64) tiles exist.
+  const int64_t nt_lay = (P + BTM - 1) / BTM;
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
   const int64_t ntiles = (P + BTM - 1) / BTM;
-  u64* maskw_all = SAVE ? reinterpret_cast<u64*>(act + ba_mask(ntiles)) : nullptr;            // [tile][8][256] u64
-  unsigned* maskv_all = SAVE ? reinterpret_cast<unsigned*>(act + ba_maskv(ntiles)) : nullptr;   // [tile][256] u32
+  u64* maskw_all = SAVE ? reinterpret_cast<u64*>(act + ba_mask(nt_lay)) : nullptr;            // [tile][8][256] u64
+  unsigned* maskv_all = SAVE ? reinterpret_cast<unsigned*>(act + ba_maskv(nt_lay)) : nullptr;   // [tile][256] u32
 
   int hofs[16];   // LDS offsets of this lane's epilogue stores (loop invariant; not for BG: that variant has no registers left)
   if (!BG) {
@@ -683,6 +704,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     const int pm = tid >> 2, pq = tid & 3;
     int64_t pp = p0 + pm;
     if (pp >= P) pp = P - 1;
+    if (live_idx) pp = live_idx[pp];
     const int64_t ray = pp / S;
     const float* rr = rays + ray * 11;
 #ifdef BF_TRACE
@@ -758,7 +780,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     __syncthreads();
     if (SAVE) {   // PE tile in K-fragment order: 16 (24) KiB staged at the head of H
       constexpr int PE_U4 = BG ? 1536 : 1024;
-      uint4* dst = act + ba_pe(ntiles) + tile * PE_U4;
+      uint4* dst = act + ba_pe(nt_lay) + tile * PE_U4;
 #pragma unroll
       for (int i = 0; i < PE_U4 / 256; ++i) dst[i * 256 + tid] = *reinterpret_cast<const uint4*>(bsm + (i * 256 + tid) * 16);
     }
@@ -779,7 +801,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     }
     if (SAVE || BG) __syncthreads();   // staging copy / X2 block read out before H is written
     if (SAVE) {
-      ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, 0) + tile * 4096);
+      ea.gsave = reinterpret_cast<uint2*>(act + ba_h(nt_lay, 0) + tile * 4096);
       ea.mask_out = maskw_all + (tile * 8 + 0) * 256;
     }
     if (PRE) bprefetch<2>(pre, pk + boff.off[1], 16, 0, wn * 2, lane);
@@ -811,7 +833,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       __syncthreads();
       TR(4 * l + 2);
       if (SAVE) {
-        ea.gsave = reinterpret_cast<uint2*>(act + ba_h(ntiles, l) + tile * 4096);
+        ea.gsave = reinterpret_cast<uint2*>(act + ba_h(nt_lay, l) + tile * 4096);
         ea.mask_out = maskw_all + (tile * 8 + l) * 256;
       }
       if (PRE) {   // layer l + 1 (layer 5 starts with its skip-input segment), after layer 7 the feature layer
@@ -841,7 +863,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       s += __shfl_xor(s, 2, 64);
       alpha_val = s + params[lay.AB];
       const float v[3] = {rr[8], rr[9], rr[10]};
-      unsigned short* gv = SAVE ? reinterpret_cast<unsigned short*>(act + ba_vpe(ntiles) + tile * 512) : nullptr;
+      unsigned short* gv = SAVE ? reinterpret_cast<unsigned short*>(act + ba_vpe(nt_lay) + tile * 512) : nullptr;
       auto estv = [&](int c, float val) {
         unsigned h, l;
         split1(val, h, l);
@@ -875,7 +897,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     bzero<2>(acc);
     bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane, &pre);
     __syncthreads();
-    if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(ntiles) + tile * 4096);
+    if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(nt_lay) + tile * 4096);
     BPre<1> prev;
     if (PRE) bprefetch<1>(prev, pk + boff.off[9], 18, 0, wn, lane);
     bepi256<true, false, false, false, false, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
@@ -890,7 +912,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       bgemm<1, 1>(av, Ehi, Elo, 0, 2, pk + boff.off[9], 18, 16, wn, lane);
       __syncthreads();
       if (SAVE) {
-        ea.gsave = reinterpret_cast<uint2*>(act + ba_hv(ntiles) + tile * 2048);
+        ea.gsave = reinterpret_cast<uint2*>(act + ba_hv(nt_lay) + tile * 2048);
         ea.mask_out = maskv_all + tile * 256;
       }
       bepi128<true, true, false, SAVE, SAVE>(av, ea, Hhi, Hlo, wn, lane);
@@ -916,7 +938,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
       s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
       s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
-      if (pq == 0 && pm < valid) {
+      if (pq == 0 && pm < valid && raw) {
         float4 o;
         o.x = s0 + params[lay.RB]; o.y = s1 + params[lay.RB + 1]; o.z = s2 + params[lay.RB + 2]; o.w = alpha_val;
         *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
@@ -931,12 +953,9 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
   b_sched_exit(sched, tid);
 }
 
-extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const float* z,
-                                     const float* params, const float* packed_fwd, float* raw, float* act,
-                                     fn_stream_t stream) {
-  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
-  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
-  if (n == 0) return 0;
+static int b_fwd_launch(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                        const float* packed_fwd, float* raw, float* act, const int* live_idx, const int* live_cnt,
+                        fn_stream_t stream) {
   const NetLayout& lay = b_layout(kind);
   const BOff O = b_offsets(lay);
   const int64_t P = n * S;
@@ -968,14 +987,34 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   if (kind == 2) {
-    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
-    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
   } else {
-    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
-    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched);
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
   }
   FN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const float* z,
+                                     const float* params, const float* packed_fwd, float* raw, float* act,
+                                     fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
+  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
+  if (n == 0) return 0;
+  return b_fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream);
+}
+
+// Training forward over a live-point list (see fastnerf.h): activations of the points live_idx[0 .. *live_cnt) are saved
+// in list order; nothing else is written.  act is sized for all n*S points.
+extern "C" int fastnerf_mlp_bf16_fwd_live(int kind, int64_t n, int S, const float* rays11, const float* z,
+                                          const float* params, const float* packed_fwd, float* act,
+                                          const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(rays11 && z && params && packed_fwd && act && live_idx && live_cnt, "null pointer");
+  FN_CHECK_ARG(n * (int64_t)S < ((int64_t)1 << 31), "live lists index points with int32");
+  return b_fwd_launch(kind, n, S, rays11, z, params, packed_fwd, nullptr, act, live_idx, live_cnt, stream);
 }
 
 // =========================================================================================
@@ -984,7 +1023,8 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
 __global__ void __launch_bounds__(BNTHR, 2)
 mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* __restrict__ act,
                        const float* __restrict__ params, const uint4* __restrict__ pkt, uint4* __restrict__ dact,
-                       NetLayout lay, BOff boff, unsigned* __restrict__ sched) {
+                       NetLayout lay, BOff boff, unsigned* __restrict__ sched, const int* __restrict__ live_idx,
+                       const int* __restrict__ live_cnt) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   char* Hhi = bsm;
   char* Hlo = bsm + BTM * 512;
@@ -993,9 +1033,11 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t nt_lay = (P + BTM - 1) / BTM;   // (live-list mode: see the forward kernel)
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
   const int64_t ntiles = (P + BTM - 1) / BTM;
-  const u64* maskw_all = reinterpret_cast<const u64*>(act + ba_mask(ntiles));
-  const unsigned* maskv_all = reinterpret_cast<const unsigned*>(act + ba_maskv(ntiles));
+  const u64* maskw_all = reinterpret_cast<const u64*>(act + ba_mask(nt_lay));
+  const unsigned* maskv_all = reinterpret_cast<const unsigned*>(act + ba_maskv(nt_lay));
 
   int hofs[16];   // LDS offsets of this lane's epilogue stores (loop invariant)
   {
@@ -1009,9 +1051,9 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     if (tid < BTM) {
       const int64_t p = p0 + tid;
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < P) d = *reinterpret_cast<const float4*>(draw + p * 4);
+      if (p < P) d = *reinterpret_cast<const float4*>(draw + (live_idx ? (int64_t)live_idx[p] : p) * 4);
       *reinterpret_cast<float4*>(Dr + tid * 4) = d;
-      reinterpret_cast<float*>(dact + bd_alpha(ntiles))[p0 + tid] = d.w;   // compact copy for the dW rank-1 row
+      reinterpret_cast<float*>(dact + bd_alpha(nt_lay))[p0 + tid] = d.w;   // compact copy for the dW rank-1 row
     }
     __syncthreads();
     EpiArgs ea{};
@@ -1034,7 +1076,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
           const float4 d = *reinterpret_cast<const float4*>(Dr + (mt * 32 + bcrow(r, lane)) * 4);
           av[mt][0][r] = fmaf(d.z, w2, fmaf(d.y, w1, d.x * w0));
         }
-      ea.gsave = reinterpret_cast<uint2*>(dact + bd_yv(ntiles) + tile * 2048);
+      ea.gsave = reinterpret_cast<uint2*>(dact + bd_yv(nt_lay) + tile * 2048);
       bepi128<false, false, true, false, true>(av, ea, Hhi, Hlo, wn, lane);
     }
     __syncthreads();
@@ -1043,7 +1085,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     bzero<2>(acc);
     bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane, &pre);
     __syncthreads();
-    ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(ntiles) + tile * 4096);
+    ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(nt_lay) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[1], 16, 0, wn * 2, lane);
     bepi256<false, false, false, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
@@ -1055,7 +1097,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     bzero<2>(acc);
     bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane, &pre);
     __syncthreads();
-    ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, 7) + tile * 4096);
+    ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, 7) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[2], 16, 0, wn * 2, lane);
     bepi256<false, false, true, true, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
@@ -1067,7 +1109,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
       bzero<2>(acc);
       bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane, &pre);
       __syncthreads();
-      ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(ntiles, l - 1) + tile * 4096);
+      ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, l - 1) + tile * 4096);
       if (PRE && l > 1) bprefetch<2>(pre, pkt + boff.off[10 - l], 16, 0, wn * 2, lane);
       bepi256<false, false, true, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
       if (l > 1) __syncthreads();
@@ -1162,7 +1204,8 @@ template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
 __global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, const uint4* __restrict__ X,
                            const float* __restrict__ dalpha, float* __restrict__ partial_w, float* __restrict__ partial_b,
-                           float* __restrict__ partial_r) {
+                           float* __restrict__ partial_r, const int* __restrict__ live_cnt) {
+  if (live_cnt) ntiles = ((int64_t)__builtin_amdgcn_readfirstlane(*live_cnt) + BTM - 1) / BTM;   // live-list mode
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int CTO = WO * TO, CTI = WI * TI;
   constexpr int NW = WO * WI;
@@ -1280,8 +1323,10 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
 // rgb head + alpha bias gradients: out[wg][0..383] = dWr[c][k], [384..386] = dbr[c], [387] = dba
 __global__ void __launch_bounds__(128) head_grads_bf16_kernel(int64_t P, int64_t ntiles, const float* __restrict__ draw,
                                                                const uint4* __restrict__ hv,
-                                                               float* __restrict__ partial) {
+                                                               float* __restrict__ partial, const int* __restrict__ live_idx,
+                                                               const int* __restrict__ live_cnt) {
   const int k = threadIdx.x;
+  if (live_idx) { P = *live_cnt; ntiles = (P + BTM - 1) / BTM; }
   const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int64_t ta = blockIdx.x * per;
   int64_t tb = ta + per;
@@ -1297,7 +1342,7 @@ __global__ void __launch_bounds__(128) head_grads_bf16_kernel(int64_t P, int64_t
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pb + e < P) d = *reinterpret_cast<const float4*>(draw + (pb + e) * 4);
+        if (pb + e < P) d = *reinterpret_cast<const float4*>(draw + (live_idx ? (int64_t)live_idx[pb + e] : pb + e) * 4);
         s0 = fmaf(d.x, h[e], s0); s1 = fmaf(d.y, h[e], s1); s2 = fmaf(d.z, h[e], s2);
         if (k < 4) sb += (k == 0) ? d.x : (k == 1) ? d.y : (k == 2) ? d.z : d.w;
       }
@@ -1369,7 +1414,7 @@ extern "C" int64_t fastnerf_mlp_bf16_partial_floats(void) {
 
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
 static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, const uint4* X, int CTi, const float* dalpha,
-                       float* base, int nwg, hipStream_t st) {
+                       float* base, int nwg, hipStream_t st, const int* live_cnt = nullptr) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
@@ -1382,7 +1427,7 @@ static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, cons
     FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, ntiles, dY, X, dalpha, pw, pb, pr);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, ntiles, dY, X, dalpha, pw, pb, pr, live_cnt);
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -1394,11 +1439,9 @@ static void b_add_seg(BRedTable& T, int64_t src, int64_t wg_stride, int nwg, int
   s.valid_cols = valid_cols; s.perm = perm;
 }
 
-extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const float* act_f,
-                                     const float* params, const float* packed_bwd, float* dact_f, float* partial,
-                                     float* grads, fn_stream_t stream) {
-  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
-  FN_CHECK_ARG(draw && act_f && params && packed_bwd && dact_f && partial && grads, "null pointer");
+static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const float* act_f, const float* params,
+                        const float* packed_bwd, float* dact_f, float* partial, float* grads, const int* live_idx,
+                        const int* live_cnt, fn_stream_t stream) {
   const NetLayout& L = b_layout(kind);
   const BOff OB = b_offsets_bwd();
   hipStream_t st = fn::S(stream);
@@ -1421,7 +1464,7 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   hipLaunchKernelGGL(mlp_bwd_dx_bf16_kernel, dim3(grid), dim3(BNTHR), BLDS_BYTES, st, P, draw, act, params,
-                     reinterpret_cast<const uint4*>(packed_bwd), dact, L, OB, sched);
+                     reinterpret_cast<const uint4*>(packed_bwd), dact, L, OB, sched, live_idx, live_cnt);
   FN_LAUNCH_CHECK();
 
   int nwg = ncu;
@@ -1445,35 +1488,35 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   };
   const uint4* a_pe = act + ba_pe(nt);
   // L0
-  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 2, nullptr, region(0), nwg, st);
-  else rc = b_launch_dw<4, 1, 2, 3, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 3, nullptr, region(0), nwg, st);
+  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 2, nullptr, region(0), nwg, st, live_cnt);
+  else rc = b_launch_dw<4, 1, 2, 3, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 3, nullptr, region(0), nwg, st, live_cnt);
   if (rc) return rc;
   segs(0, L.LW[0], L.in_pe, L.in_pe, 1, L.LB[0], 0);
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
-    if ((rc = b_launch_dw<DW_CFG, true, false>(P, nt, dact + bd_y(nt, l), 8, act + ba_h(nt, l - 1), 8, nullptr, region(l), nwg, st))) return rc;
+    if ((rc = b_launch_dw<DW_CFG, true, false>(P, nt, dact + bd_y(nt, l), 8, act + ba_h(nt, l - 1), 8, nullptr, region(l), nwg, st, live_cnt))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, 3, L.LB[l], 0);
   }
   // L5 pe part
-  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st);
-  else rc = b_launch_dw<4, 1, 2, 3, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 3, nullptr, region(8), nwg, st);
+  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st, live_cnt);
+  else rc = b_launch_dw<4, 1, 2, 3, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 3, nullptr, region(8), nwg, st, live_cnt);
   if (rc) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 1, 0, 0);
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
   if ((rc = b_launch_dw<DW_CFG, true, true>(P, nt, dact + bd_feat(nt), 8, act + ba_h(nt, 7), 8,
-                                                 reinterpret_cast<const float*>(dact + bd_alpha(nt)), region(9), nwg, st))) return rc;
+                                                 reinterpret_cast<const float*>(dact + bd_alpha(nt)), region(9), nwg, st, live_cnt))) return rc;
   segs(9, L.FW, 256, 256, 3, L.FB, L.AW);
   // view layer
-  if ((rc = b_launch_dw<2, 2, 2, 4, true, false>(P, nt, dact + bd_yv(nt), 4, act + ba_feat(nt), 8, nullptr, region(10), nwg, st))) return rc;
+  if ((rc = b_launch_dw<2, 2, 2, 4, true, false>(P, nt, dact + bd_yv(nt), 4, act + ba_feat(nt), 8, nullptr, region(10), nwg, st, live_cnt))) return rc;
   segs(10, L.VW, 283, 256, 2, L.VB, 0);
-  if ((rc = b_launch_dw<4, 1, 1, 1, false, false>(P, nt, dact + bd_yv(nt), 4, act + ba_vpe(nt), 1, nullptr, region(11), nwg, st))) return rc;
+  if ((rc = b_launch_dw<4, 1, 1, 1, false, false>(P, nt, dact + bd_yv(nt), 4, act + ba_vpe(nt), 1, nullptr, region(11), nwg, st, live_cnt))) return rc;
   segs(11, L.VW + 256, 283, 27, 0, 0, 0);
   // rgb head + alpha bias
   {
     int hg = (int)(nt > BHEAD_MAX_WG ? BHEAD_MAX_WG : nt);
     if (hg < 1) hg = 1;
     const int64_t hb = b_job_base(12, ncu, PEP);
-    hipLaunchKernelGGL(head_grads_bf16_kernel, dim3(hg), dim3(128), 0, st, P, nt, draw, act + ba_hv(nt), partial + hb);
+    hipLaunchKernelGGL(head_grads_bf16_kernel, dim3(hg), dim3(128), 0, st, P, nt, draw, act + ba_hv(nt), partial + hb, live_idx, live_cnt);
     FN_LAUNCH_CHECK();
     b_add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387, 0);   // dWr (384) + dbr (3), contiguous in every layout
     b_add_seg(T, hb + 387, 388, hg, 1, 1, L.AB, 1, 1, 0);   // dba
@@ -1481,4 +1524,23 @@ extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* dr
   hipLaunchKernelGGL(breduce_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
   FN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const float* act_f,
+                                     const float* params, const float* packed_bwd, float* dact_f, float* partial,
+                                     float* grads, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(draw && act_f && params && packed_bwd && dact_f && partial && grads, "null pointer");
+  return b_bwd_launch(kind, n, S, draw, act_f, params, packed_bwd, dact_f, partial, grads, nullptr, nullptr, stream);
+}
+
+// Backward over a live-point list: act holds the activations fastnerf_mlp_bf16_fwd_live saved for live_idx[0 .. *live_cnt),
+// draw is the full [n*S, 4] upstream gradient (read through the list).  Points not in the list contribute nothing.
+extern "C" int fastnerf_mlp_bf16_bwd_live(int kind, int64_t n, int S, const float* draw, const float* act_f,
+                                          const float* params, const float* packed_bwd, float* dact_f, float* partial,
+                                          float* grads, const int32_t* live_idx, const int32_t* live_cnt,
+                                          fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(draw && act_f && params && packed_bwd && dact_f && partial && grads && live_idx && live_cnt, "null pointer");
+  return b_bwd_launch(kind, n, S, draw, act_f, params, packed_bwd, dact_f, partial, grads, live_idx, live_cnt, stream);
 }

@@ -85,3 +85,56 @@ extern "C" int fastnerf_render_rays_bwd(int math_mode, int64_t n, int N_samples,
   if ((rc = fastnerf_raw2outputs_bwd(n, N_samples, raw0, z0, rays11, noise0, white_bkgd, g_coarse, draw_ws, stream))) return rc;
   return mlp(N_samples, act0, params_c, packed_bwd_c, grads_c);
 }
+
+
+// Training backward with exact zero-gradient point compaction (split-bf16 math mode).  The forward ran WITHOUT saving
+// activations (the inference kernels); per pass:  compositing backward -> list of the points with a non-zero
+// d(loss)/d(raw) (fastnerf_compact_live) -> forward over that list, saving activations -> dX / dW over that list.
+// The gradients equal fastnerf_render_rays_bwd's up to fp32 summation order (the dead points' terms are exact zeros).
+// No host round trip: the list length stays on the device.  live_ws: 4 + n*S1 + fastnerf_compact_ws_ints(n*S1) int32;
+// act_ws: fastnerf_mlp_bf16_floats(0, 3, n*S1) floats; counts_out (optional): 4 int32 = live/total fine, live/total coarse.
+extern "C" int fastnerf_render_rays_bwd_live(int64_t n, int N_samples, int N_importance, const float* rays11, int white_bkgd,
+                                             const float* g_rgb, const float* g_rgb0, const float* noise0, const float* noise1,
+                                             const float* z0, const float* raw0, const float* z1, const float* raw1,
+                                             const float* params_c, const float* packed_fwd_c, const float* packed_bwd_c,
+                                             const float* params_f, const float* packed_fwd_f, const float* packed_bwd_f,
+                                             float* draw_ws, float* act_ws, float* dact_ws, float* partial_ws, int32_t* live_ws,
+                                             float* grads_c, float* grads_f, int32_t* counts_out, fn_stream_t stream) {
+  if (n <= 0 || N_samples < 2 || N_importance < 0) {
+    fn::set_error("fastnerf_render_rays_bwd_live: bad argument: n>0, N_samples>=2, N_importance>=0");
+    return -1;
+  }
+  if (!rays11 || !z0 || !raw0 || !params_c || !packed_fwd_c || !packed_bwd_c || !draw_ws || !act_ws || !dact_ws ||
+      !partial_ws || !live_ws || !grads_c) {
+    fn::set_error("fastnerf_render_rays_bwd_live: null pointer (coarse pass)");
+    return -1;
+  }
+  const int S1 = N_samples + N_importance;
+  int32_t* cnt = live_ws;            // [4]: (live, total) of the fine pass, of the coarse pass
+  int32_t* idx = live_ws + 4;
+  int32_t* cws = idx + n * (int64_t)S1;
+  int rc;
+  auto pass = [&](int S, const float* z, const float* raw, const float* noise, const float* g, const float* params,
+                  const float* pf, const float* pb, float* grads, int32_t* cnt_out) -> int {
+    if ((rc = fastnerf_raw2outputs_bwd(n, S, raw, z, rays11, noise, white_bkgd, g, draw_ws, stream))) return rc;
+    if ((rc = fastnerf_compact_live(n * (int64_t)S, draw_ws, idx, cnt_out, cws, stream))) return rc;
+    if ((rc = fastnerf_mlp_bf16_fwd_live(0, n, S, rays11, z, params, pf, act_ws, idx, cnt_out, stream))) return rc;
+    return fastnerf_mlp_bf16_bwd_live(0, n, S, draw_ws, act_ws, params, pb, dact_ws, partial_ws, grads, idx, cnt_out, stream);
+  };
+  const float* g_coarse = g_rgb;
+  int32_t* c_fine = counts_out ? counts_out : cnt;
+  int32_t* c_coarse = counts_out ? counts_out + 2 : cnt + 2;
+  if (N_importance > 0) {
+    if (!g_rgb || !g_rgb0 || !z1 || !raw1 || !params_f || !packed_fwd_f || !packed_bwd_f || !grads_f) {
+      fn::set_error("fastnerf_render_rays_bwd_live: null pointer (fine pass)");
+      return -1;
+    }
+    if ((rc = pass(S1, z1, raw1, noise1, g_rgb, params_f, packed_fwd_f, packed_bwd_f, grads_f, c_fine))) return rc;
+    g_coarse = g_rgb0;
+  }
+  if (!g_coarse) {
+    fn::set_error("fastnerf_render_rays_bwd_live: null gradient");
+    return -1;
+  }
+  return pass(N_samples, z0, raw0, noise0, g_coarse, params_c, packed_fwd_c, packed_bwd_c, grads_c, c_coarse);
+}

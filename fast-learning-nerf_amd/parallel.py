@@ -63,3 +63,19 @@ def shard(n, rk=None, world=None):
 def barrier():
     if world_size() > 1:
         dist.barrier()
+
+
+def sync_seed():
+    """Rank 0 draws a seed from its torch CPU generator and every rank re-seeds torch (CPU + current GPU) and
+    numpy with it, so that RNG-driven host decisions made redundantly on every rank (the epoch's quadtree pixel
+    picks, the warm-up coordinates) are identical.  No-op for a single process.  Returns the seed (or None)."""
+    if world_size() <= 1:
+        return None
+    import numpy as np
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(dev)
+    dist.broadcast(t, src=0)
+    seed = int(t.item())
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    return seed

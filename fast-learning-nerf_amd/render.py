@@ -32,24 +32,98 @@ def _pytest_rand(shape, device):
 
 
 class _Workspace:
-    """Per-device scratch for the backward pass (activations are allocated per call; the
-    split-K partial buffer and the dact scratch are reused)."""
+    """Scratch for the backward pass, one set per (device, stream): kernels of one stream run in order, so reuse
+    across calls on that stream is safe, and two streams running backward concurrently never share a buffer."""
     _cache = {}
 
     @classmethod
+    def _key(cls, name, device):
+        return (name, str(device), torch.cuda.current_stream(device).cuda_stream)
+
+    @classmethod
     def partial(cls, device):
-        key = ('partial', str(device))
+        key = cls._key('partial', device)
         if key not in cls._cache:
             cls._cache[key] = torch.empty(ops.mlp_bwd_partial_floats(), device=device, dtype=torch.float32)
         return cls._cache[key]
 
     @classmethod
-    def dact(cls, device, floats):
-        key = ('dact', str(device))
+    def get(cls, name, device, count, dtype=torch.float32):
+        key = cls._key(name, device)
         t = cls._cache.get(key)
-        if t is None or t.numel() < floats:
-            cls._cache[key] = t = torch.empty(floats, device=device, dtype=torch.float32)
+        if t is None or t.numel() < count:
+            cls._cache[key] = t = torch.empty(count, device=device, dtype=dtype)
         return t
+
+    @classmethod
+    def dact(cls, device, floats):
+        return cls.get('dact', device, floats)
+
+
+# ---- exact zero-gradient point compaction of the training backward (csrc/train.hip, render.cpp) ----
+# FASTNERF_COMPACT = auto (default) | 1 | 0.  The compacted backward recomputes the forward of the live points
+# (forward work 1 + f, backward work f for a live fraction f), the plain one saves every activation in the first
+# forward (1, 1): compaction wins below f ~ 0.73.  `auto` starts compacted and follows the measured fraction.
+_COMPACT = os.environ.get('FASTNERF_COMPACT', 'auto')
+assert _COMPACT in ('auto', '0', '1'), 'FASTNERF_COMPACT must be auto, 0 or 1'
+
+
+def set_compact(mode):
+    global _COMPACT
+    assert mode in ('auto', '0', '1')
+    _COMPACT = mode
+
+
+def get_compact():
+    return _COMPACT
+
+
+class LivePolicy:
+    """Decides per step whether the backward runs compacted; fed with the (live, total) counters of compacted steps
+    through pinned-memory copies that are only read once their event has completed (never stalls the stream)."""
+    SWITCH_OFF, SWITCH_ON, EVERY, PROBE = 0.78, 0.70, 16, 256
+
+    def __init__(self):
+        self.frac = None          # last measured live fraction (both passes together)
+        self.on = True
+        self.step = 0
+        self._pending = None      # (pinned host tensor, event)
+
+    def available(self, net_c, net_f, N_importance):
+        return ops.get_math() == 'bf16x3' and (N_importance == 0 or (net_f is not None and net_f is not net_c))
+
+    def use_live(self, net_c, net_f, N_importance):
+        if _COMPACT == '0' or not self.available(net_c, net_f, N_importance):
+            return False
+        if _COMPACT == '1':
+            return True
+        self.poll()
+        if self.on:
+            return True
+        return self.step % self.PROBE == 0     # an occasional compacted step keeps the measurement alive
+
+    def poll(self):
+        if self._pending is not None and self._pending[1].query():
+            c = self._pending[0].tolist()
+            self._pending = None
+            tot = c[1] + c[3]
+            if tot > 0:
+                self.frac = (c[0] + c[2]) / tot
+                if self.on and self.frac > self.SWITCH_OFF:
+                    self.on = False
+                elif not self.on and self.frac < self.SWITCH_ON:
+                    self.on = True
+
+    def after_live_step(self, counts):
+        if self._pending is None and (self.step % self.EVERY == 0 or not self.on):
+            host = torch.empty(4, dtype=torch.int32).pin_memory()
+            host.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (host, ev)
+
+    def tick(self):
+        self.step += 1
 
 
 def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, perturb, white_bkgd, t_rand, u, noise0,
@@ -68,7 +142,7 @@ def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, pertur
                             seed1=_next_seed() if (N_importance > 0 and perturb and u is None) else 0, save=save)
     out = {}
     saved = {'rays11': rays11, 'z0': o['z0'], 'raw0': o['raw0'], 'act0': o['act0'], 'noise0': noise0, 'white': white_bkgd,
-             'net_c': net_c, 'net_f': None, 'pc': pc}
+             'net_c': net_c, 'net_f': None, 'pc': pc, 'live': not save}
     if N_importance > 0:
         out.update(rgb_map=o['rgb1'], disp_map=o['disp1'], acc_map=o['acc1'], raw=o['raw1'], rgb0=o['rgb0'], disp0=o['disp0'],
                    acc0=o['acc0'], z_std=o['z_std'], weights=o['w1'], z_vals=o['z1'], depth_map=o['depth1'],
@@ -80,9 +154,11 @@ def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, pertur
     return out, saved
 
 
-def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None):
+def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None, counts=None):
     """Writes d(loss)/d(params) of the coarse (and fine) net, given d(loss)/d(rgb maps), into
-    out_c / out_f (flat, parameter order; default: the nets' flat_grad buffers)."""
+    out_c / out_f (flat, parameter order; default: the nets' flat_grad buffers).  A forward that saved no activations
+    (saved['live']) is followed by the compacted backward; `counts` (int32[4], device) then receives the live / total
+    point counts of the fine and the coarse pass."""
     rays11 = saved['rays11']
     dev = rays11.device
     partial = _Workspace.partial(dev)
@@ -91,6 +167,21 @@ def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None):
     if net_f is not None and net_f is not net_c:
         out_f = out_f if out_f is not None else net_f.flat_grad
     n, S0 = saved['z0'].shape
+    if saved.get('live'):
+        assert net_f is None or net_f is not net_c, 'the compacted backward needs two distinct nets (or one pass)'
+        Ni = 0 if net_f is None else saved['z1'].shape[1] - S0
+        P = n * (S0 + Ni)
+        g_a = g_rgb if g_rgb is not None else torch.zeros(n, 3, device=dev)
+        g_b = (g_rgb0 if g_rgb0 is not None else torch.zeros(n, 3, device=dev)) if Ni > 0 else None
+        ws = _Workspace.dact(dev, ops.dact_floats(P) + P * 4)
+        draw_ws = ws[ops.dact_floats(P):]
+        act_ws = _Workspace.get('act', dev, ops.act_floats(P))
+        live_ws = _Workspace.get('live', dev, ops.live_ws_ints(P), torch.int32)
+        ops.render_rays_bwd_live(rays11, saved['white'], g_a, g_b, saved['noise0'], saved.get('noise1'), saved['z0'], saved['raw0'],
+                                 saved.get('z1'), saved.get('raw1'), net_c.flat, saved['pc'], None if Ni == 0 else net_f.flat,
+                                 None if Ni == 0 else saved['pf'], draw_ws, act_ws, ws, partial, live_ws, out_c,
+                                 out_f if Ni > 0 else None, S0, Ni, counts=counts)
+        return
     if net_f is None or net_f is not net_c:
         # one C-ABI call: compositing backward + MLP backward for the fine and the coarse pass
         Ni = 0 if net_f is None else saved['z1'].shape[1] - S0
@@ -118,6 +209,9 @@ def _backward_core(saved, g_rgb, g_rgb0, out_c=None, out_f=None):
     out_c.add_(gtmp)
 
 
+_POLICY = LivePolicy()   # the autograd route's policy (the fused Trainer keeps its own)
+
+
 def _grad_views(flat):
     return [flat[off:off + int(np.prod(shape))].view(shape) for _, off, shape in param_slices()]
 
@@ -128,7 +222,8 @@ class _RenderRaysFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, *params):
-        out, saved = _forward_core(save=True, **cfg)
+        live = _POLICY.use_live(cfg['net_c'], cfg['net_f'], cfg['N_importance'])
+        out, saved = _forward_core(save=not live, **cfg)
         ctx.saved = saved
         ctx.n_params = len(params)
         keys = ['rgb_map', 'disp_map', 'acc_map', 'raw'] + (['rgb0', 'disp0', 'acc0', 'z_std'] if 'rgb0' in out else [])
@@ -146,7 +241,11 @@ class _RenderRaysFn(torch.autograd.Function):
         two = saved['net_f'] is not None and saved['net_f'] is not saved['net_c']
         out_c = torch.empty_like(saved['net_c'].flat)
         out_f = torch.empty_like(saved['net_f'].flat) if two else None
-        _backward_core(saved, g.get('rgb_map'), g.get('rgb0'), out_c, out_f)
+        counts = _Workspace.get('counts', out_c.device, 4, torch.int32) if saved.get('live') else None
+        _backward_core(saved, g.get('rgb_map'), g.get('rgb0'), out_c, out_f, counts=counts)
+        if counts is not None:
+            _POLICY.after_live_step(counts)
+        _POLICY.tick()
         grads = list(_grad_views(out_c)) + (list(_grad_views(out_f)) if two else [])
         assert len(grads) == ctx.n_params
         return (None,) + tuple(grads)

@@ -17,7 +17,7 @@ import torch
 
 from . import ops, parallel
 from .model import NeRF
-from .render import _backward_core, _forward_core, render, render_path  # noqa: F401
+from .render import LivePolicy, _backward_core, _forward_core, render, render_path  # noqa: F401
 from .run_nerf_helpers import get_embedder, img2mse, mse2psnr
 from .tree import QuadTreeManager
 
@@ -107,8 +107,10 @@ def create_nerf(args, device='cuda'):
         d = os.path.join(args.basedir, args.expname)
         if os.path.isdir(d):
             ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if 'tar' in f]
+    create_nerf.last_ckpt_path = None
     if len(ckpts) > 0 and not args.no_reload:
         ckpt = torch.load(ckpts[-1], map_location=dev, weights_only=False)
+        create_nerf.last_ckpt_path = ckpts[-1]
         start_epoch, start_iter = ckpt['global_epoch'], ckpt['global_iter']
         optimizer.load_state_dict(ckpt['optimizer_state_dict'])
         model.load_state_dict(ckpt['network_fn_state_dict'])
@@ -158,6 +160,9 @@ class Trainer:
         self.adam_t = 0
         self.global_iter = 0
         self.world = parallel.world_size()
+        self.live = LivePolicy()   # exact zero-gradient point compaction of the backward (render.py)
+        self.live_counts = torch.zeros(4, device=self.flat.device, dtype=torch.int32)
+        self.last_step_live = False
         self.repack()
 
     def repack(self):
@@ -174,18 +179,28 @@ class Trainer:
         if self.raw_noise_std > 0.:
             noise0 = torch.randn(n, self.N_samples, device=dev) * self.raw_noise_std
             noise1 = torch.randn(n, self.N_samples + self.N_importance, device=dev) * self.raw_noise_std
+        live = self.live.use_live(self.net_c, self.net_f, self.N_importance)
         out, saved = _forward_core(rays11, self.net_c, self.net_f, self.N_samples, self.N_importance, self.lindisp,
-                                   self.perturb, self.white_bkgd, t_rand, u, noise0, noise1, save=True,
+                                   self.perturb, self.white_bkgd, t_rand, u, noise0, noise1, save=not live,
                                    packed_c=self.pc, packed_f=self.pf)
         scale = 1.0 if n_global is None else float(n) / float(n_global)
         loss2, g, g0 = ops.mse_leafmax(out['rgb_map'], out.get('rgb0'), target, grad_scale=scale, leaf_tag=leaf_tag,
                                        max_leaves=max_leaves, table=table)
-        _backward_core(saved, g, g0)
+        _backward_core(saved, g, g0, counts=self.live_counts if live else None)
+        if live:
+            self.live.after_live_step(self.live_counts)
+        self.live.tick()
+        self.last_step_live = live
         return loss2, out
 
     def step(self, rays_o, rays_d, target, leaf_tag=None, table=None, max_leaves=0, t_rand=None, u=None,
              n_global=None, decay=None):
-        loss2, out = self.forward_backward(rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global)
+        if rays_o.shape[0] == 0:
+            # a rank whose shard of a (tail) batch is empty still joins the collective with a zero gradient
+            self.grad.zero_()
+            loss2, out = torch.zeros(2, device=self.grad.device), {}
+        else:
+            loss2, out = self.forward_backward(rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global)
         if self.world > 1:
             parallel.all_reduce_sum(self.grad)
         self.adam_t += 1
@@ -245,6 +260,31 @@ class Trainer:
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v'])
         self.adam_t, self.global_iter, self.lr = sd['adam_t'], sd['global_iter'], sd['lr']
+
+
+def reference_state_dict(net):
+    """state_dict with the `module.` prefix of the nn.DataParallel wrapper the reference saves and strictly loads
+    (run_nerf.py:82,90,124-126,535-536)."""
+    return {'module.' + k: v for k, v in net.state_dict().items()}
+
+
+def tree_pkl_path(args, epoch):
+    """run_nerf.py:339,542."""
+    return os.path.join(args.basedir, args.expname, 'treeDivide_{:04d}.pkl'.format(epoch))
+
+
+def save_checkpoint(args, epoch_id, trainer, kw_train, mgr):
+    """run_nerf.py:532-544: `{epoch:03d}.tar` (global_epoch, global_iter, the two DataParallel state_dicts, the Adam
+    state in torch.optim's format) + `treeDivide_{epoch:04d}.pkl`.  Both files load in the reference."""
+    d = os.path.join(args.basedir, args.expname)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, '{:03d}.tar'.format(epoch_id))
+    torch.save({'global_epoch': epoch_id, 'global_iter': trainer.global_iter,
+                'network_fn_state_dict': reference_state_dict(kw_train['network_fn']),
+                'network_fine_state_dict': reference_state_dict(kw_train['network_fine']),
+                'optimizer_state_dict': trainer.torch_optimizer_state_dict()}, path)
+    mgr.save_trees(tree_pkl_path(args, epoch_id))
+    return path
 
 
 def load_dataset(args):
@@ -310,6 +350,10 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
     images = torch.as_tensor(images, dtype=torch.float32)
     poses = torch.as_tensor(poses, dtype=torch.float32)[:, :3, :4]
     mgr = QuadTreeManager(H, W, K, images, poses, mseThres=0.0, max_depth=args.init_level, device=dev)
+    # like the model, the subdivided trees of the checkpointed epoch are reloaded (run_nerf.py:338-345)
+    if os.path.exists(tree_pkl_path(args, start_epoch)):
+        mgr.load_trees(tree_pkl_path(args, start_epoch), cur_level=start_epoch)
+        log("load '" + tree_pkl_path(args, start_epoch) + "'")
     N_rand = args.N_rand
     rank, world = parallel.rank(), parallel.world_size()
     history = []
@@ -328,6 +372,7 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
                 break
         return loss2, it
 
+    parallel.sync_seed()   # every rank draws the same pixel lists (rows rank::world of ONE global batch)
     if start_epoch == 0:
         # center-crop warm-up (run_nerf.py:367-423): one coordinate set shared by all images, no LR decay
         dH, dW = H // 4, W // 4
@@ -344,6 +389,7 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
 
     for epoch_id in range(start_epoch + 1, args.n_epoch + 1):
         t0 = time.time()
+        parallel.sync_seed()
         last = epoch_id == args.n_epoch
         if last:
             mgr.epoch_size = mgr.n_images * mgr.h * mgr.w
@@ -361,11 +407,5 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
                 parallel.all_reduce_max_int(table)
             mgr.adjust_tree_from_table(table.view(mgr.n_images, max_leaves), thres=args.subdivide_thres)
         if rank == 0 and getattr(args, 'save_ckpt', False):
-            d = os.path.join(args.basedir, args.expname)
-            os.makedirs(d, exist_ok=True)
-            torch.save({'global_epoch': epoch_id, 'global_iter': trainer.global_iter,
-                        'network_fn_state_dict': kw_train['network_fn'].state_dict(),
-                        'network_fine_state_dict': kw_train['network_fine'].state_dict(),
-                        'optimizer_state_dict': trainer.torch_optimizer_state_dict(),
-                        'tree_leaves': mgr.export_leaves()}, os.path.join(d, '{:03d}.tar'.format(epoch_id)))
+            save_checkpoint(args, epoch_id, trainer, kw_train, mgr)
     return kw_train, kw_test, trainer, mgr, history

@@ -1,4 +1,4 @@
-"""Quadtree ray selection -- mirror of nerf-ours/tree.py's QuadTreeManager on a native backend.
+"""Quadtree ray selection -- mirror of nerf-ours/tree.py on a native backend.
 
 The reference keeps a Python object graph per image and scans every ray of the epoch once per leaf
 on the CPU (tree.py:629-652).  Here the trees are DFS leaf arrays in libfastnerf.so (host C++), the
@@ -7,17 +7,195 @@ per-(image, leaf) max |gt-pred| is reduced on the device while training runs
 gathering from [n,H,W,3] host arrays.  Leaf enumeration, per-leaf ray counts, pixel ranges and the
 split rule are bit-exact with the reference (tests/test_tree_*.py).
 
-API kept: QuadTreeManager(H, W, K, images, poses, mseThres, max_depth) (tree.py:161),
-gen_rays_v3_multiThread (:377-428), adjust_tree_multiThread (:533-557), attributes h, w, n_images,
-images, epoch_size, cur_level, result_leaf_id, childrens, origins, dirs.
+API kept (everything run_nerf.py touches):
+  QuadTreeManager(H, W, K, images, poses, mseThres, max_depth) (tree.py:161),
+  gen_rays_v3_multiThread (:377-428), adjust_tree_multiThread (:533-557), attributes h, w, n_images, images,
+  epoch_size, cur_level, result_leaf_id, origins, dirs, and -- as settable object VIEWS over the native leaf
+  arrays -- `quadTrees` (list of QuadTree, run_nerf.py:342,544) and `childrens` (list of lists of leaf
+  QuadTreeNode, run_nerf.py:343);
+  QuadTreeNode (:17-79), QuadTree (:82-99), recursive_subdivide (:655-676), get_children (:679-686);
+  save_quadtrees / load_quadtrees: the `treeDivide_{epoch:04d}.pkl` files of run_nerf.py:338-345,542-544,
+  written so that the reference's own `pickle.load` accepts them and reading the reference's files.
 """
-import ctypes as C
+import io
+import math
+import pickle
+import sys
+import types
 
 import numpy as np
 import torch
 
 from . import ops
 from ._lib import check, lib
+
+
+class QuadTreeNode:
+    """tree.py:17-79: a float box (x = row axis, y = column axis) and its four children (or [])."""
+
+    def __init__(self, x0, y0, x1, y1):
+        self.x0, self.y0, self.x1, self.y1 = x0, y0, x1, y1
+        self.children = []
+
+    @property
+    def area(self):
+        return (self.x1 - self.x0) * (self.y1 - self.y0)
+
+    def box(self):
+        return (self.x0, self.y0, self.x1, self.y1)
+
+    def get_error(self, img):
+        """tree.py:29-55: sum over the three channels of the population variance of the block's pixels
+        (rows ceil(x0)..floor(x1), columns ceil(y0)..floor(y1))."""
+        r0, r1 = math.ceil(self.x0), math.floor(self.x1)
+        c0, c1 = math.ceil(self.y0), math.floor(self.y1)
+        px = img[r0:r1, c0:c1, :]
+        if torch.is_tensor(px):
+            px = px.detach().cpu().numpy()
+        total = 0.0
+        for c in range(3):
+            ch = px[:, :, c]
+            total = total + np.square(np.subtract(ch, np.mean(ch))).mean()
+        return total
+
+    def subdivide_once(self):
+        """tree.py:57-72: midpoint split; child order (x0,y0,mx,my), (mx,y0,x1,my), (x0,my,mx,y1), (mx,my,x1,y1)."""
+        mx, my = (self.x0 + self.x1) / 2, (self.y0 + self.y1) / 2
+        self.children = [QuadTreeNode(self.x0, self.y0, mx, my), QuadTreeNode(mx, self.y0, self.x1, my),
+                         QuadTreeNode(self.x0, my, mx, self.y1), QuadTreeNode(mx, my, self.x1, self.y1)]
+
+    def __str__(self):
+        return "({:.1f}, {:.1f}), ({:.1f}, {:.1f})".format(self.x0, self.y0, self.x1, self.y1)
+
+
+def recursive_subdivide(node, thres, image, cur_depth, max_depth):
+    """tree.py:655-676: split while depth < max_depth and the block's colour variance is >= thres."""
+    if cur_depth >= max_depth or node.get_error(image) < thres:
+        return
+    node.subdivide_once()
+    for child in node.children:
+        recursive_subdivide(child, thres, image, cur_depth + 1, max_depth)
+
+
+def get_children(node):
+    """tree.py:679-686: the leaves below `node` in depth-first child order (= the leaf ids)."""
+    out, stack = [], [node]
+    while stack:
+        n = stack.pop()
+        if n.children:
+            stack.extend(reversed(n.children))
+        else:
+            out.append(n)
+    return out
+
+
+class QuadTree:
+    """tree.py:82-99.  `QuadTree(image, stdThres, max_depth)` builds the initial tree like the reference
+    (uniform when stdThres == 0); `QuadTree.from_leaves` rebuilds the node graph from a DFS leaf array."""
+
+    def __init__(self, image, stdThres, max_depth):
+        self.H, self.W = image.shape[:2]
+        self.threshold = stdThres
+        self.image = image
+        self.root = QuadTreeNode(0, 0, self.H, self.W)
+        recursive_subdivide(self.root, self.threshold, self.image, 1, max_depth)
+        self.minArea = self.H * self.W / (4 ** (max_depth - 1))
+
+    @classmethod
+    def from_leaves(cls, H, W, boxes, minArea, image=None, threshold=0.0):
+        """Inverse of get_children for trees made of midpoint splits: boxes [n,4] in DFS order."""
+        t = cls.__new__(cls)
+        t.H, t.W, t.threshold, t.image, t.minArea = H, W, threshold, image, minArea
+        boxes = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+        t.root = QuadTreeNode(0, 0, H, W)
+        pos = 0
+        stack = [(t.root, 0)]
+        while stack:
+            node, depth = stack.pop()
+            if pos >= boxes.shape[0]:
+                raise ValueError('leaf list ends before the tree is complete')
+            b = boxes[pos]
+            if node.x0 == b[0] and node.y0 == b[1] and node.x1 == b[2] and node.y1 == b[3]:
+                pos += 1
+                continue
+            if depth > 24:
+                raise ValueError('leaf list is not the DFS enumeration of a midpoint quadtree')
+            node.subdivide_once()
+            stack.extend((c, depth + 1) for c in reversed(node.children))
+        if pos != boxes.shape[0]:
+            raise ValueError('leaf list has {} entries beyond the tree'.format(boxes.shape[0] - pos))
+        return t
+
+    def leaf_array(self):
+        return np.array([n.box() for n in get_children(self.root)], dtype=np.float64).reshape(-1, 4)
+
+
+# ---- treeDivide_*.pkl (run_nerf.py:338-345, 542-544) -------------------------------------------------
+# The reference pickles `treeManager.quadTrees`, i.e. instances of ITS classes tree.QuadTree / tree.QuadTreeNode
+# (pickle records "module name + class name" and restores __dict__ without calling __init__).  Files written here
+# name the same two classes, so the reference's plain `pickle.load` rebuilds its own objects from them; files
+# written by the reference are read by mapping those two names onto the classes above.  The per-tree image copy the
+# reference drags along (7.7 MB per 800x800 view) is not written: nothing on the path reads QuadTree.image after
+# construction.
+_REF_MODULE = 'tree'
+
+
+def _reference_classes():
+    mod = sys.modules.get(_REF_MODULE)
+    if mod is not None and hasattr(mod, 'QuadTree') and hasattr(mod, 'QuadTreeNode'):
+        return mod.QuadTree, mod.QuadTreeNode, None
+    stub = types.ModuleType(_REF_MODULE)
+    T = type('QuadTree', (), {'__module__': _REF_MODULE})
+    N = type('QuadTreeNode', (), {'__module__': _REF_MODULE})
+    stub.QuadTree, stub.QuadTreeNode = T, N
+    return T, N, stub
+
+
+def save_quadtrees(trees, path):
+    """Write a list of QuadTree (e.g. `treeManager.quadTrees`) as `treeDivide_XXXX.pkl`."""
+    T, N, stub = _reference_classes()
+
+    def conv(node):
+        out = N.__new__(N)
+        out.__dict__.update(x0=node.x0, y0=node.y0, x1=node.x1, y1=node.y1, children=[conv(c) for c in node.children])
+        return out
+    objs = []
+    for t in trees:
+        o = T.__new__(T)
+        o.__dict__.update(H=t.H, W=t.W, threshold=t.threshold, image=None, root=conv(t.root), minArea=t.minArea)
+        objs.append(o)
+    prev = sys.modules.get(_REF_MODULE)
+    if stub is not None:
+        sys.modules[_REF_MODULE] = stub
+    try:
+        data = pickle.dumps(objs, protocol=2)
+    finally:
+        if stub is not None:
+            if prev is None:
+                sys.modules.pop(_REF_MODULE, None)
+            else:
+                sys.modules[_REF_MODULE] = prev
+    with open(path, 'wb') as f:
+        f.write(data)
+
+
+class _TreeUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if name == 'QuadTree' and module.split('.')[-1] == 'tree':
+            return QuadTree
+        if name == 'QuadTreeNode' and module.split('.')[-1] == 'tree':
+            return QuadTreeNode
+        return super().find_class(module, name)
+
+
+def load_quadtrees(path):
+    """Read a `treeDivide_XXXX.pkl` written by save_quadtrees OR by the reference (run_nerf.py:542-544)."""
+    with open(path, 'rb') as f:
+        trees = _TreeUnpickler(io.BytesIO(f.read())).load()
+    for t in trees:
+        if not isinstance(t, QuadTree):
+            raise TypeError('{} does not hold a list of QuadTree'.format(path))
+    return trees
 
 
 class QuadTreeManager:
@@ -29,9 +207,6 @@ class QuadTreeManager:
         self.criterion = criterion
         self._sharp_in = sharp_imgs
         self.processor = None
-        if mseThres != 0.0:
-            raise NotImplementedError('variance-gated initial subdivision (mseThres>0) is never used by the '
-                                      'reference driver (run_nerf.py:337 passes 0.0)')
         self.h, self.w = int(H), int(W)
         self.K = np.asarray(K, dtype=np.float64)
         self.n_images = int(poses.shape[0])
@@ -43,6 +218,12 @@ class QuadTreeManager:
         self._t = lib().fastnerf_tree_create(self.h, self.w, self.n_images, int(max_depth))
         if not self._t:
             raise RuntimeError('fastnerf_tree_create failed')
+        self._views = None           # cached QuadTree views of the native leaf arrays (invalidated by every change)
+        if mseThres != 0.0:
+            # variance-gated initial subdivision (tree.py:101-156 with get_error; the reference driver always passes
+            # 0.0): built by the Python mirror above, then handed to the native arrays like a loaded pickle
+            imgs_np = self.images.cpu().numpy()
+            self.quadTrees = [QuadTree(imgs_np[i], mseThres, max_depth) for i in range(self.n_images)]
         self.result_leaf_id = None   # [N,2] float32 (image, leaf), as the reference stores it
         self.result_leaf_tag = None  # [N,2] int32 on the device (what the kernels consume)
         self._dev_images = None
@@ -73,9 +254,39 @@ class QuadTreeManager:
         check(lib().fastnerf_tree_get_leaves(self._t, i, out.ctypes.data), 'fastnerf_tree_get_leaves')
         return out
 
+    # `quadTrees` / `childrens` (tree.py:183-193) are object views of the native state: reading builds (and caches)
+    # QuadTree / QuadTreeNode graphs from the leaf arrays; ASSIGNING (what run_nerf.py:342-343 does after
+    # pickle.load) writes the leaves + minArea back into the native arrays.  Mutating a returned node in place does
+    # not reach the native side -- assign the list back.
+    def _tree_views(self):
+        if self._views is None:
+            self._views = [QuadTree.from_leaves(self.h, self.w, self.leaves(i), self.min_area(i))
+                           for i in range(self.n_images)]
+        return self._views
+
+    @property
+    def quadTrees(self):
+        return self._tree_views()
+
+    @quadTrees.setter
+    def quadTrees(self, trees):
+        trees = list(trees)
+        if len(trees) != self.n_images:
+            raise ValueError('expected {} trees, got {}'.format(self.n_images, len(trees)))
+        self.import_leaves([(np.array([[n.x0, n.y0, n.x1, n.y1] for n in get_children(t.root)], dtype=np.float64),
+                             t.minArea) for t in trees])
+
     @property
     def childrens(self):
-        return [self.leaves(i) for i in range(self.n_images)]
+        return [get_children(t.root) for t in self._tree_views()]
+
+    @childrens.setter
+    def childrens(self, lists):
+        lists = list(lists)
+        if len(lists) != self.n_images:
+            raise ValueError('expected {} leaf lists, got {}'.format(self.n_images, len(lists)))
+        self.import_leaves([(np.array([[n.x0, n.y0, n.x1, n.y1] for n in leaves], dtype=np.float64).reshape(-1, 4),
+                             self.min_area(i)) for i, leaves in enumerate(lists)])
 
     def export_leaves(self):
         return [(self.leaves(i), self.min_area(i)) for i in range(self.n_images)]
@@ -85,6 +296,17 @@ class QuadTreeManager:
             b = np.ascontiguousarray(boxes, dtype=np.float64)
             check(lib().fastnerf_tree_set_leaves(self._t, i, b.shape[0], b.ctypes.data, float(min_area)),
                   'fastnerf_tree_set_leaves')
+        self._views = None
+
+    def save_trees(self, path):
+        """run_nerf.py:542-544: `pickle.dump(treeManager.quadTrees, f)` in the reference's own class names."""
+        save_quadtrees(self.quadTrees, path)
+
+    def load_trees(self, path, cur_level=None):
+        """run_nerf.py:339-345."""
+        self.quadTrees = load_quadtrees(path)
+        if cur_level is not None:
+            self.cur_level = cur_level
 
     def leaf_plan(self, i, ray_num_per_pixel, last_epoch=False):
         """[n,5] int32: ray count, row_lo, row_hi, col_lo, col_hi (tree.py:578-581,598-599)."""
@@ -270,6 +492,7 @@ class QuadTreeManager:
         assert t.shape[0] == self.n_images
         tot = check(lib().fastnerf_tree_adjust(self._t, t.data_ptr(), int(t.shape[1]), float(thres)),
                     'fastnerf_tree_adjust')
+        self._views = None
         self.cur_level += 1
         return int(tot)
 
@@ -280,6 +503,7 @@ class QuadTreeManager:
         c = counts.detach().to(torch.int32).cpu().contiguous().view(self.n_images, -1)
         tot = check(lib().fastnerf_tree_adjust_mean(self._t, s.data_ptr(), c.data_ptr(), int(s.shape[1]), float(thres)),
                     'fastnerf_tree_adjust_mean')
+        self._views = None
         self.cur_level += 1
         return int(tot)
 

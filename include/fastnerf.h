@@ -224,6 +224,38 @@ int64_t fastnerf_tree_adjust(fn_tree* t, const float* table_host, int max_leaves
 int64_t fastnerf_tree_adjust_mean(fn_tree* t, const double* sum_host, const int32_t* count_host, int max_leaves,
                                   double thres);
 
+
+/* ---- exact zero-gradient point compaction of the training backward -------------------------------------------
+ * loss.backward() (run_nerf.py:493) spends most of its time on samples whose d(loss)/d(raw) is exactly zero
+ * (sigma + noise <= 0 => alpha = 0 => weight = 0 and relu' = 0; render.py:162,182): all of their pre-activation
+ * gradients are exact zeros.  These entry points run the backward on the other ("live") samples only.
+ * fastnerf_compact_live: live_idx[0..count) = ascending indices of the points p with draw[p*4..p*4+3] != 0,
+ * count_out[0] = count, count_out[1] = n_points (device values: no host round trip).  ws: fastnerf_compact_ws_ints()
+ * int32 of scratch. */
+int64_t fastnerf_compact_ws_ints(int64_t n_points);
+int fastnerf_compact_live(int64_t n_points, const float* draw, int32_t* live_idx, int32_t* count_out, int32_t* ws,
+                          fn_stream_t stream);
+/* NeRF.forward + Embedder.embed (model.py:38-63) over a live list, saving activations for the backward in list
+ * order; act sized by fastnerf_mlp_bf16_floats(kind, 3, n*S). */
+int fastnerf_mlp_bf16_fwd_live(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                               const float* packed_fwd, float* act, const int32_t* live_idx, const int32_t* live_cnt,
+                               fn_stream_t stream);
+/* backward of the MLP over the same list: draw is the full [n*S,4] gradient, read through live_idx. */
+int fastnerf_mlp_bf16_bwd_live(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                               const float* packed_bwd, float* dact, float* partial, float* grads,
+                               const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream);
+/* the whole backward of render_rays (render.py:238-299 under loss.backward()) with compaction, for a forward that
+ * saved nothing: per pass compositing backward -> live list -> saving forward over the list -> dX / dW.
+ * live_ws: 4 + n*(N_samples+N_importance) + fastnerf_compact_ws_ints(...) int32; counts_out: NULL or 4 int32
+ * (live, total of the fine pass; live, total of the coarse pass). */
+int fastnerf_render_rays_bwd_live(int64_t n, int N_samples, int N_importance, const float* rays11, int white_bkgd,
+                                  const float* g_rgb, const float* g_rgb0, const float* noise0, const float* noise1,
+                                  const float* z0, const float* raw0, const float* z1, const float* raw1,
+                                  const float* params_c, const float* packed_fwd_c, const float* packed_bwd_c,
+                                  const float* params_f, const float* packed_fwd_f, const float* packed_bwd_f,
+                                  float* draw_ws, float* act_ws, float* dact_ws, float* partial_ws, int32_t* live_ws,
+                                  float* grads_c, float* grads_f, int32_t* counts_out, fn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

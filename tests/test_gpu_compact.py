@@ -1,0 +1,246 @@
+"""Exact zero-gradient point compaction of the training backward (csrc/train.hip cp_*, the *_live entry points,
+render.cpp fastnerf_render_rays_bwd_live).
+
+What is shown, in this order:
+  1. the live list is exactly the ascending list of points with a non-zero d(loss)/d(raw);
+  2. a point with a zero d(loss)/d(raw) contributes EXACTLY nothing: the plain backward is bit-invariant to what such
+     points are (their inputs are replaced by garbage);
+  3. the live-list kernels are bit-identical to the plain kernels run on the batch made of the live points only
+     (same tiles, same order) -- including the list of all points, and an empty list;
+  => the compacted gradient differs from the plain one only by fp32 summation grouping in dW (bounded below), and is
+     compared with the CPU oracle's autograd like the plain one;
+  4. whole training steps with and without compaction: identical losses (the forward is the same arithmetic), gradients
+     to rounding, trajectories together; counters and the auto policy."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def fn():
+    import fastnerf
+    return fastnerf
+
+
+@pytest.fixture(scope='module')
+def weights(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g7_weights.npz'))
+    return {k[2:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith('c.')}
+
+
+@pytest.fixture()
+def bf16(fn):
+    old = fn.ops.get_math()
+    fn.ops.set_math('bf16x3')
+    yield
+    fn.ops.set_math(old)
+
+
+def flat_of(sd):
+    return torch.cat([sd[n].reshape(-1) for n, _ in O.nerf_param_shapes()])
+
+
+@pytest.mark.parametrize('P,frac', [(1, 1.0), (1, 0.0), (1023, 0.5), (1024, 0.5), (1025, 0.3), (4096 * 192, 0.45), (70001, 1.0), (70001, 0.0)])
+def test_compact_live_list(fn, P, frac):
+    gen = torch.Generator().manual_seed(P)
+    draw = torch.randn(P, 4, generator=gen)
+    dead = torch.rand(P, generator=gen) >= frac
+    draw[dead] = 0.0
+    draw[dead & (torch.rand(P, generator=gen) < 0.3)] = -0.0          # negative zeros are zeros
+    one = (~dead) & (torch.rand(P, generator=gen) < 0.2)              # a single non-zero component keeps a point alive
+    draw[one] = 0.0
+    draw[one, 3] = 1e-30
+    idx, cnt = fn.ops.compact_live(draw.cuda())
+    want = torch.nonzero((draw != 0).any(1)).reshape(-1).int()
+    c = cnt.cpu().tolist()
+    assert c == [want.numel(), P]
+    assert torch.equal(idx.cpu()[:c[0]], want)
+
+
+def _setup(fn, weights, n, S, seed, dead_frac):
+    gen = torch.Generator().manual_seed(seed)
+    ro = torch.randn(n, 3, generator=gen) * 0.4
+    rd = torch.randn(n, 3, generator=gen)
+    rb = O.make_ray_batch(ro, rd, 2.0, 6.0)
+    z = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, -1).values
+    cot = torch.randn(n, S, 4, generator=gen)
+    dead = torch.rand(n, S, generator=gen) < dead_frac
+    cot[dead] = 0.0
+    flat = flat_of(weights).cuda()
+    pf, pb = fn.ops.mlp_pack(flat)
+    return rb, z, cot, dead, flat, pf, pb
+
+
+def _plain(fn, rb, z, cot, flat, pf, pb):
+    n, S = z.shape
+    act = torch.empty(fn.ops.act_floats(n * S)).cuda()
+    fn.ops.mlp_fwd(rb.cuda(), z.cuda(), flat, pf, act=act)
+    dact = torch.empty(fn.ops.dact_floats(n * S)).cuda()
+    partial = torch.empty(fn.ops.mlp_bwd_partial_floats()).cuda()
+    g = torch.full((fn.ops.NET_PARAMS,), float('nan')).cuda()
+    fn.ops.mlp_bwd(cot.cuda(), act, flat, pb, dact, partial, g)
+    return g
+
+
+def _live(fn, rb, z, cot, flat, pf, pb, idx=None, cnt=None):
+    n, S = z.shape
+    if idx is None:
+        idx, cnt = fn.ops.compact_live(cot.cuda())
+    act = torch.full((fn.ops.act_floats(n * S),), float('nan')).cuda()      # stale scratch must not matter
+    dact = torch.full((fn.ops.dact_floats(n * S),), float('nan')).cuda()
+    fn.ops.mlp_fwd_live(rb.cuda(), z.cuda(), flat, pf, act, idx, cnt)
+    partial = torch.empty(fn.ops.mlp_bwd_partial_floats()).cuda()
+    g = torch.full((fn.ops.NET_PARAMS,), float('nan')).cuda()
+    fn.ops.mlp_bwd_live(cot.cuda(), act, flat, pb, dact, partial, g, idx, cnt)
+    return g, idx, cnt
+
+
+@pytest.mark.parametrize('n,S,dead_frac', [(9, 50, 0.5), (64, 192, 0.55), (300, 64, 0.97), (7, 9, 0.4)])
+def test_dead_points_contribute_exact_zeros_and_live_kernels_are_the_plain_kernels(fn, weights, bf16, n, S, dead_frac):
+    rb, z, cot, dead, flat, pf, pb = _setup(fn, weights, n, S, 11 * n + S, dead_frac)
+    g_plain = _plain(fn, rb, z, cot, flat, pf, pb)
+    assert torch.isfinite(g_plain).all()
+    # (2) garbage at the dead points: bit-identical gradient
+    z_bad = z.clone()
+    z_bad[dead] = torch.rand(int(dead.sum())) * 40 - 20
+    assert torch.equal(_plain(fn, rb, z_bad, cot, flat, pf, pb), g_plain)
+    # (3) live kernels == plain kernels on the batch of the live points (one "ray" per point, S = 1)
+    g_live, idx, cnt = _live(fn, rb, z, cot, flat, pf, pb)
+    k = int(cnt[0])
+    assert k == int((~dead).sum()) and torch.isfinite(g_live).all()
+    sel = idx[:k].long().cpu()
+    rb_g = rb[sel // S].contiguous()
+    z_g = z.reshape(-1)[sel].reshape(-1, 1).contiguous()
+    cot_g = cot.reshape(-1, 4)[sel].reshape(-1, 1, 4).contiguous()
+    assert torch.equal(_plain(fn, rb_g, z_g, cot_g, flat, pf, pb), g_live)
+    # => compacted vs plain: only the grouping of fp32 partial sums differs
+    scale = g_plain.abs().max().item()
+    assert (g_live - g_plain).abs().max().item() < 3e-6 * scale, ((g_live - g_plain).abs().max().item(), scale)
+    # and against the oracle's autograd, like the plain kernels (tests/test_gpu_mlp.py)
+    if n * S <= 20000:
+        sd = {kk: v.clone().requires_grad_(True) for kk, v in weights.items()}
+        pts = rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None]
+        out = O.run_network(sd, pts, rb[:, 8:11])
+        ref = torch.cat([t.reshape(-1) for t in torch.autograd.grad((out * cot).sum(), list(sd.values()))])
+        off = 0
+        for (name, shape) in O.nerf_param_shapes():
+            kk = int(np.prod(shape))
+            r = ref[off:off + kk]
+            err = (g_live.cpu()[off:off + kk] - r).abs().max().item()
+            assert err < 2e-5 * max(1.0, r.abs().max().item()), (name, err)
+            off += kk
+
+
+def test_live_list_of_everything_and_of_nothing(fn, weights, bf16):
+    rb, z, cot, dead, flat, pf, pb = _setup(fn, weights, 33, 40, 5, 0.0)
+    g_plain = _plain(fn, rb, z, cot, flat, pf, pb)
+    g_live, idx, cnt = _live(fn, rb, z, cot, flat, pf, pb)
+    assert cnt.cpu().tolist() == [33 * 40, 33 * 40] and torch.equal(g_live, g_plain)
+    g_none, _, cnt0 = _live(fn, rb, z, torch.zeros_like(cot), flat, pf, pb)
+    assert cnt0.cpu().tolist() == [0, 33 * 40] and torch.count_nonzero(g_none) == 0
+    # a list that is a permutation: the kernels follow the list order (results = plain on the permuted batch)
+    perm = torch.randperm(33 * 40, generator=torch.Generator().manual_seed(1)).int().cuda()
+    g_perm, _, _ = _live(fn, rb, z, cot, flat, pf, pb, idx=perm, cnt=cnt)
+    sel = perm.long().cpu()
+    g_ref = _plain(fn, rb[sel // 40].contiguous(), z.reshape(-1)[sel].reshape(-1, 1).contiguous(),
+                   cot.reshape(-1, 4)[sel].reshape(-1, 1, 4).contiguous(), flat, pf, pb)
+    assert torch.equal(g_perm, g_ref)
+
+
+def _trainer(fn, golden_dir, compact):
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    g = np.load(os.path.join(golden_dir, 'g7_weights.npz'))
+    args = fn.run_nerf.make_args(N_importance=128, N_samples=64, perturb=1.0, white_bkgd=True, no_reload=True)
+    torch.manual_seed(0)
+    ktr, _, _, _, _, _ = fn.run_nerf.create_nerf(args)
+    ktr['network_fn'].load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('c.')})
+    ktr['network_fine'].load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('f.')})
+    fn.render.set_compact(compact)
+    return fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0), K
+
+
+def test_training_steps_with_and_without_compaction(fn, golden_dir, bf16):
+    old = fn.render.get_compact()
+    try:
+        imgs, poses, focal = fn.synthetic.make_dataset(n_images=2, H=48, W=48)
+        K48 = np.array([[focal, 0, 24.0], [0, focal, 24.0], [0, 0, 1]])
+        rays = [fn.run_nerf_helpers.get_rays(48, 48, K48, poses[i]) for i in range(2)]
+        ro = torch.cat([r[0].reshape(-1, 3) for r in rays], 0)
+        rd = torch.cat([r[1].reshape(-1, 3) for r in rays], 0)
+        tgt = imgs.reshape(-1, 3).cuda()
+        gen = torch.Generator().manual_seed(3)
+        res = {}
+        for mode in ('0', '1'):
+            tr, _ = _trainer(fn, golden_dir, mode)
+            losses, gnorm = [], []
+            g2 = torch.Generator().manual_seed(9)
+            for it in range(12):
+                sel = torch.randint(0, ro.shape[0], (1024,), generator=g2).cuda()
+                t_rand = torch.rand(1024, 64, generator=g2).cuda()
+                u = torch.rand(1024, 128, generator=g2).cuda()
+                if it == 0:
+                    loss2, _ = tr.forward_backward(ro[sel], rd[sel], tgt[sel], t_rand=t_rand, u=u)
+                    g_first = tr.grad.clone()
+                    assert tr.last_step_live == (mode == '1')
+                    if mode == '1':
+                        c = tr.live_counts.cpu().tolist()
+                        assert c[1] == 1024 * 192 and c[3] == 1024 * 64 and 0 < c[0] < c[1] and 0 < c[2] < c[3]
+                        res['frac'] = (c[0] + c[2]) / (c[1] + c[3])
+                loss2, _ = tr.step(ro[sel], rd[sel], tgt[sel], t_rand=t_rand, u=u)
+                losses.append(loss2.cpu().tolist())
+            res[mode] = (g_first, losses, tr.flat.clone())
+        ga, gb = res['0'][0], res['1'][0]
+        assert res['0'][1][0] == res['1'][1][0]                                   # same forward arithmetic: identical losses
+        assert (ga - gb).abs().max().item() < 3e-6 * ga.abs().max().item()         # same gradient up to summation grouping
+        la, lb = np.array(res['0'][1]), np.array(res['1'][1])
+        assert np.abs(la - lb).max() < 2e-4 * la.max() and lb[-1, 0] < lb[0, 0]    # trajectories stay together, and train
+        assert 0.2 < res['frac'] < 0.9
+    finally:
+        fn.render.set_compact(old)
+
+
+def test_autograd_route_and_policy(fn, golden_dir, bf16):
+    """render(...); loss.backward() picks the compacted backward too; `auto` follows the measured live fraction."""
+    old = fn.render.get_compact()
+    try:
+        tr, K = _trainer(fn, golden_dir, '1')
+        ktr = dict(network_fn=tr.net_c, network_fine=tr.net_f, N_samples=64, N_importance=128, perturb=1.0, white_bkgd=True,
+                   raw_noise_std=0., use_viewdirs=True, ndc=False, lindisp=False, network_query_fn=None)
+        gen = torch.Generator().manual_seed(2)
+        c2w = O.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+        ro, rd = fn.run_nerf_helpers.get_rays(800, 800, K, c2w)
+        sel = torch.randint(0, 640000, (512,), generator=gen).cuda()
+        rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        tgt = torch.rand(512, 3, generator=gen).cuda()
+        grads = {}
+        for mode in ('0', '1'):
+            fn.render.set_compact(mode)
+            for p in list(tr.net_c.parameters()) + list(tr.net_f.parameters()):
+                p.grad = None
+            rgb, disp, acc, ex = fn.render.render(800, 800, K, chunk=32768, rays=rays, retraw=True, near=2.0, far=6.0,
+                                                  pytest=True, **ktr)
+            loss = fn.run_nerf_helpers.img2mse(rgb, tgt) + fn.run_nerf_helpers.img2mse(ex['rgb0'], tgt)
+            loss.backward()
+            grads[mode] = torch.cat([p.grad.reshape(-1) for p in list(tr.net_c.parameters()) + list(tr.net_f.parameters())])
+        assert (grads['0'] - grads['1']).abs().max().item() < 3e-6 * grads['0'].abs().max().item()
+        # the policy: a high measured fraction switches compaction off, a low one back on; probes keep measuring
+        pol = fn.render.LivePolicy()
+        fn.render.set_compact('auto')
+        assert pol.use_live(tr.net_c, tr.net_f, 128)
+        for frac, want in ((0.9, False), (0.75, False), (0.5, True), (0.74, True)):
+            pol._pending = (torch.tensor([int(frac * 1000), 1000, 0, 0], dtype=torch.int32), torch.cuda.Event())
+            pol._pending[1].record(); torch.cuda.synchronize()
+            pol.step = 1
+            assert pol.use_live(tr.net_c, tr.net_f, 128) == want and abs(pol.frac - frac) < 1e-3
+        pol.on, pol.step = False, pol.PROBE
+        assert pol.use_live(tr.net_c, tr.net_f, 128)                       # probe step
+        fn.ops.set_math('fp32')
+        assert not pol.use_live(tr.net_c, tr.net_f, 128)                   # the exact-fp32 mode keeps the plain backward
+    finally:
+        fn.render.set_compact(old)
