@@ -2,11 +2,12 @@
 """bench.py -- training rays/s of the MI355X-native NeRF inner loop (BASELINE.json metric).
 
 A "step" = one full optimisation step (ray packing -> stratified + hierarchical sampling -> PE ->
-coarse/fine MLP -> compositing -> 2xMSE + leaf-error table -> backward -> [RCCL all-reduce] ->
-Adam + LR decay) on 4096 rays x (64 + 128) samples per GPU, i.e. BASELINE.json configs[1]
-("nerf-ours Lego full 800x800, 4096 rays, 64+128 samples"), synthetic Lego-like cameras
+coarse/fine MLP -> compositing -> 2xMSE + per-(image, leaf) error table (atomicMax) -> backward ->
+[RCCL all-reduce] -> Adam + LR decay) on 4096 rays x (64 + 128) samples per GPU, i.e. BASELINE.json
+configs[1] ("nerf-ours Lego full 800x800, 4096 rays, 64+128 samples"), synthetic Lego-like cameras
 (100 x pose_spherical, 800x800, focal 1111.11, near 2 / far 6), U[0,1) targets, default-init
-weights (seed 0).  Inputs are resident in HBM before the timed region.
+weights (seed 0), quadtree leaf tags of a depth-5 tree (256 leaves per image).  Inputs are resident
+in HBM before the timed region.  The GPU legs import nothing from oracle/; only `cpu_baseline` does.
 
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
@@ -25,47 +26,84 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_RAYS, N_SAMPLES, N_IMPORTANCE = 4096, 64, 128
+S1 = N_SAMPLES + N_IMPORTANCE
 MAC_PER_POINT = 593408
 FWD_FLOP_PER_POINT = 2 * MAC_PER_POINT     # 1.186816 MFLOP
-TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)  # 893.2 MFLOP
+TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + S1)  # 893.2 MFLOP
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 matrix peak
+PROFILE_ROUND = 'r02'
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (a port of the reference's step, validated against it by tests/) timed on the
-    host cores of this box on a bounded sample of the same workload: full 64+128 samples per ray,
-    fewer rays per step."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(protocol='full'):
+    """The CPU oracle (a port of the reference's step, validated against it by tests/) timed on the host cores of this
+    box, SURVEY §8(d) protocol: the identical step (64+128 samples, fp32) at N = 1024 rays, 3 warm-up + 10 timed steps,
+    median; with 32 threads (where torch's CPU GEMMs peak on this box) and with every core; N = 4096 as a short
+    confirmation (1 + 2 steps).  `--cpu-protocol short` = 1 + 3 steps of 256 rays (for quick runs)."""
     from oracle import nerf_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))   # torch's CPU GEMMs stop scaling (and start thrashing) beyond this
-    torch.set_num_threads(cores)
-    n = 256
     gen = torch.Generator().manual_seed(0)
     sdc, sdf = O.init_nerf_params(gen), O.init_nerf_params(gen)
     opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
     c2w = O.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
     K = O.intrinsics(800, 800, 1111.111)
     ro, rd = O.get_rays(800, 800, K, c2w)
-    sel = torch.randint(0, 640000, (n,), generator=gen)
-    rb = O.make_ray_batch(ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], 2.0, 6.0)
-    tgt = torch.rand(n, 3, generator=gen)
-    times = []
-    t_start = time.time()
-    for it in range(16):   # ~0.8 s per step on 32 cores: 10-15 s of CPU work, bounded by seconds_budget
-        t_rand, u = torch.rand(n, N_SAMPLES, generator=gen), torch.rand(n, N_IMPORTANCE, generator=gen)
-        t0 = time.time()
-        O.train_step(sdc, sdf, opt, rb, tgt, N_SAMPLES, N_IMPORTANCE, True, t_rand=t_rand, u=u)
-        times.append(time.time() - t0)
-        if it >= 1 and time.time() - t_start > seconds_budget:
-            break
-    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return {'value': n / med, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{len(times) - 1} timed steps of {n} rays x (64+128) samples, torch CPU fp32, '
-                      f'{cores} threads of {avail} available (oracle/nerf_oracle.py train_step)'}
+
+    def run(n, threads, warm, timed):
+        torch.set_num_threads(threads)
+        sel = torch.randint(0, 640000, (n,), generator=gen)
+        rb = O.make_ray_batch(ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], 2.0, 6.0)
+        tgt = torch.rand(n, 3, generator=gen)
+        times = []
+        for it in range(warm + timed):
+            t_rand, u = torch.rand(n, N_SAMPLES, generator=gen), torch.rand(n, N_IMPORTANCE, generator=gen)
+            t0 = time.time()
+            O.train_step(sdc, sdf, opt, rb, tgt, N_SAMPLES, N_IMPORTANCE, True, t_rand=t_rand, u=u)
+            times.append(time.time() - t0)
+        return n / float(np.median(times[warm:]))
+
+    t32 = max(1, min(avail, 32))
+    if protocol == 'short':
+        v = run(256, t32, 1, 3)
+        return {'value': v, 'unit': 'rays/s', 'cores': t32, 'kind': 'port', 'cpu': cpu_model(), 'cores_available': avail,
+                'sample': f'1 warm-up + 3 timed steps of 256 rays x (64+128) samples, median, torch CPU fp32, {t32} threads '
+                          '(oracle/nerf_oracle.py train_step)'}
+    v32 = run(1024, t32, 3, 10)
+    vall = run(1024, avail, 2, 5) if avail > t32 else v32
+    v4096 = run(4096, t32, 1, 2)
+    best, cores = (v32, t32) if v32 >= vall else (vall, avail)
+    return {'value': best, 'unit': 'rays/s', 'cores': cores, 'kind': 'port', 'cpu': cpu_model(), 'cores_available': avail,
+            'rays_per_s_32_threads_n1024': v32, 'rays_per_s_all_cores_n1024': vall, 'rays_per_s_32_threads_n4096': v4096,
+            'sample': f'SURVEY 8(d): N=1024 rays x (64+128) samples per step, 3 warm-up + 10 timed steps, median, torch CPU '
+                      f'fp32 with {t32} threads; 2 + 5 steps with all {avail} cores; 1 + 2 steps at N=4096 '
+                      '(oracle/nerf_oracle.py train_step); value = the better of the two thread counts'}
+
+
+def time_launch(fn_, reps):
+    """Average duration (ms) of reps back-to-back calls of fn_ on torch's current stream (= the stream the kernels are
+    launched on: ops.* pass torch.cuda.current_stream() through the C ABI), HIP events."""
+    for _ in range(2):
+        fn_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn_()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def main():
@@ -73,12 +111,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--sustained-steps', type=int, default=400)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-protocol', choices=['full', 'short'], default='full')
     a = ap.parse_args()
 
     import fastnerf
     from fastnerf import ops, parallel
-    from oracle import nerf_oracle as O
+    from fastnerf.synthetic import pose_spherical
     rank, world, local = parallel.init_from_env('cuda')
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
     local = local % max(1, torch.cuda.device_count())   # (only differs in single-GPU plumbing tests of the N>1 path)
@@ -92,21 +132,25 @@ def main():
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
-    poses = torch.stack([O.pose_spherical(-180.0 + 3.6 * k, -30.0, 4.0)[:3, :4] for k in range(100)], 0).to(dev)
+    n_img, max_leaves = 100, 256
+    poses = torch.stack([pose_spherical(-180.0 + 3.6 * k, -30.0, 4.0)[:3, :4] for k in range(n_img)], 0).to(dev)
     gen = torch.Generator().manual_seed(1000 + rank)
     n_batches = 8
     batches = []
     for _ in range(n_batches):
-        pix = torch.stack([torch.randint(0, 100, (N_RAYS,), generator=gen), torch.randint(0, H, (N_RAYS,), generator=gen),
-                           torch.randint(0, W, (N_RAYS,), generator=gen)], 1).int().to(dev)
-        ro, rd = ops.gen_rays_pixels(pix, poses, K)
-        batches.append((ro, rd, torch.rand(N_RAYS, 3, generator=gen).to(dev)))
+        pix = torch.stack([torch.randint(0, n_img, (N_RAYS,), generator=gen), torch.randint(0, H, (N_RAYS,), generator=gen),
+                           torch.randint(0, W, (N_RAYS,), generator=gen)], 1).int()
+        ro, rd = ops.gen_rays_pixels(pix.to(dev), poses, K)
+        # (image, leaf) tags of a depth-5 quadtree: 16 x 16 leaves of 50 x 50 pixels, DFS order irrelevant for timing
+        tag = torch.stack([pix[:, 0], (pix[:, 1] // 50) * 16 + pix[:, 2] // 50], 1).int().to(dev).contiguous()
+        batches.append((ro, rd, torch.rand(N_RAYS, 3, generator=gen).to(dev), tag))
+    table = torch.zeros(n_img * max_leaves, device=dev, dtype=torch.int32)
     tr = fastnerf.run_nerf.Trainer(ktr, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
     n_global = N_RAYS * world if world > 1 else None
 
-    def step(i):
-        ro, rd, tgt = batches[i % n_batches]
-        return tr.step(ro, rd, tgt, n_global=n_global)
+    def step(i, trainer=tr):
+        ro, rd, tgt, tag = batches[i % n_batches]
+        return trainer.step(ro, rd, tgt, leaf_tag=tag, table=table, max_leaves=max_leaves, n_global=n_global)
 
     for i in range(a.warmup):
         step(i)
@@ -116,66 +160,106 @@ def main():
     for i in range(a.steps):
         loss2, _ = step(a.warmup + i)
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank_ms = [1e3 * t_local / a.steps]
+    allreduce_ms = None
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        tl = torch.tensor([1e3 * t_local / a.steps], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(tl) for _ in range(world)]
+        torch.distributed.all_gather(gathered, tl)
+        per_rank_ms = [float(g[0]) for g in gathered]
+        # the step's only data-path collective, timed alone: all-reduce(SUM) of the flat gradient (4.77 MB)
+        allreduce_ms = time_launch(lambda: parallel.all_reduce_sum(tr.grad), 20)
     dt = float(t[0])
+    live_frac = None
+    if tr.last_step_live:
+        c = tr.live_counts.cpu().tolist()
+        live_frac = {'fine': c[0] / max(1, c[1]), 'coarse': c[2] / max(1, c[3])}
 
-    # ---- dominant kernel, measured live with HIP events on the launch stream ----------------
-    # mlp_fwd_kernel<SAVE=true> over the fine pass: P = 4096*192 points in one launch
-    roof = None
-    if rank == 0:
-        ro, rd, tgt = batches[0]
-        rays11 = ops.pack_rays(ro, rd, 2.0, 6.0)
-        z = torch.sort(torch.rand(N_RAYS, N_SAMPLES + N_IMPORTANCE, device=dev) * 4 + 2, -1).values
-        P = N_RAYS * (N_SAMPLES + N_IMPORTANCE)
-        act = torch.empty(ops.act_floats(P), device=dev)
-        raw = torch.empty(N_RAYS, N_SAMPLES + N_IMPORTANCE, 4, device=dev)
-        for _ in range(2):
-            ops.mlp_fwd(rays11, z, tr.net_f.flat, tr.pf[0], act=act, raw=raw)
-        reps = max(3, min(a.steps, 10))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.mlp_fwd(rays11, z, tr.net_f.flat, tr.pf[0], act=act, raw=raw)
-        e1.record()
+    # ---- sustained leg: the same step for >= 400 more steps (power-managed clocks settle within seconds) ----------
+    sustained = None
+    if a.sustained_steps > 0:
+        parallel.barrier()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        flops = P * FWD_FLOP_PER_POINT
-        achieved = flops / (ms * 1e-3) / 1e12
-        split = ops.get_math() == 'bf16x3'
-        kname = 'void mlp_fwd_bf16_kernel<true, false>' if split else 'void mlp_fwd_kernel<true, false>'
-        traffic = None   # HBM bytes per launch from the committed PMC passes (separate rocprofv3 runs)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            traffic = pmc['kernels'][kname]['hbm_bytes']
+        t1 = time.perf_counter()
+        for i in range(a.sustained_steps):
+            step(i)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        ts = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
+        sustained = {'steps': a.sustained_steps, 'ms_per_step': 1e3 * float(ts[0]) / a.sustained_steps,
+                     'value': N_RAYS * world * a.sustained_steps / float(ts[0]), 'unit': 'rays/s', 'seconds': float(ts[0])}
+
+    def mlp_roofline(trainer, split, compact_frac):
+        """HIP-event timing of the MLP launches of one step's FINE pass (786 432 points); the one the step spends the most
+        time in is `roofline`.  achieved = algorithmic FLOPs of the launch / its average duration."""
+        ro, rd, tgt, tag = batches[0]
+        rays11 = ops.pack_rays(ro, rd, 2.0, 6.0)
+        z = torch.sort(torch.rand(N_RAYS, S1, device=dev) * 4 + 2, -1).values
+        P = N_RAYS * S1
+        act = torch.empty(ops.act_floats(P), device=dev)
+        raw = torch.empty(N_RAYS, S1, 4, device=dev)
+        reps = max(3, min(a.steps, 10))
+        peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
+        base = 'mlp_fwd_bf16_kernel' if split else 'mlp_fwd_kernel'
+        rows = []
+        ms_save = time_launch(lambda: ops.mlp_fwd(rays11, z, trainer.net_f.flat, trainer.pf[0], act=act, raw=raw), reps)
+        ms_inf = time_launch(lambda: ops.mlp_fwd(rays11, z, trainer.net_f.flat, trainer.pf[0], raw=raw), reps)
+        rows.append({'kernel': base + '<true, false>', 'what': 'training forward, saves activations, %d points' % P,
+                     'points': P, 'avg_launch_ms': ms_save})
+        rows.append({'kernel': base + '<false, false>', 'what': 'forward without saving (inference; first pass of a compacted step), %d points' % P,
+                     'points': P, 'avg_launch_ms': ms_inf})
+        if compact_frac is not None:
+            # the compacted step: inference forward on all points + saving forward on the live list
+            draw = torch.randn(P, 4, device=dev)
+            draw[torch.rand(P, device=dev) >= compact_frac] = 0
+            idx, cnt = ops.compact_live(draw)
+            k = int(cnt[0])
+            ms_live = time_launch(lambda: ops.mlp_fwd_live(rays11, z, trainer.net_f.flat, trainer.pf[0], act, idx, cnt), reps)
+            rows.append({'kernel': base + '<true, false>', 'what': 'training forward over the live list, %d of %d points' % (k, P),
+                         'points': k, 'avg_launch_ms': ms_live})
+            in_step = [rows[1], rows[2]]
+        else:
+            in_step = [rows[0]]
+        for r in rows:
+            r['flop_per_launch'] = r['points'] * FWD_FLOP_PER_POINT
+            r['achieved'] = r['flop_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12
+            r['frac'] = r['achieved'] / peak
+        dom = max(in_step, key=lambda r: r['avg_launch_ms'])
+        traffic = step_traffic = None
+        try:   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles.sh)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_pmc_traffic.json')))
+            traffic = pmc['kernels']['void ' + dom['kernel']]['hbm_bytes']
+            step_traffic = pmc.get('step_traffic')
         except Exception:
             pass
-        if split:
-            # every algorithmic multiply-add is issued as 3 bf16 MFMA terms (hi*hi + hi*lo + lo*hi), so the roofline of
-            # the algorithmic FLOPs is the dense bf16 MFMA peak / 3
-            peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-        else:
-            peak = FP32_MFMA_PEAK_TFLOPS
-        roof = {'bound': 'mfma', 'kernel': kname[5:] + ' (fine pass, 786432 points/launch)',
-                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+        roof = {'bound': 'mfma', 'kernel': dom['kernel'] + ' (fine pass; ' + dom['what'] + ')', 'achieved': dom['achieved'],
+                'peak': peak, 'unit': 'TFLOP/s', 'frac': dom['frac'],
                 'peak_note': ('dense bf16 MFMA 2500 TFLOP/s / 3 split terms per product' if split
                               else 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)'),
-                'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01_pmc_traffic.json)',
-                'avg_launch_ms': ms, 'flop_per_launch': flops, 'mfma_tflops_issued': (3.0 if split else 1.0) * achieved,
-                'hbm_write_GBps': (ops.act_floats(P) * 4 / (ms * 1e-3) / 1e9)}
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/%s_pmc_traffic.json)' % PROFILE_ROUND,
+                'step_traffic': step_traffic, 'avg_launch_ms': dom['avg_launch_ms'], 'flop_per_launch': dom['flop_per_launch'],
+                'mfma_tflops_issued': (3.0 if split else 1.0) * dom['achieved'], 'launches': rows}
         if split:
             # tools/micro/mfma_power.hip on the bench box: a saturated v_mfma_f32_32x32x16_bf16 stream (32.0 clk per
             # MFMA and SIMD) holds 2.24-2.38 GHz on constant operands but only 1.79 GHz = 1871 TFLOP/s on uniform(-1,1)
-            # bf16 data (power management); the kernel itself runs at 1.67 GHz (profiles/r01_sq_counters.md)
+            # bf16 data (power management)
             roof['peak_measured_real_data'] = 1871.0 / 3.0
-            roof['frac_of_measured_peak'] = achieved / (1871.0 / 3.0)
-        del act
+            roof['frac_of_measured_peak'] = dom['achieved'] / (1871.0 / 3.0)
+        return roof
 
-    # ---- the same step in the exact-fp32 math mode, for reference (1 GPU only; not `value`) ----------------------
+    roof = None
+    if rank == 0:
+        roof = mlp_roofline(tr, ops.get_math() == 'bf16x3', live_frac['fine'] if live_frac else None)
+
+    # ---- the same step in the exact-fp32 math mode (1 GPU only; not `value`): its own roofline block ---------------
     alt = None
     if rank == 0 and world == 1 and ops.get_math() != 'fp32':
         main_mode = ops.get_math()
@@ -184,17 +268,19 @@ def main():
             torch.manual_seed(0)
             ktr32, _, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
             tr32 = fastnerf.run_nerf.Trainer(ktr32, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
-            for i in range(2):
-                tr32.step(*batches[i % n_batches])
+            for i in range(3):
+                step(i, tr32)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n32 = 5
+            n32 = max(20, a.steps)
             for i in range(n32):
-                l32, _ = tr32.step(*batches[(2 + i) % n_batches])
+                l32, _ = step(3 + i, tr32)
             torch.cuda.synchronize()
             dt32 = (time.perf_counter() - t1) / n32
             alt = {'math_mode': 'fp32', 'dtype': 'f32', 'value': N_RAYS / dt32, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt32,
-                   'steps': n32, 'frac_of_fp32_mfma_peak': N_RAYS / dt32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                   'steps': n32, 'warmup': 3, 'final_loss': [float(x) for x in l32.tolist()],
+                   'step_frac_of_fp32_mfma_peak': N_RAYS / dt32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                   'roofline': mlp_roofline(tr32, False, None)}
             del tr32, ktr32
         finally:
             ops.set_math(main_mode)
@@ -204,7 +290,7 @@ def main():
     if rank == 0:
         n_inf = 32768
         g2 = torch.Generator().manual_seed(7)
-        pix = torch.stack([torch.randint(0, 100, (n_inf,), generator=g2), torch.randint(0, H, (n_inf,), generator=g2),
+        pix = torch.stack([torch.randint(0, n_img, (n_inf,), generator=g2), torch.randint(0, H, (n_inf,), generator=g2),
                            torch.randint(0, W, (n_inf,), generator=g2)], 1).int().to(dev)
         ro_i, rd_i = ops.gen_rays_pixels(pix, poses, K)
         with torch.no_grad():
@@ -230,15 +316,20 @@ def main():
             'dtype': 'f32 (split-bf16 x3 on the bf16 matrix cores, fp32 accumulate)' if ops.get_math() == 'bf16x3' else 'f32',
             'math_mode': ops.get_math(), 'data': 'synthetic',
             'config': {'workload': 'nerf-ours Lego full 800x800, 4096 rays/GPU/step, 64+128 samples, use_viewdirs, '
-                                   'white_bkgd, perturb=1 (BASELINE configs[1])',
+                                   'white_bkgd, perturb=1, leaf-error table on (BASELINE configs[1])',
                        'rays_per_gpu_per_step': N_RAYS, 'parallelism': f'dp{world}'},
             'final_loss': [float(x) for x in loss2.tolist()],
+            'backward': ('compacted: exact zero-gradient points skipped (FASTNERF_COMPACT=%s)' % fastnerf.render.get_compact())
+            if tr.last_step_live else 'plain (every point)',
+            'live_fraction': live_frac,
+            'per_rank_ms_per_step': per_rank_ms, 'allreduce_ms': allreduce_ms,
             'step_tflops_per_gpu': step_tflops, 'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
             'step_frac_of_bf16_mfma_peak_x3': 3.0 * step_tflops / BF16_MFMA_PEAK_TFLOPS,
+            'sustained': sustained,
             'roofline': roof,
             'inference': infer,
             'exact_fp32_mode': alt,
-            'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(),
+            'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.cpu_protocol),
         }
         print(json.dumps(out))
     if world > 1:

@@ -1471,7 +1471,9 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
 #ifdef BF_EXPERIMENT
   if (getenv("FASTNERF_DW_WGS")) nwg = atoi(getenv("FASTNERF_DW_WGS"));
 #endif
-  if (nt < nwg) nwg = (int)nt;
+  // (always one workgroup per CU, also for batches of fewer tiles -- idle workgroups write zero partials: the order in
+  // which the partial sums meet is then a function of the tile count alone, which makes the live-list backward bit-identical
+  // to the plain backward of the same points)
   BRedTable T;
   T.n = 0;
   int rc;
@@ -1513,8 +1515,7 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
   segs(11, L.VW + 256, 283, 27, 0, 0, 0);
   // rgb head + alpha bias
   {
-    int hg = (int)(nt > BHEAD_MAX_WG ? BHEAD_MAX_WG : nt);
-    if (hg < 1) hg = 1;
+    const int hg = BHEAD_MAX_WG;   // fixed, for the same reason as nwg
     const int64_t hb = b_job_base(12, ncu, PEP);
     hipLaunchKernelGGL(head_grads_bf16_kernel, dim3(hg), dim3(128), 0, st, P, nt, draw, act + ba_hv(nt), partial + hb, live_idx, live_cnt);
     FN_LAUNCH_CHECK();
