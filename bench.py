@@ -4,10 +4,19 @@
 A "step" = one full optimisation step (ray packing -> stratified + hierarchical sampling -> PE ->
 coarse/fine MLP -> compositing -> 2xMSE + per-(image, leaf) error table (atomicMax) -> backward ->
 [RCCL all-reduce] -> Adam + LR decay) on 4096 rays x (64 + 128) samples per GPU, i.e. BASELINE.json
-configs[1] ("nerf-ours Lego full 800x800, 4096 rays, 64+128 samples"), synthetic Lego-like cameras
-(100 x pose_spherical, 800x800, focal 1111.11, near 2 / far 6), U[0,1) targets, default-init
-weights (seed 0), quadtree leaf tags of a depth-5 tree (256 leaves per image).  Inputs are resident
-in HBM before the timed region.  The GPU legs import nothing from oracle/; only `cpu_baseline` does.
+configs[1] ("nerf-ours Lego full 800x800, 4096 rays, 64+128 samples"): synthetic Lego-like cameras
+(100 x pose_spherical, 800x800, focal 1111.11, near 2 / far 6), quadtree leaf tags of a depth-5 tree
+(256 leaves per image), default-init weights (seed 0).  Inputs are resident in HBM before the timed region.
+
+What the nets are trained on matters since round 2: the backward skips samples whose gradient is EXACTLY zero
+(sigma <= 0: empty space of a radiance field), so throughput depends on where the field puts its density.
+`value` is the steady state of training the analytic Lego-like scene of fastnerf.synthetic (three density
+blobs on a white background; targets by quadrature along each batch's rays): the nets are first optimised from
+their random initialisation for --scene-steps (300) untimed steps, then W warm-up and K timed steps follow on the
+same stream of batches.  The round-1 protocol -- random-init nets, U[0,1) noise targets, no scene -- is timed
+too and reported as `init_state` (there 84 % of the samples are live and the plain backward is used), as is the
+steady state with the compaction switched off (`steady_state_plain`).  The GPU legs import nothing from
+oracle/; only `cpu_baseline` does.
 
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
@@ -112,12 +121,13 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--sustained-steps', type=int, default=400)
+    ap.add_argument('--scene-steps', type=int, default=300, help='untimed optimisation steps on the analytic scene before W + K')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-protocol', choices=['full', 'short'], default='full')
     a = ap.parse_args()
 
     import fastnerf
-    from fastnerf import ops, parallel
+    from fastnerf import ops, parallel, synthetic
     from fastnerf.synthetic import pose_spherical
     rank, world, local = parallel.init_from_env('cuda')
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
@@ -125,82 +135,104 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    torch.manual_seed(0)   # identical initial weights on every rank
     args = fastnerf.run_nerf.make_args(N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, perturb=1.0, white_bkgd=True,
                                        no_reload=True, lrate=5e-4, lrate_decay=500)
-    ktr, kte, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
     n_img, max_leaves = 100, 256
     poses = torch.stack([pose_spherical(-180.0 + 3.6 * k, -30.0, 4.0)[:3, :4] for k in range(n_img)], 0).to(dev)
     gen = torch.Generator().manual_seed(1000 + rank)
-    n_batches = 8
-    batches = []
+    n_batches = 64          # 262 144 distinct rays per rank, cycled
+    batches = []            # (rays_o, rays_d, scene colour, noise colour, leaf tag)
     for _ in range(n_batches):
         pix = torch.stack([torch.randint(0, n_img, (N_RAYS,), generator=gen), torch.randint(0, H, (N_RAYS,), generator=gen),
                            torch.randint(0, W, (N_RAYS,), generator=gen)], 1).int()
         ro, rd = ops.gen_rays_pixels(pix.to(dev), poses, K)
         # (image, leaf) tags of a depth-5 quadtree: 16 x 16 leaves of 50 x 50 pixels, DFS order irrelevant for timing
         tag = torch.stack([pix[:, 0], (pix[:, 1] // 50) * 16 + pix[:, 2] // 50], 1).int().to(dev).contiguous()
-        batches.append((ro, rd, torch.rand(N_RAYS, 3, generator=gen).to(dev), tag))
+        batches.append((ro, rd, synthetic.render_rays(ro, rd).contiguous(), torch.rand(N_RAYS, 3, generator=gen).to(dev), tag))
     table = torch.zeros(n_img * max_leaves, device=dev, dtype=torch.int32)
-    tr = fastnerf.run_nerf.Trainer(ktr, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
     n_global = N_RAYS * world if world > 1 else None
 
-    def step(i, trainer=tr):
-        ro, rd, tgt, tag = batches[i % n_batches]
-        return trainer.step(ro, rd, tgt, leaf_tag=tag, table=table, max_leaves=max_leaves, n_global=n_global)
+    def new_trainer():
+        torch.manual_seed(0)   # identical initial weights on every rank, and for every leg
+        k_train, k_test, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
+        return fastnerf.run_nerf.Trainer(k_train, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500), k_test
 
-    for i in range(a.warmup):
-        step(i)
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss2, _ = step(a.warmup + i)
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
-    parallel.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    def step(trainer, i, noise=False):
+        ro, rd, tgt, tgt_noise, tag = batches[i % n_batches]
+        return trainer.step(ro, rd, tgt_noise if noise else tgt, leaf_tag=tag, table=table, max_leaves=max_leaves, n_global=n_global)
+
+    def timed(trainer, first, warm, steps, noise=False):
+        """W warm-up + K timed steps, barrier + synchronize on both sides, MAX over ranks -> (seconds, last loss, local s)."""
+        for i in range(warm):
+            step(trainer, first + i, noise)
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss2, _ = step(trainer, first + warm + i, noise)
+        torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t[0]), loss2, t_local
+
+    # ---- steady state of training the analytic scene: untimed optimisation from random init, then W + K (`value`) ----
+    tr, kte = new_trainer()
+    for i in range(a.scene_steps):
+        step(tr, i)
+    dt, loss2, t_local = timed(tr, a.scene_steps, a.warmup, a.steps)
     per_rank_ms = [1e3 * t_local / a.steps]
     allreduce_ms = None
     if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         tl = torch.tensor([1e3 * t_local / a.steps], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(tl) for _ in range(world)]
         torch.distributed.all_gather(gathered, tl)
         per_rank_ms = [float(g[0]) for g in gathered]
         # the step's only data-path collective, timed alone: all-reduce(SUM) of the flat gradient (4.77 MB)
         allreduce_ms = time_launch(lambda: parallel.all_reduce_sum(tr.grad), 20)
-    dt = float(t[0])
     live_frac = None
     if tr.last_step_live:
         c = tr.live_counts.cpu().tolist()
         live_frac = {'fine': c[0] / max(1, c[1]), 'coarse': c[2] / max(1, c[3])}
+    backward_kind = 'compacted' if tr.last_step_live else 'plain'
 
-    # ---- sustained leg: the same step for >= 400 more steps (power-managed clocks settle within seconds) ----------
+    # ---- sustained leg: the same stream of steps for >= 400 more steps (power-managed clocks settle within seconds) ----
     sustained = None
     if a.sustained_steps > 0:
-        parallel.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(a.sustained_steps):
-            step(i)
-        torch.cuda.synchronize()
-        parallel.barrier()
-        ts = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        if world > 1:
-            torch.distributed.all_reduce(ts, op=torch.distributed.ReduceOp.MAX)
-        sustained = {'steps': a.sustained_steps, 'ms_per_step': 1e3 * float(ts[0]) / a.sustained_steps,
-                     'value': N_RAYS * world * a.sustained_steps / float(ts[0]), 'unit': 'rays/s', 'seconds': float(ts[0])}
+        ts, _, _ = timed(tr, a.scene_steps + a.warmup + a.steps, 0, a.sustained_steps)
+        sustained = {'steps': a.sustained_steps, 'ms_per_step': 1e3 * ts / a.sustained_steps,
+                     'value': N_RAYS * world * a.sustained_steps / ts, 'unit': 'rays/s', 'seconds': ts}
+
+    # ---- the same steady state with the compaction switched off (every point goes through the backward) ----
+    old_mode = fastnerf.render.get_compact()
+    fastnerf.render.set_compact('0')
+    try:
+        tp, _, _ = timed(tr, 7, 3, 20)
+    finally:
+        fastnerf.render.set_compact(old_mode)
+    steady_plain = {'ms_per_step': 1e3 * tp / 20, 'value': N_RAYS * world * 20 / tp, 'unit': 'rays/s', 'steps': 20, 'warmup': 3,
+                    'what': 'FASTNERF_COMPACT=0 on the trained nets: plain backward over every sample'}
+
+    # ---- round-1 protocol: random-init nets, U[0,1) noise targets, no scene (W = 3, K = 20) ----
+    tr_i, _ = new_trainer()
+    ti, loss_i, _ = timed(tr_i, 0, 3, 20, noise=True)
+    tr_i.live.poll()
+    init_state = {'ms_per_step': 1e3 * ti / 20, 'value': N_RAYS * world * 20 / ti, 'unit': 'rays/s', 'steps': 20, 'warmup': 3,
+                  'backward': 'compacted' if tr_i.last_step_live else 'plain', 'live_fraction_measured': tr_i.live.frac,
+                  'final_loss': [float(x) for x in loss_i.tolist()],
+                  'what': 'random-init nets (seed 0), U[0,1) targets: the protocol of BENCH_r01'}
+    del tr_i
 
     def mlp_roofline(trainer, split, compact_frac):
         """HIP-event timing of the MLP launches of one step's FINE pass (786 432 points); the one the step spends the most
         time in is `roofline`.  achieved = algorithmic FLOPs of the launch / its average duration."""
-        ro, rd, tgt, tag = batches[0]
+        ro, rd = batches[0][0], batches[0][1]
         rays11 = ops.pack_rays(ro, rd, 2.0, 6.0)
         z = torch.sort(torch.rand(N_RAYS, S1, device=dev) * 4 + 2, -1).values
         P = N_RAYS * S1
@@ -265,23 +297,15 @@ def main():
         main_mode = ops.get_math()
         ops.set_math('fp32')
         try:
-            torch.manual_seed(0)
-            ktr32, _, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
-            tr32 = fastnerf.run_nerf.Trainer(ktr32, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
-            for i in range(3):
-                step(i, tr32)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
+            tr32, _ = new_trainer()
             n32 = max(20, a.steps)
-            for i in range(n32):
-                l32, _ = step(3 + i, tr32)
-            torch.cuda.synchronize()
-            dt32 = (time.perf_counter() - t1) / n32
+            t32, l32, _ = timed(tr32, 0, 3, n32, noise=True)   # (the exact-fp32 mode has no compacted backward: round-1 protocol)
+            dt32 = t32 / n32
             alt = {'math_mode': 'fp32', 'dtype': 'f32', 'value': N_RAYS / dt32, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt32,
                    'steps': n32, 'warmup': 3, 'final_loss': [float(x) for x in l32.tolist()],
                    'step_frac_of_fp32_mfma_peak': N_RAYS / dt32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                    'roofline': mlp_roofline(tr32, False, None)}
-            del tr32, ktr32
+            del tr32
         finally:
             ops.set_math(main_mode)
 
@@ -314,14 +338,18 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (split-bf16 x3 on the bf16 matrix cores, fp32 accumulate)' if ops.get_math() == 'bf16x3' else 'f32',
-            'math_mode': ops.get_math(), 'data': 'synthetic',
+            'math_mode': ops.get_math(),
+            'data': 'synthetic (analytic three-blob scene on white, 100 pose_spherical cameras; nets trained from random init inside the run)',
             'config': {'workload': 'nerf-ours Lego full 800x800, 4096 rays/GPU/step, 64+128 samples, use_viewdirs, '
-                                   'white_bkgd, perturb=1, leaf-error table on (BASELINE configs[1])',
-                       'rays_per_gpu_per_step': N_RAYS, 'parallelism': f'dp{world}'},
+                                   'white_bkgd, perturb=1, leaf-error table on (BASELINE configs[1]); steady state of training '
+                                   'the analytic Lego-like scene (%d untimed optimisation steps from random init, then W + K)' % a.scene_steps,
+                       'rays_per_gpu_per_step': N_RAYS, 'parallelism': f'dp{world}', 'scene_steps': a.scene_steps},
             'final_loss': [float(x) for x in loss2.tolist()],
-            'backward': ('compacted: exact zero-gradient points skipped (FASTNERF_COMPACT=%s)' % fastnerf.render.get_compact())
-            if tr.last_step_live else 'plain (every point)',
+            'backward': ('compacted: samples with an exactly-zero gradient skipped (FASTNERF_COMPACT=%s)' % fastnerf.render.get_compact())
+            if backward_kind == 'compacted' else 'plain (every sample)',
             'live_fraction': live_frac,
+            'steady_state_plain': steady_plain, 'speedup_vs_plain_backward': steady_plain['ms_per_step'] / (1e3 * dt / a.steps),
+            'init_state': init_state,
             'per_rank_ms_per_step': per_rank_ms, 'allreduce_ms': allreduce_ms,
             'step_tflops_per_gpu': step_tflops, 'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
             'step_frac_of_bf16_mfma_peak_x3': 3.0 * step_tflops / BF16_MFMA_PEAK_TFLOPS,

@@ -60,6 +60,9 @@ typedef unsigned long long u64;
 #ifndef BF_PF
 #define BF_PF 2   // weight fragments two k-steps ahead in the fwd / dX k-loops (1: one ahead)
 #endif
+#ifndef BF_PRE_STEPS
+#define BF_PRE_STEPS 1   // k-steps of the next layer prefetched ahead of an epilogue (PRE): 2 costs 16 more VGPRs -> scratch spills in dX
+#endif
 // Bisection hook for the SLP-vectoriser corruption (tools/slp_bisect.py): what is executed at every
 // k-loop exit, in front of the epilogue.  0: nothing (product); 1: 34 idle wait states (drains the matrix pipe);
 // 2: s_waitcnt vmcnt(0) lgkmcnt(0) (drains every outstanding load, incl. the pre-loaded bias / mask words)
@@ -284,7 +287,8 @@ __device__ __forceinline__ void bprefetch(BPre<NT>& p, const uint4* __restrict__
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const uint4* q = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128 + lane;
-    p.h0[nt] = q[0]; p.l0[nt] = q[64]; p.h1[nt] = q[128]; p.l1[nt] = q[192];
+    p.h0[nt] = q[0]; p.l0[nt] = q[64];
+    if (BF_PRE_STEPS == 2) { p.h1[nt] = q[128]; p.l1[nt] = q[192]; }
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -292,7 +296,7 @@ __device__ __forceinline__ void bprefetch(BPre<NT>& p, const uint4* __restrict__
 // accumulate nks (even) k-steps of 16.  A planes in LDS (H layout or E layout); B packed in global.
 // PRE: the fragments of k-steps 0 and 1 are already in *pre (needs nks >= 4).
 // AMODE: 0 = H planes, 1 = E planes, 2 = X2 block (pass Ahi = Hhi + X2_HI_OFF, Alo = Hhi + X2_LO_OFF)
-template <int NT, int AMODE, bool PRE = false>
+template <int NT, int AMODE, bool PRE = false, int PF = BF_PF>
 __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, const char* Alo, int a_ks0, int nks,
                                       const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane,
                                       const BPre<NT>* pre = nullptr) {
@@ -357,13 +361,18 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
 #if BF_PRIO
   __builtin_amdgcn_s_setprio(BF_PRIO);
 #endif
-#if BF_PF == 2
   // weights two k-steps ahead (four register sets), activations one ahead; nks % 4 == 0 except the 2-step segments
-  if (nks >= 4) {
+  if (PF == 2 && nks >= 4) {
     uint4 bh2[NT], bl2[NT], bh3[NT], bl3[NT];
     if (PRE) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { bh0[nt] = pre->h0[nt]; bl0[nt] = pre->l0[nt]; bh1[nt] = pre->h1[nt]; bl1[nt] = pre->l1[nt]; }
+      for (int nt = 0; nt < NT; ++nt) { bh0[nt] = pre->h0[nt]; bl0[nt] = pre->l0[nt]; }
+      if (BF_PRE_STEPS == 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bh1[nt] = pre->h1[nt]; bl1[nt] = pre->l1[nt]; }
+      } else {
+        ldB(bh1, bl1, 1);
+      }
     } else {
       ldB(bh0, bl0, 0); ldB(bh1, bl1, 1);
     }
@@ -386,7 +395,6 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
     bdbg_drain();
     return;
   }
-#endif
   ldB(bh0, bl0, 0); ldA(ah0, al0, 0);
 #pragma unroll 1
   for (int ks = 0; ks < nks; ks += 2) {
@@ -449,7 +457,6 @@ struct EpiArgs {
   const void* mask_in;        // MASK: the forward's ReLU sign bits of this tile and layer (one word per thread)
   void* mask_out;             // MOUT: where this tile's sign bits go
   uint2* gsave;               // GSAVE: K-fragment tensor, already offset to the tile
-  const int* hofs;            // optional: this lane's 16 precomputed LDS offsets hoff(bcrow(r), slot) + inslot (rows mt = 0)
   // this lane's bias / rank-1 weights / sign words, loaded by bepi*_preload BEFORE the k-loop so that their
   // latency is not paid at the head of the epilogue
   float r_b0, r_b1, r_wa0, r_wa1;
@@ -498,7 +505,7 @@ __device__ __forceinline__ float mask_get(unsigned m, int k, float v) {
 //   - LDS: the column pair is one packed 32-bit store per plane and row,
 //   - global: 4 consecutive rows of one column = 8 bytes of a K-fragment element (see the file header),
 //   - sign bits (forward, ReLU layers): 64 per thread and layer, order mt, r, nt.
-template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE, bool HOFS = false>
+template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE>
 __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs& ea, char* Hhi, char* Hlo, int wn,
                                         int lane) {
   asm volatile("" : "+v"(lane));
@@ -509,7 +516,12 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
   if (RANK1) { wa0 = ea.r_wa0; wa1 = ea.r_wa1; }
   uint2 min2 = make_uint2(0u, 0u), mout2 = make_uint2(0u, 0u);
   if (MASK) min2 = ea.r_min2;
-  const int slot = n0 >> 3, inslot = (n0 & 7) * 2;
+  // LDS offset of row m = mt*32 + bcrow(r, lane), columns n0, n0+1:  hoff(m, n0 >> 3) + (n0 & 7) * 2.  With
+  // m & 15 = ((r & 3) | ((r >> 2) & 1) << 3) ^ (half << 2) the lane part folds into ONE register,
+  //   o = (lanebase ^ (c_r << 4)) + (mt*32 + (r&3) + 8*(r>>2)) * 512,   c_r = (r & 3) | ((r >> 2) & 1) << 3,
+  // i.e. 8 distinct v_xor results per call and an immediate offset per store -- no per-lane offset table has to stay
+  // live across the k-loops (16 VGPRs that used to push the dX and background-forward kernels into scratch spills).
+  const int lanebase = (((n0 >> 3) ^ (half << 2)) << 4) + (n0 & 7) * 2 + half * (4 * 512);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     unsigned H[16], L[16];
@@ -528,7 +540,7 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
       if (MASK) { v0 = mask_get(mi, 2 * r, v0); v1 = mask_get(mi, 2 * r + 1, v1); }
       split_pair(v0, v1, H[r], L[r]);
       // (rows m and m + 32 share m & 15, so the second row tile is the first one's offset + 32 rows)
-      const int o = HOFS ? ea.hofs[r] + mt * (32 * 512) : hoff(m, slot) + inslot;
+      const int o = (lanebase ^ (((r & 3) | (((r >> 2) & 1) << 3)) << 4)) + (mt * 32 + (r & 3) + 8 * (r >> 2)) * 512;
       *reinterpret_cast<unsigned*>(Hhi + o) = H[r];
       *reinterpret_cast<unsigned*>(Hlo + o) = L[r];
     }
@@ -686,13 +698,6 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
   u64* maskw_all = SAVE ? reinterpret_cast<u64*>(act + ba_mask(nt_lay)) : nullptr;            // [tile][8][256] u64
   unsigned* maskv_all = SAVE ? reinterpret_cast<unsigned*>(act + ba_maskv(nt_lay)) : nullptr;   // [tile][256] u32
 
-  int hofs[16];   // LDS offsets of this lane's epilogue stores (loop invariant; not for BG: that variant has no registers left)
-  if (!BG) {
-    const int n0 = wn * 64 + 2 * (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hofs[r] = hoff(bcrow(r, lane), n0 >> 3) + (n0 & 7) * 2;
-  }
-
   // scheduler word: the last 8 bytes of the lo plane = columns >= 128 of row 63, which hold stale feature values at the end
   // of a tile (the rgb head reads columns < 128) and are next written by the following tile's layer-0 epilogue, one
   // barrier after every thread has read the word
@@ -786,18 +791,18 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     }
     f32x16 acc[2][2];
     EpiArgs ea{};
-    ea.hofs = hofs;
     constexpr bool PRE = !BG && (BF_PF == 2) && BF_PRE_FWD;   // (the background variant has no registers to spare)
+    constexpr int KPF = BG ? 1 : BF_PF;   // background net: weight fragments one k-step ahead (two would spill: 256 VGPRs + scratch)
     BPre<2> pre;
     // L0
     ea.bias = params + lay.LB[0];
     bepi256_preload<true, false, false>(ea, wn, lane);
     bzero<2>(acc);
     if (!BG) {
-      bgemm<2, 1>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 4, 0, wn * 2, lane);
+      bgemm<2, 1, false, KPF>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 4, 0, wn * 2, lane);
     } else {
-      bgemm<2, 1>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 6, 0, wn * 2, lane);
-      bgemm<2, 2>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, pk + boff.off[0], 6, 4, wn * 2, lane);
+      bgemm<2, 1, false, KPF>(acc, Ehi, Elo, 0, 4, pk + boff.off[0], 6, 0, wn * 2, lane);
+      bgemm<2, 2, false, KPF>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, pk + boff.off[0], 6, 4, wn * 2, lane);
     }
     if (SAVE || BG) __syncthreads();   // staging copy / X2 block read out before H is written
     if (SAVE) {
@@ -805,7 +810,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       ea.mask_out = maskw_all + (tile * 8 + 0) * 256;
     }
     if (PRE) bprefetch<2>(pre, pk + boff.off[1], 16, 0, wn * 2, lane);
-    bepi256<true, true, false, false, SAVE, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
@@ -816,18 +821,18 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       const uint4* B = pk + boff.off[l];
       if (l == 5) {
         if (!BG) {
-          bgemm<2, 1, PRE>(acc, Ehi, Elo, 0, 4, B, 20, 0, wn * 2, lane, &pre);
-          bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 20, 4, wn * 2, lane);
+          bgemm<2, 1, PRE, KPF>(acc, Ehi, Elo, 0, 4, B, 20, 0, wn * 2, lane, &pre);
+          bgemm<2, 0, false, KPF>(acc, Hhi, Hlo, 0, 16, B, 20, 4, wn * 2, lane);
         } else {
-          bgemm<2, 0>(acc, Hhi, Hlo, 0, 16, B, 22, 6, wn * 2, lane);
+          bgemm<2, 0, false, KPF>(acc, Hhi, Hlo, 0, 16, B, 22, 6, wn * 2, lane);
           __syncthreads();   // h4 consumed: the top of Hhi becomes the X2 block again
           write_x2(false);
           __syncthreads();
-          bgemm<2, 1>(acc, Ehi, Elo, 0, 4, B, 22, 0, wn * 2, lane);
-          bgemm<2, 2>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, B, 22, 4, wn * 2, lane);
+          bgemm<2, 1, false, KPF>(acc, Ehi, Elo, 0, 4, B, 22, 0, wn * 2, lane);
+          bgemm<2, 2, false, KPF>(acc, Hhi + X2_HI_OFF, Hhi + X2_LO_OFF, 0, 2, B, 22, 4, wn * 2, lane);
         }
       } else {
-        bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane, &pre);
+        bgemm<2, 0, PRE, KPF>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane, &pre);
       }
       TR(4 * l + 1);
       __syncthreads();
@@ -840,7 +845,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         const int ln = l + 1;
         bprefetch<2>(pre, pk + boff.off[ln], ln == 5 ? 20 : 16, 0, wn * 2, lane);
       }
-      bepi256<true, true, false, false, SAVE, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
+      bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
       TR(4 * l + 3);
       __syncthreads();
     }
@@ -895,12 +900,12 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     ea.bias = params + lay.FB;
     bepi256_preload<true, false, false>(ea, wn, lane);
     bzero<2>(acc);
-    bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane, &pre);
+    bgemm<2, 0, PRE, KPF>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane, &pre);
     __syncthreads();
     if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(nt_lay) + tile * 4096);
     BPre<1> prev;
     if (PRE) bprefetch<1>(prev, pk + boff.off[9], 18, 0, wn, lane);
-    bepi256<true, false, false, false, false, SAVE, !BG>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<true, false, false, false, false, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // view layer: [feat256 | vpe32] -> 128, ReLU
     {
@@ -908,8 +913,8 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       ea.bias = params + lay.VB;
       bepi128_preload<true, false>(ea, wn, lane);
       bzero<1>(av);
-      bgemm<1, 0, PRE>(av, Hhi, Hlo, 0, 16, pk + boff.off[9], 18, 0, wn, lane, &prev);
-      bgemm<1, 1>(av, Ehi, Elo, 0, 2, pk + boff.off[9], 18, 16, wn, lane);
+      bgemm<1, 0, PRE, KPF>(av, Hhi, Hlo, 0, 16, pk + boff.off[9], 18, 0, wn, lane, &prev);
+      bgemm<1, 1, false, KPF>(av, Ehi, Elo, 0, 2, pk + boff.off[9], 18, 16, wn, lane);
       __syncthreads();
       if (SAVE) {
         ea.gsave = reinterpret_cast<uint2*>(act + ba_hv(nt_lay) + tile * 2048);
@@ -1039,13 +1044,6 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
   const u64* maskw_all = reinterpret_cast<const u64*>(act + ba_mask(nt_lay));
   const unsigned* maskv_all = reinterpret_cast<const unsigned*>(act + ba_maskv(nt_lay));
 
-  int hofs[16];   // LDS offsets of this lane's epilogue stores (loop invariant)
-  {
-    const int n0 = wn * 64 + 2 * (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hofs[r] = hoff(bcrow(r, lane), n0 >> 3) + (n0 & 7) * 2;
-  }
-
   for (int64_t tile = blockIdx.x; tile < ntiles;) {
     const int64_t p0 = tile * BTM;
     if (tid < BTM) {
@@ -1057,7 +1055,6 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     }
     __syncthreads();
     EpiArgs ea{};
-    ea.hofs = hofs;
     constexpr bool PRE = (BF_PF == 2) && BF_PRE_DX;
     BPre<2> pre;
     // ---- dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] ---------------------------------------------------
@@ -1087,7 +1084,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(nt_lay) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[1], 16, 0, wn * 2, lane);
-    bepi256<false, false, false, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<false, false, false, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ---------------------------------------------------
     ea.mask_in = maskw_all + (tile * 8 + 7) * 256;
@@ -1099,7 +1096,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, 7) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[2], 16, 0, wn * 2, lane);
-    bepi256<false, false, true, true, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<false, false, true, true, false, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY_{l-1} = (dY_l . W_l[:, h part]) * [h_{l-1} > 0],  l = 7..1 ---------------------------------
 #pragma unroll 1
@@ -1111,7 +1108,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
       __syncthreads();
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, l - 1) + tile * 4096);
       if (PRE && l > 1) bprefetch<2>(pre, pkt + boff.off[10 - l], 16, 0, wn * 2, lane);
-      bepi256<false, false, true, false, false, true, true>(acc, ea, Hhi, Hlo, wn, lane);
+      bepi256<false, false, true, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
       if (l > 1) __syncthreads();
     }
     tile = b_next_tile(sched, sched_word, tid);   // (contains the tile's closing barrier)

@@ -1,166 +1,164 @@
-"""LLFF (forward-facing / 360) dataset reader: the reference's load_llff.py (:60-316) behind the same names.
-Host-side numpy only.  Differences by construction: images are read with PIL; down-scaled image folders
-(`images_<factor>`) must already exist -- the reference shells out to ImageMagick's `mogrify` to create them
-(`_minify`, :7-57), which is outside this build."""
+"""LLFF (forward-facing / 360-degree) capture reader behind the reference's entry point
+`load_llff_data(basedir, factor, recenter, bd_factor, spherify, path_zflat)` (nerf-ours/load_llff.py:244-316),
+returning the same five things: images [n,H,W,3], poses [n,3,5] (c2w | (H,W,focal) column), bds [n,2],
+render_poses [m,3,5] (all float32) and the index of the hold-out view.
+
+Written from the camera geometry, batched over views (no per-view Python loops):
+
+  * `poses_bounds.npy` rows are 15 + 2 numbers: a 3x5 matrix whose first four columns are the camera-to-world
+    transform in LLFF's (down, right, back) axis order and whose last column is (H, W, focal), then near / far depth.
+    NeRF's axis order is (right, up, back): new x = old y, new y = -old x.
+  * a "frame" is an orthonormal basis built from a viewing axis and an up hint (`frames_from`);
+  * the capture's mean frame (`mean_frame`) recentres the poses, anchors the spiral render path and picks the
+    hold-out view (closest camera to the mean position);
+  * 360-degree captures are normalised to the unit sphere around the least-squares focus point of the optical
+    axes and get a circular render path (`normalise_to_sphere`).
+
+Host-side numpy only.  Images are read with PIL; down-scaled folders (`images_<factor>`) must already exist --
+the reference shells out to ImageMagick's `mogrify` to create them (load_llff.py:7-57), which is outside this build.
+Golden vectors recorded from the reference: tests/golden/g15_loaders.npz (oracle/make_golden_loaders.py)."""
 import os
 
 import numpy as np
 
+_IMG_EXT = ('JPG', 'jpg', 'png')
 
-def _imread(path):
+
+def _list_images(folder):
+    return [os.path.join(folder, f) for f in sorted(os.listdir(folder)) if f.endswith(_IMG_EXT)]
+
+
+def _read_rgb(path):
     from PIL import Image
     with Image.open(path) as im:
         return np.asarray(im)
 
 
-def _is_img(f):
-    return f.endswith('JPG') or f.endswith('jpg') or f.endswith('png')
-
-
-def _load_data(basedir, factor=None, width=None, height=None, load_imgs=True):
-    """poses_bounds.npy -> poses [3,5,n] (columns 0..3 = c2w in LLFF's axis order, column 4 = (H, W, focal)),
-    bds [2,n], imgs [H,W,3,n] in [0,1] (load_llff.py:60-113)."""
-    arr = np.load(os.path.join(basedir, 'poses_bounds.npy'))
-    poses = arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
-    bds = arr[:, -2:].transpose([1, 0])
-    full = os.path.join(basedir, 'images')
-    sh0 = _imread(os.path.join(full, sorted(f for f in os.listdir(full) if _is_img(f))[0])).shape
-    sfx = ''
+def read_capture(basedir, factor=None, width=None, height=None):
+    """-> c2w_llff [n,3,4] (LLFF axis order), hwf [3] of the images actually loaded, bounds [n,2], images [n,H,W,3] in [0,1].
+    `factor` (or a target width / height) selects the `images_<suffix>` folder and rescales the focal length."""
+    table = np.load(os.path.join(basedir, 'poses_bounds.npy'))
+    mats = table[:, :15].reshape(-1, 3, 5)
+    bounds = table[:, 15:17].copy()
+    full_h, full_w = _read_rgb(_list_images(os.path.join(basedir, 'images'))[0]).shape[:2]
     if factor is not None:
-        sfx = '_{}'.format(factor)
+        suffix, scale = '_{}'.format(factor), float(factor)
     elif height is not None:
-        factor = sh0[0] / float(height)
-        width = int(sh0[1] / factor)
-        sfx = '_{}x{}'.format(width, height)
+        scale = full_h / float(height)
+        suffix = '_{}x{}'.format(int(full_w / scale), height)
     elif width is not None:
-        factor = sh0[1] / float(width)
-        height = int(sh0[0] / factor)
-        sfx = '_{}x{}'.format(width, height)
+        scale = full_w / float(width)
+        suffix = '_{}x{}'.format(width, int(full_h / scale))
     else:
-        factor = 1
-    imgdir = os.path.join(basedir, 'images' + sfx)
-    if not os.path.exists(imgdir):
-        raise FileNotFoundError(imgdir + ' does not exist (create the down-scaled copies first; the reference runs '
+        suffix, scale = '', 1.0
+    folder = os.path.join(basedir, 'images' + suffix)
+    if not os.path.isdir(folder):
+        raise FileNotFoundError(folder + ' does not exist (create the down-scaled copies first; the reference runs '
                                 'ImageMagick mogrify for this, load_llff.py:7-57)')
-    files = [os.path.join(imgdir, f) for f in sorted(os.listdir(imgdir)) if _is_img(f)]
-    if poses.shape[-1] != len(files):
-        raise ValueError('Mismatch between imgs {} and poses {}'.format(len(files), poses.shape[-1]))
-    sh = _imread(files[0]).shape
-    poses[:2, 4, :] = np.array(sh[:2]).reshape([2, 1])
-    poses[2, 4, :] = poses[2, 4, :] * 1. / factor
-    if not load_imgs:
-        return poses, bds
-    imgs = np.stack([_imread(f)[..., :3] / 255. for f in files], -1)
-    return poses, bds, imgs
+    files = _list_images(folder)
+    if len(files) != mats.shape[0]:
+        raise ValueError('Mismatch between imgs {} and poses {}'.format(len(files), mats.shape[0]))
+    pixels = np.stack([_read_rgb(f)[..., :3] for f in files], 0) / 255.
+    hwf = np.array([pixels.shape[1], pixels.shape[2], mats[0, 2, 4] / scale], dtype=np.float64)
+    return mats[:, :, :4].copy(), hwf, bounds, pixels
 
 
-def normalize(x):
-    return x / np.linalg.norm(x)
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
 
 
-def viewmatrix(z, up, pos):
-    """Camera frame looking along z with the given up hint: columns (right, true up, z, pos)."""
-    z = normalize(z)
-    right = normalize(np.cross(up, z))
-    return np.stack([right, normalize(np.cross(z, right)), z, pos], 1)
+def frames_from(axis, up_hint, origin):
+    """Right-handed camera frames [..,3,4] = (right | up | back | origin) whose back axis is `axis` (normalised) and whose up
+    vector is the component of `up_hint` orthogonal to it."""
+    back = _unit(np.asarray(axis, dtype=np.float64))
+    right = _unit(np.cross(np.broadcast_to(up_hint, back.shape), back))
+    up = _unit(np.cross(back, right))
+    return np.stack([right, up, back, np.broadcast_to(origin, back.shape)], -1)
 
 
-def ptstocam(pts, c2w):
-    return np.matmul(c2w[:3, :3].T, (pts - c2w[:3, 3])[..., np.newaxis])[..., 0]
+def mean_frame(c2w):
+    """One frame for the whole capture: mean camera position, summed back axes, summed up axes."""
+    return frames_from(_unit(c2w[:, :, 2].sum(0)), c2w[:, :, 1].sum(0), c2w[:, :, 3].mean(0))
 
 
-def poses_avg(poses):
-    """Mean position, summed viewing direction and summed up vector -> one [3,5] pose (hwf of pose 0)."""
-    center = poses[:, :3, 3].mean(0)
-    return np.concatenate([viewmatrix(normalize(poses[:, :3, 2].sum(0)), poses[:, :3, 1].sum(0), center), poses[0, :3, -1:]], 1)
+def _homogeneous(m34):
+    m = np.zeros(m34.shape[:-2] + (4, 4), dtype=m34.dtype)
+    m[..., :3, :] = m34
+    m[..., 3, 3] = 1.0
+    return m
 
 
-def render_path_spiral(c2w, up, rads, focal, zdelta, zrate, rots, N):
-    rads = np.array(list(rads) + [1.])
-    hwf = c2w[:, 4:5]
-    out = []
-    for theta in np.linspace(0., 2. * np.pi * rots, N + 1)[:-1]:
-        c = np.dot(c2w[:3, :4], np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * rads)
-        z = normalize(c - np.dot(c2w[:3, :4], np.array([0, 0, -focal, 1.])))
-        out.append(np.concatenate([viewmatrix(z, up, c), hwf], 1))
-    return out
+def in_frame(c2w, frame):
+    """The poses expressed in `frame`'s coordinates: frame^-1 @ c2w."""
+    return (np.linalg.inv(_homogeneous(frame)) @ _homogeneous(c2w))[..., :3, :]
 
 
-def recenter_poses(poses):
-    """Express every pose in the frame of the average pose (load_llff.py:166-178)."""
-    out = poses + 0
-    bottom = np.reshape([0, 0, 0, 1.], [1, 4])
-    c2w = np.concatenate([poses_avg(poses)[:3, :4], bottom], -2)
-    p44 = np.concatenate([poses[:, :3, :4], np.tile(bottom[None], [poses.shape[0], 1, 1])], -2)
-    out[:, :3, :4] = (np.linalg.inv(c2w) @ p44)[:, :3, :4]
-    return out
+def spiral_path(frame, up, radii, focus_depth, z_rate, turns, n_views):
+    """Cameras on an elliptical spiral around `frame`'s origin (extent `radii` per axis, z oscillating at `z_rate` times the
+    angular rate), every one looking at the point `focus_depth` in front of the frame."""
+    theta = np.linspace(0., 2. * np.pi * turns, n_views + 1)[:-1]
+    local = np.stack([np.cos(theta), -np.sin(theta), -np.sin(theta * z_rate), np.ones_like(theta)], -1) * np.append(radii, 1.)
+    position = local @ frame.T                                    # [m,4] @ [4,3]
+    target = frame @ np.array([0., 0., -focus_depth, 1.])
+    return frames_from(position - target, up, position)
 
 
-def spherify_poses(poses, bds):
-    """360-degree captures (load_llff.py:184-241): recenter on the point closest to all optical axes, scale the mean
-    camera distance to 1, and lay a 120-view circle at the cameras' mean height."""
-    def to44(p):
-        return np.concatenate([p, np.tile(np.reshape(np.eye(4)[-1, :], [1, 1, 4]), [p.shape[0], 1, 1])], 1)
-    rays_d, rays_o = poses[:, :3, 2:3], poses[:, :3, 3:4]
-    A = np.eye(3) - rays_d * np.transpose(rays_d, [0, 2, 1])
-    b = -A @ rays_o
-    center = np.squeeze(-np.linalg.inv((np.transpose(A, [0, 2, 1]) @ A).mean(0)) @ b.mean(0))
-    up = (poses[:, :3, 3] - center).mean(0)
-    v0 = normalize(up)
-    v1 = normalize(np.cross([.1, .2, .3], v0))
-    v2 = normalize(np.cross(v0, v1))
-    c2w = np.stack([v1, v2, v0, center], 1)
-    reset = np.linalg.inv(to44(c2w[None])) @ to44(poses[:, :3, :4])
-    rad = np.sqrt(np.mean(np.sum(np.square(reset[:, :3, 3]), -1)))
-    sc = 1. / rad
-    reset[:, :3, 3] *= sc
-    bds *= sc
-    rad *= sc
-    zh = np.mean(reset[:, :3, 3], 0)[2]
-    radcircle = np.sqrt(rad ** 2 - zh ** 2)
-    ring = []
-    for th in np.linspace(0., 2. * np.pi, 120):
-        origin = np.array([radcircle * np.cos(th), radcircle * np.sin(th), zh])
-        z = normalize(origin)
-        x = normalize(np.cross(z, np.array([0, 0, -1.])))
-        ring.append(np.stack([x, normalize(np.cross(z, x)), z, origin], 1))
-    ring = np.stack(ring, 0)
-    hwf = poses[0, :3, -1:]
-    ring = np.concatenate([ring, np.broadcast_to(hwf, ring[:, :3, -1:].shape)], -1)
-    reset = np.concatenate([reset[:, :3, :4], np.broadcast_to(hwf, reset[:, :3, -1:].shape)], -1)
-    return reset, ring, bds
+def normalise_to_sphere(c2w, bounds, n_views=120):
+    """360-degree captures: move the origin to the point closest (least squares) to all optical axes, turn the mean
+    camera offset into +z, scale the RMS camera distance to 1 and put `n_views` cameras on the circle at the cameras'
+    mean height, looking inwards.  -> (poses, ring, scaled bounds)."""
+    axis, origin = c2w[:, :, 2], c2w[:, :, 3]
+    # distance^2 of x to the line (o, d) is |P (x - o)|^2 with P = I - d d^T; minimise the mean over the cameras
+    proj = np.eye(3) - axis[:, :, None] * axis[:, None, :]
+    focus = np.linalg.solve((proj.transpose(0, 2, 1) @ proj).mean(0), (proj @ origin[:, :, None]).mean(0))[:, 0]
+    zdir = _unit((origin - focus).mean(0))
+    xdir = _unit(np.cross([.1, .2, .3], zdir))
+    ydir = _unit(np.cross(zdir, xdir))
+    local = in_frame(c2w, np.stack([xdir, ydir, zdir, focus], 1))
+    shrink = 1. / np.sqrt(np.mean(np.sum(np.square(local[:, :, 3]), -1)))
+    local[:, :, 3] *= shrink
+    height = local[:, 2, 3].mean()
+    ring_radius = np.sqrt(1. - height ** 2)
+    angle = np.linspace(0., 2. * np.pi, n_views)
+    spot = np.stack([ring_radius * np.cos(angle), ring_radius * np.sin(angle), np.full_like(angle, height)], -1)
+    back = _unit(spot)
+    right = _unit(np.cross(back, [0., 0., -1.]))
+    ring = np.stack([right, _unit(np.cross(back, right)), back, spot], -1)
+    return local, ring, (bounds * shrink).astype(bounds.dtype)
+
+
+def _with_hwf(c2w, hwf):
+    return np.concatenate([c2w, np.broadcast_to(np.asarray(hwf).reshape(3, 1), c2w.shape[:-1] + (1,))], -1)
 
 
 def load_llff_data(basedir, factor=8, recenter=True, bd_factor=.75, spherify=False, path_zflat=False):
-    """-> images [n,H,W,3], poses [n,3,5], bds [n,2], render_poses [m,3,5] (all float32), i_test (load_llff.py:244-316)."""
-    poses, bds, imgs = _load_data(basedir, factor=factor)
-    # LLFF stores (down, right, back); NeRF wants (right, up, back): swap the first two axes, negate the new second
-    poses = np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1)
-    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
-    images = np.moveaxis(imgs, -1, 0).astype(np.float32)
-    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
-    sc = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
-    poses[:, :3, 3] *= sc
-    bds *= sc
+    c2w, hwf, bounds, images = read_capture(basedir, factor=factor)
+    # (down, right, back) -> (right, up, back); the reference continues in float32 from here on
+    c2w = np.stack([c2w[:, :, 1], -c2w[:, :, 0], c2w[:, :, 2], c2w[:, :, 3]], -1).astype(np.float32)
+    bounds = bounds.astype(np.float32)
+    hwf = hwf.astype(np.float32)
+    if bd_factor is not None:                       # nearest scene depth -> 1 / bd_factor
+        shrink = 1. / (bounds.min() * bd_factor)
+        c2w[:, :, 3] *= shrink
+        bounds = (bounds * shrink).astype(np.float32)
     if recenter:
-        poses = recenter_poses(poses)
+        c2w = in_frame(c2w, mean_frame(c2w)).astype(np.float32)
     if spherify:
-        poses, render_poses, bds = spherify_poses(poses, bds)
+        c2w, path, bounds = normalise_to_sphere(c2w, bounds)
     else:
-        c2w = poses_avg(poses)
-        up = normalize(poses[:, :3, 1].sum(0))
-        close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
-        dt = .75
-        focal = 1. / ((1. - dt) / close_depth + dt / inf_depth)   # "focus depth" of the spiral
-        zdelta = close_depth * .2
-        rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
-        n_views, n_rots = 120, 2
-        if path_zflat:
-            c2w[:3, 3] = c2w[:3, 3] + (-close_depth * .1) * c2w[:3, 2]
-            rads[2] = 0.
-            n_rots, n_views = 1, n_views // 2   # (the reference leaves a float here, which current numpy rejects in linspace)
-        render_poses = render_path_spiral(c2w, up, rads, focal, zdelta, zrate=.5, rots=n_rots, N=n_views)
-    render_poses = np.array(render_poses).astype(np.float32)
-    c2w = poses_avg(poses)
-    i_test = np.argmin(np.sum(np.square(c2w[:3, 3] - poses[:, :3, 3]), -1))
-    return images.astype(np.float32), poses.astype(np.float32), bds, render_poses, i_test
+        centre = mean_frame(c2w)
+        up = _unit(c2w[:, :, 1].sum(0))
+        near_depth, far_depth = bounds.min() * .9, bounds.max() * 5.
+        blend = .75                                  # focus depth: harmonic blend of the depth range
+        focus_depth = 1. / ((1. - blend) / near_depth + blend / far_depth)
+        radii = np.percentile(np.abs(c2w[:, :, 3]), 90, 0)
+        n_views, turns = 120, 2
+        if path_zflat:                               # planar path slightly behind the mean camera
+            centre[:, 3] += -near_depth * .1 * centre[:, 2]
+            radii[2] = 0.
+            n_views, turns = n_views // 2, 1         # (the reference leaves a float count here, which numpy's linspace rejects)
+        path = spiral_path(centre, up, radii, focus_depth, .5, turns, n_views)
+    poses = _with_hwf(c2w, hwf).astype(np.float32)
+    render_poses = _with_hwf(path, hwf).astype(np.float32)
+    holdout = np.argmin(np.sum(np.square(mean_frame(poses[:, :, :4])[:, 3] - poses[:, :, 3]), -1))
+    return images.astype(np.float32), poses, bounds, render_poses, holdout

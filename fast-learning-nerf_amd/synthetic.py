@@ -54,6 +54,26 @@ def render_images(H, W, focal, poses, near=2.0, far=6.0, n_quad=256):
     return torch.stack(out, 0)
 
 
+def render_rays(rays_o, rays_d, near=2.0, far=6.0, n_quad=128):
+    """Colours [N,3] of the analytic scene along arbitrary rays, by the same quadrature as render_images, on the
+    rays' device (fp32 is plenty for training targets).  Used by bench.py's trained-scene leg."""
+    dev, dt_ = rays_o.device, rays_o.dtype
+    t = torch.linspace(near, far, n_quad, device=dev, dtype=dt_)
+    step = (far - near) / (n_quad - 1)
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * t[None, :, None]
+    sig = torch.zeros(pts.shape[:-1], device=dev, dtype=dt_)
+    col = torch.zeros(pts.shape, device=dev, dtype=dt_)
+    for c, s, d, rgb in BLOBS:
+        w = d * torch.exp(-((pts - torch.tensor(c, device=dev, dtype=dt_)) ** 2).sum(-1) / (2 * s * s))
+        sig = sig + w
+        col = col + w[..., None] * torch.tensor(rgb, device=dev, dtype=dt_)
+    col = col / (sig[..., None] + 1e-12)
+    alpha = 1 - torch.exp(-sig * step * rays_d.norm(dim=-1, keepdim=True))
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1 - alpha + 1e-10], -1), -1)[..., :-1]
+    w = alpha * T
+    return (w[..., None] * col).sum(-2) + (1 - w.sum(-1, keepdim=True))
+
+
 def make_dataset(n_images=8, H=32, W=32, fov=0.6911112070083618, radius=4.0, phi=-30.0):
     focal = 0.5 * W / np.tan(0.5 * fov)
     poses = torch.stack([pose_spherical(-180.0 + 360.0 * k / n_images, phi, radius)[:3, :4] for k in range(n_images)], 0)

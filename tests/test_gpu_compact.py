@@ -122,8 +122,8 @@ def test_dead_points_contribute_exact_zeros_and_live_kernels_are_the_plain_kerne
     # => compacted vs plain: only the grouping of fp32 partial sums differs
     scale = g_plain.abs().max().item()
     assert (g_live - g_plain).abs().max().item() < 3e-6 * scale, ((g_live - g_plain).abs().max().item(), scale)
-    # and against the oracle's autograd, like the plain kernels (tests/test_gpu_mlp.py)
-    if n * S <= 20000:
+    # and against the oracle's autograd, at the size and with the bound of the plain kernels' test (tests/test_gpu_mlp.py)
+    if n * S <= 1000:
         sd = {kk: v.clone().requires_grad_(True) for kk, v in weights.items()}
         pts = rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None]
         out = O.run_network(sd, pts, rb[:, 8:11])

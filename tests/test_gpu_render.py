@@ -182,6 +182,32 @@ def test_properties_at_baseline_size(fn, golden_dir, math_mode):
     with torch.no_grad():
         rgb3, _, _, _ = fn.render.render(800, 800, K, chunk=32768, rays=rays[:, perm], near=2.0, far=6.0, **kte)
     assert torch.equal(rgb3, rgb[perm])
+    # ---- oracle comparison AT bench scale (one 4096-ray launch = 12 288 fine tiles on the persistent ticket scheduler) ----
+    g = np.load(os.path.join(golden_dir, 'g7_weights.npz'))
+    sdc = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('c.')}
+    sdf = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('f.')}
+    # (a) 64 of the 4096 rays, spread over the launch incl. its first and last rows: rendered colours vs the oracle
+    pick = torch.cat([torch.arange(0, 4096, 67)[:60], torch.tensor([4092, 4093, 4094, 4095])])
+    rb = O.make_ray_batch(ro.cpu()[pick], rd.cpu()[pick], 2.0, 6.0)
+    ref = O.render_rays(rb, sdc, sdf, 64, 128, white_bkgd=True)           # perturb = 0: no randoms on either side
+    assert (rgb.cpu()[pick] - ref['rgb_map']).abs().max().item() < TOL_RGB
+    assert (ex['rgb0'].cpu()[pick] - ref['rgb0']).abs().max().item() < TOL_RGB
+    assert (acc.cpu()[pick] - ref['acc_map']).abs().max().item() < TOL_RGB
+    # (b) raw logits of three 64-point tiles from the TAIL of the fine pass's tile schedule (the last tickets drawn), evaluated
+    # by the oracle at the device's own sample positions (so the inverse-CDF sensitivity does not enter): kernel-level bound
+    rays11 = fn.ops.pack_rays(ro, rd, 2.0, 6.0)
+    out, _ = fn.render._forward_core(rays11, kte['network_fn'], kte['network_fine'], 64, 128, False, 0., True, None, None, None,
+                                     None, save=False)
+    assert torch.equal(out['rgb_map'], rgb)
+    zf, rawf = out['z_vals'].cpu(), out['raw'].cpu()
+    r11 = rays11.cpu()
+    for tile in (12287, 12286, 12285 - 517):
+        p = torch.arange(tile * 64, tile * 64 + 64)
+        ray, smp = p // 192, p % 192
+        pts = r11[ray, 0:3] + r11[ray, 3:6] * zf[ray, smp][:, None]
+        want = O.run_network(sdf, pts[:, None, :], r11[ray, 8:11])[:, 0]
+        got = rawf[ray, smp]
+        assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), tile
     # a training step at full size decreases the loss on a fixed batch
     tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0)
     tgt = torch.rand(4096, 3, generator=gen).cuda()

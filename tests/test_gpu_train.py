@@ -52,6 +52,64 @@ def test_psnr_at_equal_iterations(fn, math_mode):
     assert abs(tr.lr - opt.lr * 0 - O.lr_schedule(5e-4, 500, n_iters - 1)) < 1e-12
 
 
+def test_psnr_300_iterations_both_modes(fn):
+    """Long-horizon equivalence of the math modes: 300 optimisation steps on the synthetic scene, identical batches and
+    injected randoms, four seeds.  Seed-averaged training PSNR (last 50 iterations) of the default split-bf16 mode within
+    0.1 dB of the exact-fp32 mode; both within 0.1 dB of the CPU oracle over the prefix the oracle is run for."""
+    imgs, poses, focal = fn.synthetic.make_dataset(n_images=6, H=24, W=24)
+    H = W = 24
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    rays = [O.get_rays(H, W, K, poses[i]) for i in range(6)]
+    ro_all = torch.stack([r[0] for r in rays], 0).reshape(-1, 3)
+    rd_all = torch.stack([r[1] for r in rays], 0).reshape(-1, 3)
+    tgt_all = imgs.reshape(-1, 3)
+    n_iters, n_prefix, N, seeds = 300, 60, 192, (0, 1, 2, 3)
+    old = fn.ops.get_math()
+    psnr = {'fp32': [], 'bf16x3': [], 'oracle_prefix': [], 'fp32_prefix': [], 'bf16x3_prefix': []}
+    try:
+        for seed in seeds:
+            gen = torch.Generator().manual_seed(100 + seed)
+            sched = []
+            for it in range(n_iters):
+                sched.append((torch.randint(0, ro_all.shape[0], (N,), generator=gen), torch.rand(N, 16, generator=gen),
+                              torch.rand(N, 16, generator=gen)))
+            init = None
+            for mode in ('fp32', 'bf16x3'):
+                fn.ops.set_math(mode)
+                torch.manual_seed(seed)
+                args = fn.run_nerf.make_args(N_importance=16, N_samples=16, perturb=1.0, white_bkgd=True, no_reload=True,
+                                             lrate=5e-4, lrate_decay=500)
+                ktr, _, _, _, _, _ = fn.run_nerf.create_nerf(args)
+                if init is None:
+                    init = ({k: v.detach().cpu().clone() for k, v in ktr['network_fn'].state_dict().items()},
+                            {k: v.detach().cpu().clone() for k, v in ktr['network_fine'].state_dict().items()})
+                tr = fn.run_nerf.Trainer(ktr, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+                losses = []
+                for sel, t_rand, u in sched:
+                    loss2, _ = tr.step(ro_all[sel].cuda(), rd_all[sel].cuda(), tgt_all[sel].cuda(), t_rand=t_rand.cuda(), u=u.cuda())
+                    losses.append(loss2[0])
+                losses = torch.stack(losses).cpu().numpy()
+                psnr[mode].append(-10 * np.log10(np.mean(losses[-50:])))
+                psnr[mode + '_prefix'].append(-10 * np.log10(np.mean(losses[n_prefix - 10:n_prefix])))
+            sdc, sdf = init
+            opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
+            lc = []
+            for it, (sel, t_rand, u) in enumerate(sched[:n_prefix]):
+                opt.lr = O.lr_schedule(5e-4, 500, it - 1) if it > 0 else 5e-4
+                l1, _, _, _ = O.train_step(sdc, sdf, opt, O.make_ray_batch(ro_all[sel], rd_all[sel], 2.0, 6.0), tgt_all[sel], 16, 16,
+                                           True, t_rand=t_rand, u=u)
+                lc.append(float(l1))
+            psnr['oracle_prefix'].append(-10 * np.log10(np.mean(lc[-10:])))
+    finally:
+        fn.ops.set_math(old)
+    m = {k: float(np.mean(v)) for k, v in psnr.items()}
+    print('PSNR300', {k: [round(float(x), 3) for x in v] for k, v in psnr.items()})
+    assert m['fp32'] > m['fp32_prefix'] + 1.0                                  # 240 more iterations did train
+    assert abs(m['bf16x3'] - m['fp32']) < 0.1, m                               # the modes, at 300 iterations
+    assert abs(m['bf16x3_prefix'] - m['oracle_prefix']) < 0.1, m               # vs the oracle, on its prefix
+    assert abs(m['fp32_prefix'] - m['oracle_prefix']) < 0.1, m
+
+
 def test_train_driver_with_quadtree(fn):
     imgs, poses, focal = fn.synthetic.make_dataset(n_images=4, H=32, W=32)
     torch.manual_seed(0)
