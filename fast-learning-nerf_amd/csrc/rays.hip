@@ -219,6 +219,130 @@ extern "C" int fastnerf_gen_rays_pixels(int64_t n, const int32_t* pix, const flo
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Epoch ray generation on the device.  The reference walks every leaf of every tree in Python, draws
+// its pixels with torch.randint, gathers rays / colours from [n,H,W,3] host arrays and shuffles the epoch with one
+// randperm (tree.py:377-428, 569-626; nerf++-ours/tree.py:548-607 for the variance-weighted picks).  Here ONE launch
+// produces the epoch's rows (rays_o, rays_d, rgb, (image, leaf) tag) in their final shuffled order:
+//   output row j  <-  source index i = perm(j)   (perm: a keyed bijection of [0, N): 6-round Feistel network on the next
+//                      even power of two, cycle-walked into range -- no permutation array, no [N,3] pixel list)
+//   i -> its leaf l by binary search in the exclusive prefix sums of the per-leaf ray counts (the host plan)
+//   i -> pixel: Philox4x32-10 keyed by the seed, counter = i.  Local indices below n_weighted[l] are drawn from the
+//        leaf's clipped-variance distribution by inverse-CDF over the cumulative weights of the pixels sorted by leaf
+//        (image_process.py:58-93); the rest uniformly from the leaf's integer ranges (tree.py:598-599).
+//   pixel -> ray from the pose (get_rays, run_nerf_helpers.py:68-78), colour gathered from the device images.
+// plan rows: image, leaf, count, row_lo, row_hi, col_lo, col_hi (int32).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint64_t feistel_perm(uint64_t j, uint64_t n, int half_bits, uint32_t k0, uint32_t k1) {
+  const uint32_t mask = (half_bits >= 32) ? 0xffffffffu : ((1u << half_bits) - 1u);
+  uint64_t x = j;
+  do {   // cycle walking: the domain 2^(2*half_bits) is < 4n, so < 4 iterations on average
+    uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
+#pragma unroll
+    for (int round = 0; round < 6; ++round) {
+      const uint32_t f = mix32(r ^ (round & 1 ? k1 : k0) ^ (0x9E3779B9u * (uint32_t)(round + 1))) & mask;
+      const uint32_t nl = r;
+      r = l ^ f;
+      l = nl;
+    }
+    x = ((uint64_t)l << half_bits) | r;
+  } while (x >= n);
+  return x;
+}
+
+struct EpochArgs {
+  int64_t N;
+  int L, n_img, H, W, shuffle, half_bits;
+  float fx, fy, cx, cy;
+  uint32_t k0, k1;
+};
+
+__global__ void __launch_bounds__(256) epoch_rays_kernel(EpochArgs a, const int32_t* __restrict__ plan, const int64_t* __restrict__ offs,
+                                                          const float* __restrict__ images, const float* __restrict__ poses,
+                                                          const int32_t* __restrict__ n_weighted, const int64_t* __restrict__ seg_beg,
+                                                          const int64_t* __restrict__ seg_end, const int32_t* __restrict__ order,
+                                                          const double* __restrict__ cum, float* __restrict__ ro,
+                                                          float* __restrict__ rd, float* __restrict__ rgb,
+                                                          int32_t* __restrict__ tag, int32_t* __restrict__ pix) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < a.N; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = a.shuffle ? (int64_t)feistel_perm((uint64_t)j, (uint64_t)a.N, a.half_bits, a.k0, a.k1) : j;
+    // leaf of source index i: the last l with offs[l] <= i
+    int lo = 0, hi = a.L;   // invariant: offs[lo] <= i < offs[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offs[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int32_t* pl = plan + (int64_t)lo * 7;
+    const int img = pl[0], leaf = pl[1];
+    uint32_t r4[4];
+    philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), 0x51ED270Bu, 0u, a.k0, a.k1, r4);
+    int row, col;
+    const int64_t k = i - offs[lo];
+    if (n_weighted && k < n_weighted[lo]) {
+      // inverse CDF over this leaf's segment of the cumulative weights (fp64: 53 random bits)
+      const int64_t b = seg_beg[lo], e = seg_end[lo];
+      const double before = b > 0 ? cum[b - 1] : 0.0;
+      const double tot = cum[e - 1] - before;
+      const double u = ((double)(((uint64_t)r4[2] << 21) ^ (uint64_t)(r4[3] >> 11))) * (1.0 / 9007199254740992.0);
+      const double target = before + u * tot;
+      int64_t l2 = b, h2 = e - 1;   // first position with cum > target
+      while (l2 < h2) {
+        const int64_t m = (l2 + h2) >> 1;
+        if (cum[m] > target) h2 = m; else l2 = m + 1;
+      }
+      const int32_t flat = order[l2];
+      row = (flat / a.W) % a.H;
+      col = flat % a.W;
+    } else {
+      row = pl[3] + (int)(((uint64_t)r4[0] * (uint64_t)(uint32_t)(pl[4] - pl[3])) >> 32);
+      col = pl[5] + (int)(((uint64_t)r4[1] * (uint64_t)(uint32_t)(pl[6] - pl[5])) >> 32);
+    }
+    const float* c = poses + (int64_t)img * 12;
+    float cc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) cc[q] = c[q];
+    float d[3];
+    pixel_ray((float)row, (float)col, a.fx, a.fy, a.cx, a.cy, cc, d);
+    const float* px = images + (((int64_t)img * a.H + row) * a.W + col) * 3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      rd[j * 3 + q] = d[q];
+      ro[j * 3 + q] = cc[4 * q + 3];
+      rgb[j * 3 + q] = px[q];
+    }
+    tag[j * 2] = img;
+    tag[j * 2 + 1] = leaf;
+    if (pix) { pix[j * 3] = img; pix[j * 3 + 1] = row; pix[j * 3 + 2] = col; }
+  }
+}
+
+extern "C" int fastnerf_epoch_rays(int64_t N, int L, const int32_t* plan, const int64_t* offs, const float* images,
+                                   const float* poses, int n_img, int H, int W, float fx, float fy, float cx, float cy,
+                                   uint64_t seed, int shuffle, const int32_t* n_weighted, const int64_t* seg_beg,
+                                   const int64_t* seg_end, const int32_t* order, const double* cum, float* rays_o,
+                                   float* rays_d, float* rgb, int32_t* tag, int32_t* pix, fn_stream_t stream) {
+  FN_CHECK_ARG(N >= 0 && L >= 1 && n_img >= 1 && H >= 1 && W >= 1, "N>=0, L>=1, n_img>=1, H,W>=1");
+  if (N == 0) return 0;
+  FN_CHECK_ARG(plan && offs && images && poses && rays_o && rays_d && rgb && tag, "null pointer");
+  FN_CHECK_ARG(!n_weighted || (seg_beg && seg_end && order && cum), "weighted picks need seg_beg, seg_end, order, cum");
+  FN_CHECK_ARG((int64_t)n_img * H * W < ((int64_t)1 << 31), "pixel ids are int32");
+  EpochArgs a;
+  a.N = N; a.L = L; a.n_img = n_img; a.H = H; a.W = W; a.shuffle = shuffle;
+  a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy;
+  int bits = 2;
+  while (bits < 62 && ((uint64_t)1 << bits) < (uint64_t)N) ++bits;
+  a.half_bits = (bits + 1) / 2;
+  a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
+  hipLaunchKernelGGL(epoch_rays_kernel, dim3(grid_for(N)), dim3(256), 0, fn::S(stream), a, plan, offs, images, poses, n_weighted,
+                     seg_beg, seg_end, order, cum, rays_o, rays_d, rgb, tag, pix);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
 // -1./(W/(2.*focal)) is evaluated in double by Python and then applied as an fp32 scalar
 static inline float ndc_scale(int dim, double focal) { return (float)(-1.0 / ((double)dim / (2.0 * focal))); }
 

@@ -122,6 +122,32 @@ extern "C" int fastnerf_tree_leaf_plan(const fn_tree* t, int image, double ray_n
   return (int)n;
 }
 
+// The per-leaf plans of EVERY tree in one call, concatenated in (image, leaf) order, for the device-side epoch ray
+// generator (fastnerf_epoch_rays): rows of 7 int32 = image, leaf, count, row_lo, row_hi, col_lo, col_hi.  out_host may be
+// NULL to query the sizes.  Returns the number of rows; *n_rays_host = sum of the counts.
+extern "C" int64_t fastnerf_tree_epoch_plan(const fn_tree* t, double ray_num_per_pixel, int last_epoch, int32_t* out_host,
+                                            int64_t* n_rays_host) {
+  if (!t) { fn::set_error("fastnerf_tree_epoch_plan: bad argument"); return -1; }
+  int64_t rows = 0, rays = 0;
+  std::vector<int32_t> tmp;
+  for (int img = 0; img < t->n_images; ++img) {
+    const size_t n = last_epoch ? 1 : t->trees[img].leaves.size();
+    tmp.resize(n * 5);
+    if (fastnerf_tree_leaf_plan(t, img, ray_num_per_pixel, last_epoch, tmp.data()) < 0) return -1;
+    for (size_t i = 0; i < n; ++i) {
+      if (out_host) {
+        int32_t* o = out_host + (rows + (int64_t)i) * 7;
+        o[0] = img; o[1] = (int32_t)i;
+        for (int k = 0; k < 5; ++k) o[2 + k] = tmp[i * 5 + k];
+      }
+      rays += tmp[i * 5];
+    }
+    rows += (int64_t)n;
+  }
+  if (n_rays_host) *n_rays_host = rays;
+  return rows;
+}
+
 extern "C" int64_t fastnerf_tree_adjust(fn_tree* t, const float* table_host, int max_leaves, double thres) {
   if (!t || !table_host || max_leaves < 1) { fn::set_error("fastnerf_tree_adjust: bad argument"); return -1; }
   // torch compares the float32 loss against the Python float after casting it to float32

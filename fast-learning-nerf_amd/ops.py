@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, lib, ptr, require_gpu, stream
+from ._lib import check, lib, ptr, require_gpu, stream  # noqa: F401 (re-exported: tree.py uses ops.ptr / ops.stream)
 
 NET_PARAMS = 595844
 PACKED_FWD = 593920

@@ -17,6 +17,7 @@ API kept (everything run_nerf.py touches):
   save_quadtrees / load_quadtrees: the `treeDivide_{epoch:04d}.pkl` files of run_nerf.py:338-345,542-544,
   written so that the reference's own `pickle.load` accepts them and reading the reference's files.
 """
+import ctypes as C
 import io
 import math
 import pickle
@@ -219,13 +220,16 @@ class QuadTreeManager:
         if not self._t:
             raise RuntimeError('fastnerf_tree_create failed')
         self._views = None           # cached QuadTree views of the native leaf arrays (invalidated by every change)
+        self._version = 0            # bumped by every change of the trees (keys the cached weighted-pick tables)
+        self._wcache = None
         if mseThres != 0.0:
             # variance-gated initial subdivision (tree.py:101-156 with get_error; the reference driver always passes
             # 0.0): built by the Python mirror above, then handed to the native arrays like a loaded pickle
             imgs_np = self.images.cpu().numpy()
             self.quadTrees = [QuadTree(imgs_np[i], mseThres, max_depth) for i in range(self.n_images)]
-        self.result_leaf_id = None   # [N,2] float32 (image, leaf), as the reference stores it
+        self._leaf_id = None         # [N,2] float32 (image, leaf), as the reference stores it (built lazily from the tags)
         self.result_leaf_tag = None  # [N,2] int32 on the device (what the kernels consume)
+
         self._dev_images = None
         self._dev_poses = None
 
@@ -236,6 +240,16 @@ class QuadTreeManager:
                 self._t = None
         except Exception:
             pass
+
+    @property
+    def result_leaf_id(self):
+        if self._leaf_id is None and self.result_leaf_tag is not None:
+            self._leaf_id = self.result_leaf_tag.float()
+        return self._leaf_id
+
+    @result_leaf_id.setter
+    def result_leaf_id(self, v):
+        self._leaf_id = v
 
     # ---- tree state ---------------------------------------------------------------------------
     def num_leaves(self, i):
@@ -297,6 +311,7 @@ class QuadTreeManager:
             check(lib().fastnerf_tree_set_leaves(self._t, i, b.shape[0], b.ctypes.data, float(min_area)),
                   'fastnerf_tree_set_leaves')
         self._views = None
+        self._version += 1
 
     def save_trees(self, path):
         """run_nerf.py:542-544: `pickle.dump(treeManager.quadTrees, f)` in the reference's own class names."""
@@ -471,12 +486,105 @@ class QuadTreeManager:
         self.result_pix = pix
         return pix
 
+    # ---- epoch ray generation in one device launch (csrc/rays.hip epoch_rays_kernel) ------------------------------
+    def epoch_plan(self, down_scale=1, last_epoch=False):
+        """Host plan of the epoch: [L,7] int32 rows (image, leaf, count, row_lo, row_hi, col_lo, col_hi) of all trees,
+        and the total ray count (tree.py:572-581, 598-599)."""
+        ray_num_per_pixel = (self.epoch_size / self.n_images / down_scale) / self.h / self.w
+        n_rays = C.c_int64(0)
+        L = check(lib().fastnerf_tree_epoch_plan(self._t, float(ray_num_per_pixel), int(bool(last_epoch)), None, C.byref(n_rays)),
+                  'fastnerf_tree_epoch_plan')
+        plan = np.empty((L, 7), dtype=np.int32)
+        check(lib().fastnerf_tree_epoch_plan(self._t, float(ray_num_per_pixel), int(bool(last_epoch)), plan.ctypes.data,
+                                             C.byref(n_rays)), 'fastnerf_tree_epoch_plan')
+        return plan, int(n_rays.value)
+
+    def _weighted_tables(self, last_epoch):
+        """Per-leaf inverse-CDF tables of the clipped-variance weights (image_process.py:58-72 per leaf block
+        [int(x0):int(x1), int(y0):int(y1)]): pixels sorted by leaf, running sum of clip(var + 1e-6, 0.01 * leaf mean, .)
+        (the /max and /sum normalisations cancel in the inverse CDF).  Cached until the trees change."""
+        key = (self._version, bool(last_epoch))
+        if self._wcache is not None and self._wcache[0] == key:
+            return self._wcache[1]
+        if self.processor is None:
+            from .image_process import ImageProcessor
+            self.processor = ImageProcessor([self.images[i].cpu().numpy() for i in range(self.n_images)], scale=0,
+                                            sharp_imgs=self._sharp_in)
+        dev = self.device
+        H, W, nI = self.h, self.w, self.n_images
+        sharp = torch.stack([torch.as_tensor(np.asarray(self.processor.sharp_imgs[i]), dtype=torch.float64)
+                             for i in range(nI)], 0).to(dev)
+        boxes = []
+        for i in range(nI):
+            b = np.array([[0.0, 0.0, float(H), float(W)]]) if last_epoch else self.leaves(i)
+            boxes.append(np.concatenate([np.full((b.shape[0], 1), i), np.floor(b)], 1))
+        bx = torch.from_numpy(np.concatenate(boxes, 0)).to(dev).long()            # [L,5] img, int(x0), int(y0), int(x1), int(y1)
+        L = bx.shape[0]
+        gid = torch.arange(1, L + 1, device=dev, dtype=torch.int64)
+        diff = torch.zeros(nI, H + 1, W + 1, device=dev, dtype=torch.int64)       # paint the leaf rectangles (2-D difference array)
+        for (r, c, sgn) in ((1, 2, 1), (1, 4, -1), (3, 2, -1), (3, 4, 1)):
+            diff.index_put_((bx[:, 0], bx[:, r], bx[:, c]), sgn * gid, accumulate=True)
+        leaf_of = diff.cumsum(1).cumsum(2)[:, :H, :W].reshape(-1) - 1
+        g = sharp.reshape(-1) + 1e-6
+        ok = leaf_of >= 0
+        lid = torch.where(ok, leaf_of, torch.zeros_like(leaf_of))
+        cnt = torch.zeros(L, device=dev, dtype=torch.float64).index_add_(0, lid[ok], torch.ones_like(g[ok]))
+        ssum = torch.zeros(L, device=dev, dtype=torch.float64).index_add_(0, lid[ok], g[ok])
+        gmin = 0.01 * ssum / cnt.clamp(min=1.0)
+        wgt = torch.where(ok, torch.maximum(g, gmin[lid]), torch.zeros_like(g))
+        order = torch.argsort(torch.where(ok, leaf_of, torch.full_like(leaf_of, L)), stable=True)
+        cum = torch.cumsum(wgt[order], 0).contiguous()
+        seg_end = torch.cumsum(cnt.long(), 0).contiguous()
+        seg_beg = (seg_end - cnt.long()).contiguous()
+        tabs = dict(order=order.int().contiguous(), cum=cum, seg_beg=seg_beg, seg_end=seg_end, npix=cnt.long())
+        self._wcache = (key, tabs)
+        return tabs
+
+    def gen_rays_device(self, down_scale=1, last_epoch=False, prob=False, rand=1.0, seed=None, shuffle=True, want_pix=False):
+        """The whole epoch in one launch: per-leaf counts -> prefix sums -> Philox pixel draws -> rays from the poses ->
+        colour gather -> (image, leaf) tags, already in shuffled order.  Same distribution as tree.py:377-428 / 569-626
+        (and nerf++-ours/tree.py:548-607 with prob=True: int(n * (1 - rand)) variance-weighted picks per leaf, the rest
+        uniform); the seed comes from torch's global CPU generator unless given.  Returns (rays_o, rays_d, rgb) on the
+        device and sets result_leaf_tag (int32) / result_leaf_id (float32, lazily) / result_pix (when want_pix)."""
+        plan, N = self.epoch_plan(down_scale, last_epoch)
+        dev = self.device
+        imgs, poses = self._dev()
+        offs = np.zeros(plan.shape[0] + 1, dtype=np.int64)
+        np.cumsum(plan[:, 2], out=offs[1:])
+        plan_d = torch.from_numpy(plan).to(dev)
+        offs_d = torch.from_numpy(offs).to(dev)
+        wt = [None] * 5
+        if prob:
+            tabs = self._weighted_tables(last_epoch)
+            n1 = np.floor(plan[:, 2].astype(np.float64) * (1.0 - rand)).astype(np.int32)
+            n1_d = torch.from_numpy(n1).to(dev)
+            n1_d = torch.where(tabs['npix'] > 0, n1_d, torch.zeros_like(n1_d)).contiguous()   # empty integer block: uniform only
+            wt = [n1_d, tabs['seg_beg'], tabs['seg_end'], tabs['order'], tabs['cum']]
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        f32 = dict(device=dev, dtype=torch.float32)
+        ro, rd, rgb = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
+        tag = torch.empty(N, 2, device=dev, dtype=torch.int32)
+        pix = torch.empty(N, 3, device=dev, dtype=torch.int32) if want_pix else None
+        K = self.K
+        check(lib().fastnerf_epoch_rays(N, plan.shape[0], ops.ptr(plan_d), ops.ptr(offs_d), ops.ptr(imgs.contiguous()), ops.ptr(poses.contiguous()),
+                                        self.n_images, self.h, self.w, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
+                                        int(seed), int(bool(shuffle)), *[ops.ptr(t) for t in wt], ops.ptr(ro), ops.ptr(rd), ops.ptr(rgb),
+                                        ops.ptr(tag), ops.ptr(pix), ops.stream()), 'fastnerf_epoch_rays')
+        self.result_leaf_tag = tag
+        self._tags_i32 = tag
+        self._leaf_id = None
+        self.result_pix = pix
+        return ro, rd, rgb
+
     def gen_rays_v3_multiThread(self, down_scale=16, prob=True, randSamp_proc=0.95, debug=False, last_epoch=False,
                                 compat_rng=True):
         """tree.py:377-428.  compat_rng=True draws pixels with torch's global CPU generator in the
         reference's exact call order (per image, per leaf: randint rows, randint cols; then one
-        randperm), so a seeded run selects identical pixels; compat_rng=False draws the same
-        distribution vectorised on the device.  Returns (origins, dirs, rgb) on the device."""
+        randperm), so a seeded run selects identical pixels; compat_rng=False generates the whole epoch
+        in one device launch (gen_rays_device: same distribution).  Returns (origins, dirs, rgb) on the device."""
+        if not compat_rng and self.device.type == 'cuda':
+            return self.gen_rays_device(down_scale, last_epoch, prob=prob, rand=randSamp_proc)
         pix = self.gen_pixels(down_scale, last_epoch, compat_rng, prob=prob, rand=randSamp_proc)
         self.result_leaf_tag = self._tags_i32.to(self.device).contiguous()
         return self.gather(pix)
@@ -493,6 +601,7 @@ class QuadTreeManager:
         tot = check(lib().fastnerf_tree_adjust(self._t, t.data_ptr(), int(t.shape[1]), float(thres)),
                     'fastnerf_tree_adjust')
         self._views = None
+        self._version += 1
         self.cur_level += 1
         return int(tot)
 
@@ -504,6 +613,7 @@ class QuadTreeManager:
         tot = check(lib().fastnerf_tree_adjust_mean(self._t, s.data_ptr(), c.data_ptr(), int(s.shape[1]), float(thres)),
                     'fastnerf_tree_adjust_mean')
         self._views = None
+        self._version += 1
         self.cur_level += 1
         return int(tot)
 

@@ -225,6 +225,24 @@ int64_t fastnerf_tree_adjust_mean(fn_tree* t, const double* sum_host, const int3
                                   double thres);
 
 
+/* ---- epoch ray generation on the device (gen_rays_v3_multiThread + gen_rays_v3_1_subThread, tree.py:377-428, 569-626;
+ * the variance-weighted picks of nerf++-ours/tree.py:566-578 + image_process.py:58-93) ------------------------------
+ * fastnerf_tree_epoch_plan (host): the plans of all trees in one call, rows of 7 int32 = image, leaf, ray count,
+ * row_lo, row_hi, col_lo, col_hi; out_host may be NULL to query sizes; returns rows, *n_rays_host = total rays.
+ * fastnerf_epoch_rays (device): N rows (rays_o, rays_d, rgb [N,3], tag [N,2] = image, leaf; pix [N,3] optional) in
+ * their final shuffled order (replaces the per-leaf torch.randint draws, the [n,H,W,3] gathers and the epoch's
+ * torch.randperm).  plan [L,7] and offs [L+1] (int64 exclusive prefix sums of the counts) are device copies of the
+ * host plan; images [n_img,H,W,3], poses [n_img,3,4].  Weighted picks (all five pointers or none): per leaf the first
+ * n_weighted[l] rays are drawn with probability proportional to the weights whose running sum over the pixels sorted
+ * by leaf is cum (fp64); order = flat pixel ids in that order; seg_beg / seg_end = the leaf's range in it. */
+int64_t fastnerf_tree_epoch_plan(const fn_tree* t, double ray_num_per_pixel, int last_epoch, int32_t* out_host,
+                                 int64_t* n_rays_host);
+int fastnerf_epoch_rays(int64_t N, int L, const int32_t* plan, const int64_t* offs, const float* images,
+                        const float* poses, int n_img, int H, int W, float fx, float fy, float cx, float cy,
+                        uint64_t seed, int shuffle, const int32_t* n_weighted, const int64_t* seg_beg,
+                        const int64_t* seg_end, const int32_t* order, const double* cum, float* rays_o, float* rays_d,
+                        float* rgb, int32_t* tag, int32_t* pix, fn_stream_t stream);
+
 /* ---- exact zero-gradient point compaction of the training backward -------------------------------------------
  * loss.backward() (run_nerf.py:493) spends most of its time on samples whose d(loss)/d(raw) is exactly zero
  * (sigma + noise <= 0 => alpha = 0 => weight = 0 and relu' = 0; render.py:162,182): all of their pre-activation

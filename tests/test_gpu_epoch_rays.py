@@ -1,0 +1,142 @@
+"""Device-side epoch ray generation (csrc/rays.hip epoch_rays_kernel behind QuadTreeManager.gen_rays_device /
+gen_rays_v3_multiThread(compat_rng=False)): one launch per epoch replaces tree.py:377-428, 569-626 (per-leaf
+torch.randint draws, [n,H,W,3] gathers, the epoch randperm) and nerf++-ours/tree.py:566-578 (variance-weighted picks).
+Checked: per-leaf ray counts EXACTLY the reference's rule, every pixel inside its leaf's integer ranges, rays and colours
+identical to the stand-alone kernels at the drawn pixels, the shuffle is a bijection that mixes batches, uniform /
+weighted pixel histograms within 5 sigma of the reference's distributions; and the generation time at 100 x 800 x 800."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def fn():
+    import fastnerf
+    return fastnerf
+
+
+def _mgr(fn, n=3, H=64, W=48, depth=2, seed=0, sharp=None):
+    gen = torch.Generator().manual_seed(seed)
+    imgs = torch.rand(n, H, W, 3, generator=gen)
+    poses = torch.stack([fn.synthetic.pose_spherical(40.0 * i, -30.0, 4.0)[:3, :4] for i in range(n)], 0)
+    K = np.array([[50.0, 0, W / 2], [0, 50.0, H / 2], [0, 0, 1]])
+    return fn.tree.QuadTreeManager(H, W, K, imgs, poses, 0.0, depth, sharp_imgs=sharp), imgs, poses, K
+
+
+def _refine(mgr, rounds=2, seed=5):
+    """Two adjust rounds with a random error table -> leaves of different depths (counts 10 and int(area))."""
+    gen = torch.Generator().manual_seed(seed)
+    for _ in range(rounds):
+        ml = mgr.max_leaves()
+        table = torch.rand(mgr.n_images, ml, generator=gen)
+        mgr.adjust_tree_from_table(table, thres=0.5)
+
+
+def test_counts_ranges_rays_and_shuffle(fn):
+    mgr, imgs, poses, K = _mgr(fn)
+    _refine(mgr)
+    plan, N = mgr.epoch_plan(down_scale=1)
+    assert N == int(plan[:, 2].sum()) and plan.shape[0] == sum(mgr.num_leaves(i) for i in range(3))
+    assert set(np.unique(plan[:, 2])) - {10} != set()                      # mixed: coarse leaves (10 rays) and finest ones
+    for i in range(3):                                                       # the one-call plan == the per-image plans
+        assert np.array_equal(plan[plan[:, 0] == i][:, 2:], mgr.leaf_plan(i, 1.0))
+    torch.manual_seed(3)
+    ro, rd, rgb = mgr.gen_rays_device(down_scale=1, want_pix=True)
+    tag, pix = mgr.result_leaf_tag.cpu().long(), mgr.result_pix.cpu().long()
+    assert ro.shape == (N, 3) and tag.shape == (N, 2) and torch.equal(mgr.result_leaf_id.cpu(), tag.float())
+    # per-(image, leaf) counts: exactly the plan
+    base = np.concatenate([[0], np.cumsum([mgr.num_leaves(i) for i in range(3)])])
+    gl = torch.from_numpy(base[:-1])[tag[:, 0]] + tag[:, 1]
+    assert torch.equal(torch.bincount(gl, minlength=plan.shape[0]), torch.from_numpy(plan[:, 2]).long())
+    # pixels inside the leaf's integer ranges, image ids consistent
+    pl = torch.from_numpy(plan).long()[gl]
+    assert torch.equal(pix[:, 0], tag[:, 0])
+    assert ((pix[:, 1] >= pl[:, 3]) & (pix[:, 1] < pl[:, 4]) & (pix[:, 2] >= pl[:, 5]) & (pix[:, 2] < pl[:, 6])).all()
+    # rays / colours == the stand-alone ray kernel and a plain gather at those pixels
+    ro2, rd2 = fn.ops.gen_rays_pixels(mgr.result_pix, poses.cuda(), K)
+    assert torch.equal(ro, ro2) and torch.equal(rd, rd2)
+    assert torch.equal(rgb.cpu(), imgs[pix[:, 0], pix[:, 1], pix[:, 2]])
+    # same seed -> same epoch; the shuffle only permutes rows: unshuffled generation has the same multiset of rows
+    torch.manual_seed(3)
+    ro_b, _, _ = mgr.gen_rays_device(down_scale=1, want_pix=True)
+    assert torch.equal(ro_b, ro)
+    torch.manual_seed(3)
+    mgr.gen_rays_device(down_scale=1, want_pix=True, shuffle=False)
+    pix_u, tag_u = mgr.result_pix.cpu().long(), mgr.result_leaf_tag.cpu().long()
+    assert torch.equal(tag_u[:, 0], torch.sort(tag_u[:, 0]).values)          # leaf order without the shuffle
+    key = lambda p, t: torch.sort(((p[:, 0] * 64 + p[:, 1]) * 48 + p[:, 2]) * 4096 + t[:, 1]).values
+    assert torch.equal(key(pix_u, tag_u), key(pix, tag))
+    # ... and it mixes: the image histogram of every 512-row batch is within 5 sigma of the epoch's proportions
+    p_img = torch.bincount(tag[:, 0], minlength=3).double() / N
+    for b0 in range(0, N - 511, 512):
+        h = torch.bincount(tag[b0:b0 + 512, 0], minlength=3).double()
+        assert ((h - 512 * p_img).abs() <= 5 * torch.sqrt(512 * p_img * (1 - p_img)) + 1).all()
+
+
+def test_uniform_and_weighted_pixel_distributions(fn):
+    H, W = 32, 32
+    rng = np.random.RandomState(0)
+    sharp = [np.abs(rng.randn(H, W)) ** 2 * 0.05 for _ in range(2)]          # variance maps as an input fixture
+    sharp[0][:8, :8] = 0.0                                                   # a flat block: clipped to 1 % of the leaf mean
+    mgr, imgs, poses, K = _mgr(fn, n=2, H=H, W=W, depth=2, sharp=sharp)
+    rounds, rand = 300, 0.25
+    hist = torch.zeros(2, H, W, dtype=torch.float64)
+    for r in range(rounds):
+        mgr.gen_rays_device(down_scale=1, prob=True, rand=rand, seed=1000 + r, want_pix=True)
+        p = mgr.result_pix.long()
+        hist += torch.bincount((p[:, 0] * H + p[:, 1]) * W + p[:, 2], minlength=2 * H * W).reshape(2, H, W).cpu().double()
+    plan, N = mgr.epoch_plan(down_scale=1)
+    assert int(hist.sum()) == rounds * N
+    # expectation per pixel: leaf count * [ (1-rand) share by clipped variance (image_process.py:58-72) + rand share uniform ]
+    from fastnerf.image_process import ImageProcessor
+    proc = ImageProcessor([imgs[i].numpy() for i in range(2)], scale=0, sharp_imgs=sharp)
+    worst = 0.0
+    for i in range(2):
+        boxes = mgr.leaves(i)
+        pl = mgr.leaf_plan(i, 1.0)
+        for li, (x0, y0, x1, y1) in enumerate(boxes):
+            n = int(pl[li, 0])
+            n1 = int(n * (1 - rand))
+            prob = proc.to_prob_v2(sharp[i][int(x0):int(x1), int(y0):int(y1)])
+            uni = np.zeros_like(prob)
+            uni[pl[li, 1] - int(x0):pl[li, 2] - int(x0), pl[li, 3] - int(y0):pl[li, 4] - int(y0)] = 1.0
+            uni /= uni.sum()
+            expect = rounds * (n1 * prob + (n - n1) * uni)
+            got = hist[i, int(x0):int(x1), int(y0):int(y1)].numpy()
+            sig = np.sqrt(np.maximum(expect, 1.0))
+            worst = max(worst, float(np.abs(got - expect).max() / sig.max()), float((np.abs(got - expect) / sig).max()))
+            assert (np.abs(got - expect) <= 5 * sig + 2).all(), (i, li)
+    # uniform-only epoch: every pixel of a finest leaf equally likely
+    hist2 = torch.zeros(2 * H * W, dtype=torch.float64)
+    for r in range(200):
+        mgr.gen_rays_device(down_scale=1, prob=False, seed=77 + r, want_pix=True)
+        p = mgr.result_pix.long()
+        hist2 += torch.bincount((p[:, 0] * H + p[:, 1]) * W + p[:, 2], minlength=2 * H * W).cpu().double()
+    exp = 200.0 * N / (2 * H * W)
+    assert ((hist2 - exp).abs() <= 5 * np.sqrt(exp) + 2).all()
+
+
+def test_epoch_generation_at_full_scale(fn, capsys):
+    """100 views of 800 x 800, depth-7 trees: 64 M rays in one launch; time printed for DESIGN.md."""
+    n, H, W = 100, 800, 800
+    imgs = torch.rand(n, H, W, 3)
+    poses = torch.stack([fn.synthetic.pose_spherical(-180.0 + 3.6 * i, -30.0, 4.0)[:3, :4] for i in range(n)], 0)
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+    K = np.array([[focal, 0, 400.0], [0, focal, 400.0], [0, 0, 1]])
+    mgr = fn.tree.QuadTreeManager(H, W, K, imgs, poses, 0.0, 7)
+    mgr.gen_rays_device(down_scale=4)                                      # warm-up (uploads images and poses)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ro, rd, rgb = mgr.gen_rays_device(down_scale=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert ro.shape[0] == n * H * W and mgr.result_leaf_tag.shape == (n * H * W, 2)
+    sel = torch.randint(0, ro.shape[0], (4096,))
+    assert torch.isfinite(rd[sel.cuda()]).all()
+    with capsys.disabled():
+        print('\nEPOCHGEN 100x800x800 depth 7: %d rays in %.3f s (%.1f M rays/s)' % (ro.shape[0], dt, ro.shape[0] / dt / 1e6))
+    assert dt < 5.0

@@ -263,3 +263,34 @@ def test_render_single_image_g14(fn, golden_dir, math_mode):
             # parity bar, per-ray depths get the looser one
             tol = TOL_RGB if ('rgb' in k or k == 'bg_lambda') else 2e-3
             assert err < tol * max(1.0, np.abs(ref).max()), (m, k, err)
+
+
+def test_pp_loader_rays(fn, golden_dir, tmp_path):
+    """nerf++ scene-directory reader: rays / depth of every view and seeded random_sample batches vs the reference (G17);
+    the samplers plug into render_single_image."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('pp_loader_golden', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'test_pp_loader_golden.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    write_scene = mod.write_scene
+    from fastnerf.data_loader_split import load_data_split
+    g = np.load(os.path.join(golden_dir, 'g17_pp_loader.npz'))
+    base = str(tmp_path)
+    write_scene(g, base)
+    for split, n in (('train', 3), ('test', 2)):
+        samplers = load_data_split(base, 'scene', split)
+        for i, s in enumerate(samplers):
+            p = '%s.out%d.' % (split, i)
+            al = s.get_all()
+            assert al['ray_o'].shape == (24, 3) and al['rgb'].shape == (24, 3) and al['ray_d'].is_cuda
+            assert np.abs(al['ray_o'].cpu().numpy() - g[p + 'rays_o']).max() < 1e-6
+            assert np.abs(al['ray_d'].cpu().numpy() - g[p + 'rays_d']).max() < 2e-6
+            assert np.abs(al['depth'].cpu().numpy() - g[p + 'depth']).max() < 1e-6
+            assert (al['mask'] is None) == (split == 'test')
+        np.random.seed(5)
+        a = samplers[0].random_sample(7, center_crop=False)
+        b = samplers[1].random_sample(4, center_crop=True)
+        assert np.abs(a['ray_d'].cpu().numpy() - g['%s.rand_ray_d' % split]).max() < 2e-6
+        assert np.abs(a['rgb'].numpy() - g['%s.rand_rgb' % split]).max() < 1e-7
+        assert np.abs(b['ray_d'].cpu().numpy() - g['%s.crop_ray_d' % split]).max() < 2e-6
+        assert a['img_name'].endswith('000.png') and list(a.keys()) == ['ray_o', 'ray_d', 'depth', 'rgb', 'mask', 'min_depth', 'img_name']

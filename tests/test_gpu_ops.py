@@ -53,6 +53,11 @@ def test_gen_rays_g1(fn, golden_dir):
     pix = torch.tensor([[0, int(r), int(c)] for r, c in idx], dtype=torch.int32).cuda()
     ro, rd = fn.ops.gen_rays_pixels(pix, G(g['c2w'])[None].contiguous(), g['K'])
     assert torch.equal(rd.cpu(), d.cpu()[idx[:, 0], idx[:, 1]])
+    # the numpy twin (run_nerf_helpers.py:81-88; only the dead use_batching prelude calls it): numpy in, numpy out
+    onp, dnp = fn.run_nerf_helpers.get_rays_np(6, 8, Ks, g['c2w'])
+    assert isinstance(onp, np.ndarray) and onp.shape == (6, 8, 3) and onp.dtype == np.float32
+    assert np.array_equal(onp, g['np_o'])
+    ok, e = close(dnp, g['np_d'], 1e-6); assert ok, e
 
 
 def test_ndc_g2(fn, golden_dir):
