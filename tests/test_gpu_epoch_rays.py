@@ -134,7 +134,8 @@ def test_epoch_generation_at_full_scale(fn, capsys):
     ro, rd, rgb = mgr.gen_rays_device(down_scale=1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    assert ro.shape[0] == n * H * W and mgr.result_leaf_tag.shape == (n * H * W, 2)
+    n_rays = n * 4096 * 156          # depth 7: 4096 leaves of 156.25 px^2 per view, int(area * 1.0) rays each (tree.py:581)
+    assert ro.shape[0] == n_rays and mgr.result_leaf_tag.shape == (n_rays, 2)
     sel = torch.randint(0, ro.shape[0], (4096,))
     assert torch.isfinite(rd[sel.cuda()]).all()
     with capsys.disabled():
