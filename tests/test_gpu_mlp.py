@@ -259,6 +259,44 @@ def test_large_batch_consistency(fn, weights):
     assert (ga - gb).abs().max().item() < 2e-2 * ga.abs().max().item()   # ReLU-mask-flip floor, DESIGN section 4
 
 
+def test_training_forward_stress_at_bench_size(fn, weights, math_mode):
+    """the training forward once showed a timing-dependent corruption (bias missing in lanes 48..63 of one
+    accumulator register on ~0.1 % of the points) that disappeared with -fno-slp-vectorize and was never root-caused; at
+    HEAD it does not reproduce with SLP on either (tools/slp_bisect.py: 0 bad points in 5 x 40 launches of 786 432 points,
+    profiles/r02_slp_bisect.md).  This is the witness that caught it, at the bench size (12 288 tiles, 24 per persistent
+    workgroup), repeated: the saving forward must reproduce the non-saving forward bit for bit on every launch, and the
+    saved layer-7 activations must decode to the values that produce those outputs."""
+    flat = flat_of(weights).cuda()
+    gen = torch.Generator().manual_seed(321)
+    n, S = 4096, 192
+    ro = torch.randn(n, 3, generator=gen) * 0.3
+    rd = torch.randn(n, 3, generator=gen)
+    rays = torch.from_numpy(O.make_ray_batch(ro, rd, 2.0, 6.0).numpy()).cuda()
+    z = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, -1).values.cuda()
+    pf, pb = fn.ops.mlp_pack(flat)
+    act = torch.empty(fn.ops.act_floats(n * S)).cuda()
+    ref = fn.ops.mlp_fwd(rays, z, flat, pf).clone()
+    assert torch.isfinite(ref).all()
+    for rep in range(12):
+        got = fn.ops.mlp_fwd(rays, z, flat, pf, act=act)
+        bad = int((got != ref).any(-1).sum())
+        assert bad == 0, 'launch %d: %d of %d points differ between the saving and the non-saving forward' % (rep, bad, n * S)
+        assert torch.equal(fn.ops.mlp_fwd(rays, z, flat, pf), ref)
+    if math_mode == 'bf16x3':
+        # alpha = h7 . w_alpha + b_alpha recomputed from the SAVED layer-7 activations of 64 tiles spread over the launch
+        nt = n * S // 64
+        lo = 7 * nt * 4096                                     # ba_h(nt, 7) in 16-byte units: only the h7 block is copied
+        buf = act[lo * 4:(lo + nt * 4096) * 4].view(torch.int16).cpu().numpy().view(np.uint16)
+        base = 0
+        wa = weights['alpha_linear.weight'].numpy().reshape(-1).astype(np.float64)
+        ba = float(weights['alpha_linear.bias'])
+        for tile in list(range(0, nt, nt // 60))[:60] + [nt - 1]:
+            h7 = decode_kfrag(buf, base + tile * 4096, 8, 1, True).astype(np.float64)       # [64, 256]
+            alpha = h7 @ wa + ba
+            want = ref.reshape(-1, 4)[tile * 64:(tile + 1) * 64, 3].cpu().numpy()
+            assert np.abs(alpha - want).max() < 2e-5 * max(1.0, np.abs(want).max()), tile
+
+
 def test_tile_scheduler_back_to_back_and_streams(fn, weights):
     """The persistent forward / dX kernels draw their tiles from a self-resetting ticket counter (one counter pair per
     launch from a pool): many launches of very different sizes, back to back and interleaved on two streams, must

@@ -164,7 +164,11 @@ def test_sample_pdf_g6(fn, golden_dir):
     for key, kw in (('spike_det', dict(det=True)), ('spike_u', dict(u=G(g['u'])))):
         got = fn.ops.sample_pdf(bins, w, 128, **kw).cpu().numpy()
         err = np.abs(got - g[key])
-        assert (err < 2e-5).mean() > 0.9 and err.max() <= width, (key, (err < 2e-5).mean(), err.max())
+        out_frac = float((err >= 2e-5).mean())
+        assert out_frac < 0.1 and err.max() <= width, \
+            '%s: %.3f %% of the samples off by more than 2e-5 (bound 10 %% at the reference\'s own discontinuity), worst %.3e' % (
+                key, 100 * out_frac, err.max())
+        print('SAMPLEPDF %s outlier fraction %.4f %% max %.2e' % (key, 100 * out_frac, err.max()))
     # reference's pytest hook through the mirrored signature
     got = fn.run_nerf_helpers.sample_pdf(bins, G(g['w_rand']), 128, det=False, pytest=True)
     ok, e = close(got, g['rand_u'], 2e-5); assert ok, e
@@ -185,7 +189,11 @@ def test_sample_pdf_merge_vs_oracle(fn):
         width = float((z[:, 1:] - z[:, :-1]).max())
         for a, b in ((zs, smp), (zo, ref)):
             err = (a.cpu() - b).abs()
-            assert (err < 2e-5).float().mean() > 0.98 and err.max() <= width, (S, Ni, float(err.max()))
+            out_frac = float((err >= 2e-5).float().mean())
+            assert out_frac < 0.02 and err.max() <= width, \
+                'S=%d Ni=%d: %.4f %% of the samples off by more than 2e-5 (bound 2 %%), worst %.3e of a %.3e bin' % (
+                    S, Ni, 100 * out_frac, float(err.max()), width)
+            print('SAMPLEPDF injected-u S=%d Ni=%d outlier fraction %.5f %% max %.2e' % (S, Ni, 100 * out_frac, float(err.max())))
         assert (zo[:, 1:] >= zo[:, :-1]).all()
         ok, e = close(zstd, torch.std(smp, -1, unbiased=False), 2e-5, 1e-5); assert ok, e
         # merged output is exactly the multiset union of its own inputs (bit-exact index work)
@@ -198,7 +206,11 @@ def test_sample_pdf_merge_vs_oracle(fn):
         # the sample to the bin's left edge) make a 1-ulp cdf difference move a sample by one whole
         # bin, in the reference itself; require the bulk to agree and outliers to stay within a bin
         err = (zo2.cpu() - ref_d).abs()
-        assert (err < 2e-5).float().mean() > 0.98 and err.max() <= width, (S, Ni, float(err.max()))
+        out_frac = float((err >= 2e-5).float().mean())
+        assert out_frac < 0.02 and err.max() <= width, \
+            'det S=%d Ni=%d: %.4f %% of the samples off by more than 2e-5 (bound 2 %%), worst %.3e of a %.3e bin' % (
+                S, Ni, 100 * out_frac, float(err.max()), width)
+        print('SAMPLEPDF det S=%d Ni=%d outlier fraction %.5f %% max %.2e' % (S, Ni, 100 * out_frac, float(err.max())))
 
 
 def test_mse_leafmax_and_adam(fn):
