@@ -8,7 +8,7 @@ The directory name contains '-', import it with
 or through the `fastnerf` shim module at the repository root.
 """
 from . import _lib, ops  # noqa: F401
-from . import run_nerf_helpers, model, render, run_nerf, tree, parallel, synthetic, nerfpp  # noqa: F401
+from . import run_nerf_helpers, model, render, run_nerf, tree, parallel, synthetic, nerfpp, torch_ops  # noqa: F401
 from .build import build  # noqa: F401
 
 __all__ = ['ops', 'run_nerf_helpers', 'model', 'render', 'run_nerf', 'tree', 'parallel', 'build']

@@ -1,0 +1,53 @@
+"""`torch.ops.fastnerf.*`: the C-ABI entry points registered as PyTorch custom ops (fastnerf/torch_ops.py) -- schemas and
+fake-tensor shapes on CPU; values and the registered autograd formula on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_registered_schemas_and_fake_shapes():
+    import fastnerf
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in fastnerf.torch_ops.OPS:
+        op = getattr(torch.ops.fastnerf, name)
+        assert str(op.default._schema).startswith('fastnerf::' + name + '(')
+    assert 'Tensor(a0!) params' in str(torch.ops.fastnerf.adam_step.default._schema)       # in-place ops declare it
+    with FakeTensorMode():
+        z, raw, r11 = torch.empty(5, 7), torch.empty(5, 7, 4), torch.empty(5, 11)
+        out = torch.ops.fastnerf.raw2outputs(raw, z, r11, None, True)
+        assert [tuple(o.shape) for o in out] == [(5, 3), (5,), (5,), (5, 7), (5,)]
+        assert torch.ops.fastnerf.sample_pdf_merge(z, z, 3, True, None, 0)[0].shape == (5, 10)
+        assert torch.ops.fastnerf.posenc(torch.empty(9, 3), 10).shape == (9, 63)
+        assert torch.ops.fastnerf.mlp_fwd(r11, z, torch.empty(3), torch.empty(3)).shape == (5, 7, 4)
+    with pytest.raises(RuntimeError):
+        torch.ops.fastnerf.posenc(torch.zeros(2, 3), 4)          # no CPU kernel behind the op either
+
+
+@pytest.mark.gpu
+def test_custom_ops_on_the_gpu(golden_dir):
+    import fastnerf
+    g = np.load(os.path.join(golden_dir, 'g5_raw2out_S64_wb1.npz'))
+    raw = torch.from_numpy(g['raw']).cuda().requires_grad_(True)
+    z = torch.from_numpy(g['z']).cuda()
+    r11 = torch.zeros(64, 11).cuda()
+    r11[:, 3:6] = torch.from_numpy(g['rd']).cuda()
+    rgb, disp, acc, w, depth = torch.ops.fastnerf.raw2outputs(raw, z, r11, None, True)
+    assert np.abs(rgb.detach().cpu().numpy() - g['rgb']).max() < 2e-6
+    assert np.abs(w.detach().cpu().numpy() - g['weights']).max() < 2e-6
+    (rgb * torch.from_numpy(g['cot']).cuda()).sum().backward()                  # the registered autograd formula
+    assert np.abs(raw.grad.cpu().numpy() - g['graw']).max() < 2e-6 * max(1.0, np.abs(g['graw']).max())
+    x = torch.rand(100, 3).cuda()
+    assert torch.equal(torch.ops.fastnerf.posenc(x, 10), fastnerf.ops.posenc(x, 10))
+    draw = torch.randn(3000, 4).cuda()
+    draw[::3] = 0
+    idx, cnt = torch.ops.fastnerf.compact_live(draw)
+    assert cnt.cpu().tolist() == [2000, 3000] and int(idx[0]) == 1
+    p, gr, m, v = (torch.randn(1000).cuda() for _ in range(4))
+    v.abs_()
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    torch.ops.fastnerf.adam_step(p, gr, m, v, 5e-4, 3, 0.9, 0.999, 1e-8)
+    fastnerf.ops.adam_step(p2, gr, m2, v2, 5e-4, 3, 0.9, 0.999, 1e-8)
+    assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2) and not torch.equal(p, gr)
+    torch.library.opcheck(torch.ops.fastnerf.sample_coarse.default, (r11, 16, False, False, None, 0), test_utils=('test_schema', 'test_faketensor'))
