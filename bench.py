@@ -299,12 +299,26 @@ def main():
         try:
             tr32, _ = new_trainer()
             n32 = max(20, a.steps)
-            t32, l32, _ = timed(tr32, 0, 3, n32, noise=True)   # (the exact-fp32 mode has no compacted backward: round-1 protocol)
+            t32, l32, _ = timed(tr32, 0, 3, n32, noise=True)   # round-1 protocol: random init, noise targets
             dt32 = t32 / n32
-            alt = {'math_mode': 'fp32', 'dtype': 'f32', 'value': N_RAYS / dt32, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt32,
-                   'steps': n32, 'warmup': 3, 'final_loss': [float(x) for x in l32.tolist()],
-                   'step_frac_of_fp32_mfma_peak': N_RAYS / dt32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                   'roofline': mlp_roofline(tr32, False, None)}
+            # steady state: the trained state of the main leg (same weights, Adam moments, LR position), W = 3, K = n32
+            with torch.no_grad():
+                tr32.flat.copy_(tr.flat); tr32.m.copy_(tr.m); tr32.v.copy_(tr.v)
+            tr32.adam_t, tr32.global_iter, tr32.lr = tr.adam_t, tr.global_iter, tr.lr
+            tr32.repack()
+            tr32.live = fastnerf.render.LivePolicy()
+            ts32, ls32, _ = timed(tr32, a.scene_steps, 3, n32)
+            c32 = tr32.live_counts.cpu().tolist() if tr32.last_step_live else None
+            alt = {'math_mode': 'fp32', 'dtype': 'f32', 'value': N_RAYS * n32 / ts32, 'unit': 'rays/s', 'ms_per_step': 1e3 * ts32 / n32,
+                   'steps': n32, 'warmup': 3, 'final_loss': [float(x) for x in ls32.tolist()],
+                   'what': 'steady state of the trained scene (the main leg\'s weights), exact-fp32 MFMA kernels',
+                   'backward': 'compacted' if tr32.last_step_live else 'plain',
+                   'live_fraction': None if c32 is None else {'fine': c32[0] / max(1, c32[1]), 'coarse': c32[2] / max(1, c32[3])},
+                   'step_frac_of_fp32_mfma_peak': N_RAYS * n32 / ts32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                   'init_state': {'value': N_RAYS / dt32, 'ms_per_step': 1e3 * dt32, 'final_loss': [float(x) for x in l32.tolist()],
+                                  'step_frac_of_fp32_mfma_peak': N_RAYS / dt32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                  'what': 'random init, U[0,1) targets, plain backward: the protocol of BENCH_r01'},
+                   'roofline': mlp_roofline(tr32, False, c32[0] / max(1, c32[1]) if c32 else None)}
             del tr32
         finally:
             ops.set_math(main_mode)

@@ -73,7 +73,9 @@ SIGNATURES = {
     'fastnerf_compact_live': (I, [L, P, P, P, P, P]),
     'fastnerf_mlp_bf16_fwd_live': (I, [I, L, I, P, P, P, P, P, P, P, P]),
     'fastnerf_mlp_bf16_bwd_live': (I, [I, L, I, P, P, P, P, P, P, P, P, P, P]),
-    'fastnerf_render_rays_bwd_live': (I, [L, I, I, P, I] + [P] * 22 + [P]),
+    'fastnerf_mlp_fwd_live_ex': (I, [I, L, I, P, P, P, P, P, P, P, P]),
+    'fastnerf_mlp_bwd_live_ex': (I, [I, L, I, P, P, P, P, P, P, P, P, P, P]),
+    'fastnerf_render_rays_bwd_live': (I, [I, L, I, I, P, I] + [P] * 22 + [P]),
 }
 
 _lib = None

@@ -398,7 +398,12 @@ template <bool SAVE, bool BG>
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                const float* __restrict__ params, const float* __restrict__ packed, float* __restrict__ raw,
-               float* __restrict__ act, NetLayout lay, unsigned* __restrict__ sched) {
+               float* __restrict__ act, NetLayout lay, unsigned* __restrict__ sched, const int* __restrict__ live_idx,
+               const int* __restrict__ live_cnt) {
+  // live-list mode (exact zero-gradient point compaction, see mlp_bf16.hip / train.hip): row j of the launch is point
+  // live_idx[j], the row count is a device value; the saved tensors keep the strides of the capacity PL they were sized for
+  const int64_t PL = P;
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;
   float* Es = smem + LDS_H;
@@ -420,11 +425,12 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     unsigned long long* maskw =
-        SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(P, PEP)) + tile * (8 * NWAVES * 64) : nullptr;
+        SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(PL, PEP)) + tile * (8 * NWAVES * 64) : nullptr;
     // ---- phase A: points + positional encoding -> Es (+ X2) ---------------------------
     const int pm = tid >> 2, pq = tid & 3;
     int64_t pp = p0 + pm;
     if (pp >= P) pp = P - 1;
+    if (live_idx) pp = live_idx[pp];
     const int64_t ray = pp / S;
     const float* rr = rays + ray * 11;
     float x4[4] = {0.f, 0.f, 0.f, 0.f};   // BG: kept live for the L5 re-encode of channels 64..83
@@ -469,7 +475,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     }
     __syncthreads();
     if (SAVE) {
-      float* ape = act + act_pe(P, PEP) + p0 * PEP;
+      float* ape = act + act_pe(PL, PEP) + p0 * PEP;
       for (int i = tid; i < TM * 16; i += NTHR) {
         const int m = i >> 4, sl = i & 15;
         if (m < valid)
@@ -503,7 +509,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       zero_acc<2>(acc);
       const float4* B = pk + lay.PF[l] / 4;
       load_bias<2>(bv2, params + lay.LB[l], wn, lane);
-      float* sv = SAVE ? act + act_h(P, PEP, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
+      float* sv = SAVE ? act + act_h(PL, PEP, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
       if (l == 5) {
         const int KS5 = (PEP + 256) / 8;
         if (!BG) {
@@ -557,12 +563,12 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     zero_acc<2>(acc);
     load_bias<2>(bv2, params + lay.FB, wn, lane);
     gemm_seg<2, 0>(acc, Hs, 0, 32, pk + lay.PF[8] / 4, 32, 0, wn * 2, wm, lane, dbg,
-                   SAVE ? act + act_h(P, PEP, 7) + p0 * 256 : nullptr, valid, wave);
+                   SAVE ? act + act_h(PL, PEP, 7) + p0 * 256 : nullptr, valid, wave);
     __syncthreads();
     epilogue_fwd<2, false>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
     __syncthreads();
     if (SAVE) {
-      float* avp = act + act_vpe(P, PEP) + p0 * 32;
+      float* avp = act + act_vpe(PL, PEP) + p0 * 32;
       for (int i = tid; i < TM * 8; i += NTHR) {
         const int m = i >> 3, sl = i & 7;
         if (m < valid)
@@ -576,13 +582,13 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       float bv1[1];
       load_bias<1>(bv1, params + lay.VB, wn, lane);
       gemm_seg<1, 0>(av, Hs, 0, 32, pk + lay.PF[9] / 4, 36, 0, wn, wm, lane, dbg,
-                     SAVE ? act + act_feat(P, PEP) + p0 * 256 : nullptr, valid, wave);
+                     SAVE ? act + act_feat(PL, PEP) + p0 * 256 : nullptr, valid, wave);
       gemm_seg<1, 1>(av, Es, 0, 4, pk + lay.PF[9] / 4, 36, 32, wn, wm, lane, dbg);
       __syncthreads();
       epilogue_fwd<1, true>(av, bv1, Hs, wm, wn, lane, nullptr, 128, valid);
       __syncthreads();
       if (SAVE) {   // hv: 32 slots per row, whole 512-byte rows per half wave
-        float* ahv = act + act_hv(P, PEP) + p0 * 128;
+        float* ahv = act + act_hv(PL, PEP) + p0 * 128;
         for (int i = tid; i < TM * 32; i += NTHR) {
           const int m = i >> 5, sl = i & 31;
           if (m < valid)
@@ -608,7 +614,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
       s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
       s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
-      if (pq == 0 && pm < valid) {
+      if (pq == 0 && pm < valid && raw) {
         float4 o;
         o.x = s0 + params[lay.RB]; o.y = s1 + params[lay.RB + 1]; o.z = s2 + params[lay.RB + 2]; o.w = alpha_val;
         *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
@@ -619,12 +625,9 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
   b_sched_exit(sched, tid);
 }
 
-extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const float* z,
-                                   const float* params, const float* packed_fwd, float* raw, float* act,
-                                   fn_stream_t stream) {
-  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
-  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
-  if (n == 0) return 0;
+static int fwd_launch(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                      const float* packed_fwd, float* raw, float* act, const int* live_idx, const int* live_cnt,
+                      fn_stream_t stream) {
   const NetLayout& lay = layout_of(kind);
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
@@ -646,14 +649,31 @@ extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   if (kind == 2) {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
   } else {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched);
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
   }
   FN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const float* z,
+                                   const float* params, const float* packed_fwd, float* raw, float* act,
+                                   fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
+  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
+  if (n == 0) return 0;
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream);
+}
+// exact-fp32 twin of fastnerf_mlp_bf16_fwd_live
+extern "C" int fastnerf_mlp_fwd_live_ex(int kind, int64_t n, int S, const float* rays11, const float* z,
+                                        const float* params, const float* packed_fwd, float* act,
+                                        const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(rays11 && z && params && packed_fwd && act && live_idx && live_cnt, "null pointer");
+  FN_CHECK_ARG(n * (int64_t)S < ((int64_t)1 << 31), "live lists index points with int32");
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, nullptr, act, live_idx, live_cnt, stream);
 }
 extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const float* z, const float* params,
                                 const float* packed_fwd, float* raw, float* act, fn_stream_t stream) {
@@ -722,7 +742,10 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __restrict__ act,
                   const float* __restrict__ params, const float* __restrict__ packed_t, float* __restrict__ dact,
-                  NetLayout lay, unsigned* __restrict__ sched) {
+                  NetLayout lay, unsigned* __restrict__ sched, const int* __restrict__ live_idx,
+                  const int* __restrict__ live_cnt) {
+  const int64_t PL = P;   // (live-list mode: see the forward kernel)
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;
   float* Es = smem + LDS_H;  // Es[0..127] = dalpha of the tile's rows
@@ -739,17 +762,17 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     const int64_t p0 = tile * TM;
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     const unsigned long long* maskw =
-        reinterpret_cast<const unsigned long long*>(act + act_mask(P, lay.pe_pad)) + tile * (8 * NWAVES * 64);
+        reinterpret_cast<const unsigned long long*>(act + act_mask(PL, lay.pe_pad)) + tile * (8 * NWAVES * 64);
     // ---- phase A: dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] --------------------------
     {
       const int pm = tid >> 2, pq = tid & 3;
       const bool ok = pm < valid;
       const int64_t pp = ok ? p0 + pm : P - 1;
-      const float4 dr = *reinterpret_cast<const float4*>(draw + pp * 4);
+      const float4 dr = *reinterpret_cast<const float4*>(draw + (live_idx ? (int64_t)live_idx[pp] : pp) * 4);
       if (pq == 0) Es[pm] = ok ? dr.w : 0.f;
       const float* wr = params + lay.RW;
-      const float* hv = act + act_hv(P, lay.pe_pad) + pp * 128;
-      float* dyv = dact + dact_yv(P) + pp * 128;
+      const float* hv = act + act_hv(PL, lay.pe_pad) + pp * 128;
+      float* dyv = dact + dact_yv(PL) + pp * 128;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = pq * 32 + i * 4;
@@ -781,7 +804,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     {
       const DxPre pre = dx_preload<true, true>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
       gemm_seg<2, 0>(acc, Hs, 0, 32, pk + lay.PB[1] / 4, 32, 0, wn * 2, wm, lane, 0,
-                         dact + dact_feat(P) + p0 * 256, valid, wave);    // streams dfeat (what it reads) out
+                         dact + dact_feat(PL) + p0 * 256, valid, wave);    // streams dfeat (what it reads) out
       __syncthreads();
       epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
     }
@@ -793,13 +816,13 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       zero_acc<2>(acc);
       const DxPre pre = dx_preload<true, false>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
       gemm_seg<2, 0>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane, 0,
-                         dact + dact_y(P, l) + p0 * 256, valid, wave);    // streams dY_l (what it reads) out
+                         dact + dact_y(PL, l) + p0 * 256, valid, wave);    // streams dY_l (what it reads) out
       __syncthreads();
       epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
       __syncthreads();
     }
     {   // dY0 has no consumer loop: copy it out row-wise
-      float* d0 = dact + dact_y(P, 0) + p0 * 256;
+      float* d0 = dact + dact_y(PL, 0) + p0 * 256;
       for (int i = tid; i < TM * 64; i += NTHR) {
         const int m = i >> 6, sl = i & 63;
         if (m < valid)
@@ -823,7 +846,9 @@ template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
 __global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                   const float* __restrict__ draw /*RANK1: dalpha = draw[p*4+3]*/, float* __restrict__ partial_w,
-                  float* __restrict__ partial_b, float* __restrict__ partial_r) {
+                  float* __restrict__ partial_b, float* __restrict__ partial_r, const int* __restrict__ live_idx,
+                  const int* __restrict__ live_cnt) {
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);   // live-list mode: rows 0 .. *live_cnt of dY / X
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int NTD = WO * WI * 64;  // threads
   constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;  // floats per LDS stage (+32 dalpha)
@@ -874,7 +899,7 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
     }
     if (RANK1 && tid < DW_MT) {
       const int64_t p = pbase + tid;
-      rda = (p < P) ? draw[p * 4 + 3] : 0.f;
+      rda = (p < P) ? draw[(live_idx ? (int64_t)live_idx[p] : p) * 4 + 3] : 0.f;
     }
   };
   auto store_stage = [&](float* st) {
@@ -971,8 +996,11 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
 //   out[wg][0..383] = dWr[c][k], [384..386] = dbr[c], [387] = dba
 __global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float* __restrict__ draw,
                                                           const float* __restrict__ hv,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, const int* __restrict__ live_idx,
+                                                          const int* __restrict__ live_cnt) {
   const int k = threadIdx.x;
+  if (live_idx) P = *live_cnt;
+  auto dptr = [&](int64_t q) { return draw + (live_idx ? (int64_t)live_idx[q] : q) * 4; };
   const int64_t per = (P + gridDim.x - 1) / gridDim.x;
   const int64_t pa = blockIdx.x * per;
   int64_t pb = pa + per;
@@ -984,7 +1012,7 @@ __global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float*
     float h[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      d[i] = *reinterpret_cast<const float4*>(draw + (p + i) * 4);
+      d[i] = *reinterpret_cast<const float4*>(dptr(p + i));
       h[i] = hv[(p + i) * 128 + k];
     }
 #pragma unroll
@@ -994,7 +1022,7 @@ __global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float*
     }
   }
   for (; p < pb; ++p) {
-    const float4 d = *reinterpret_cast<const float4*>(draw + p * 4);
+    const float4 d = *reinterpret_cast<const float4*>(dptr(p));
     const float h = hv[p * 128 + k];
     s0 = fmaf(d.x, h, s0); s1 = fmaf(d.y, h, s1); s2 = fmaf(d.z, h, s2);
     if (k < 4) sb += (k == 0) ? d.x : (k == 1) ? d.y : (k == 2) ? d.z : d.w;
@@ -1064,7 +1092,7 @@ extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
 
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
 static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* base,
-                     int nwg, hipStream_t st) {
+                     int nwg, hipStream_t st, const int* live_idx = nullptr, const int* live_cnt = nullptr) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
   const size_t lds = 2 * STAGE * sizeof(float);
@@ -1077,7 +1105,7 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
   float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr, live_idx, live_cnt);
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -1089,11 +1117,9 @@ static void add_seg(RedTable& T, int64_t src, int64_t wg_stride, int nwg, int ro
   s.valid_cols = valid_cols;
 }
 
-extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const float* act,
-                                   const float* params, const float* packed_bwd, float* dact, float* partial,
-                                   float* grads, fn_stream_t stream) {
-  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
-  FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads, "null pointer");
+static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                      const float* packed_bwd, float* dact, float* partial, float* grads, const int* live_idx,
+                      const int* live_cnt, fn_stream_t stream) {
   const NetLayout& L = layout_of(kind);
   const int PEP = L.pe_pad;
   hipStream_t st = fn::S(stream);
@@ -1110,13 +1136,13 @@ extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw
   }
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
-  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L, sched);
+  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L, sched, live_idx, live_cnt);
   FN_LAUNCH_CHECK();
 
   // ---- dW jobs: every job writes per-workgroup partials into its own region ------------------
-  const int64_t nt32 = (P + DW_MT - 1) / DW_MT;
-  int nwg = ncu;
-  if (nt32 < nwg) nwg = (int)nt32;
+  // (always one workgroup per CU and a fixed head-gradient grid, also for small batches: the order in which partial sums
+  // meet then depends on the point count alone -- live-list backward == plain backward of the same points, bit for bit)
+  const int nwg = ncu;
   RedTable T;
   T.n = 0;
   int rc;
@@ -1131,35 +1157,33 @@ extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw
     if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
   };
   // L0
-  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st);
-  else rc = launch_dw<4, 1, 2, 3, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st);
+  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
+  else rc = launch_dw<4, 1, 2, 3, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
   if (rc) return rc;
   segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
-    if ((rc = launch_dw<4, 2, 2, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st))) return rc;
+    if ((rc = launch_dw<4, 2, 2, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
   }
   // L5 pe part
-  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st);
-  else rc = launch_dw<4, 1, 2, 3, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st);
+  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
+  else rc = launch_dw<4, 1, 2, 3, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
   if (rc) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
-  if ((rc = launch_dw<4, 2, 2, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st))) return rc;
+  if ((rc = launch_dw<4, 2, 2, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
   segs(9, L.FW, 256, 256, L.FB, L.AW);
   // view layer
-  if ((rc = launch_dw<2, 4, 2, 2, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st))) return rc;
+  if ((rc = launch_dw<2, 4, 2, 2, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st, live_idx, live_cnt))) return rc;
   segs(10, L.VW, 283, 256, L.VB, 0);
-  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st))) return rc;
+  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
   segs(11, L.VW + 256, 283, 27, 0, 0);
   // rgb head + alpha bias
   {
-    int64_t hg64 = (P + 255) / 256;
-    int hg = (int)(hg64 > HEAD_MAX_WG ? HEAD_MAX_WG : hg64);
-    if (hg < 1) hg = 1;
+    const int hg = HEAD_MAX_WG;
     const int64_t hb = dw_job_base(12, ncu, PEP);
-    hipLaunchKernelGGL(head_grads_kernel, dim3(hg), dim3(128), 0, st, P, draw, act + act_hv(P, PEP), partial + hb);
+    hipLaunchKernelGGL(head_grads_kernel, dim3(hg), dim3(128), 0, st, P, draw, act + act_hv(P, PEP), partial + hb, live_idx, live_cnt);
     FN_LAUNCH_CHECK();
     add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387);   // dWr (384) + dbr (3), contiguous in every layout
     add_seg(T, hb + 387, 388, hg, 1, 1, L.AB, 1, 1);   // dba
@@ -1167,6 +1191,22 @@ extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw
   hipLaunchKernelGGL(reduce_all_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
   FN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const float* act,
+                                   const float* params, const float* packed_bwd, float* dact, float* partial,
+                                   float* grads, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads, "null pointer");
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, nullptr, nullptr, stream);
+}
+// exact-fp32 twin of fastnerf_mlp_bf16_bwd_live
+extern "C" int fastnerf_mlp_bwd_live_ex(int kind, int64_t n, int S, const float* draw, const float* act,
+                                        const float* params, const float* packed_bwd, float* dact, float* partial,
+                                        float* grads, const int32_t* live_idx, const int32_t* live_cnt,
+                                        fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads && live_idx && live_cnt, "null pointer");
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream);
 }
 extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float* act, const float* params,
                                 const float* packed_bwd, float* dact, float* partial, float* grads,

@@ -87,21 +87,21 @@ extern "C" int fastnerf_render_rays_bwd(int math_mode, int64_t n, int N_samples,
 }
 
 
-// Training backward with exact zero-gradient point compaction (split-bf16 math mode).  The forward ran WITHOUT saving
+// Training backward with exact zero-gradient point compaction (math_mode 1: split-bf16 kernels, 0: exact-fp32 kernels).  The forward ran WITHOUT saving
 // activations (the inference kernels); per pass:  compositing backward -> list of the points with a non-zero
 // d(loss)/d(raw) (fastnerf_compact_live) -> forward over that list, saving activations -> dX / dW over that list.
 // The gradients equal fastnerf_render_rays_bwd's up to fp32 summation order (the dead points' terms are exact zeros).
 // No host round trip: the list length stays on the device.  live_ws: 4 + n*S1 + fastnerf_compact_ws_ints(n*S1) int32;
-// act_ws: fastnerf_mlp_bf16_floats(0, 3, n*S1) floats; counts_out (optional): 4 int32 = live/total fine, live/total coarse.
-extern "C" int fastnerf_render_rays_bwd_live(int64_t n, int N_samples, int N_importance, const float* rays11, int white_bkgd,
+// act_ws: fastnerf_mlp_bf16_floats(0, 3, n*S1) / fastnerf_mlp_act_floats(0, n*S1) floats; counts_out (optional): 4 int32 = live/total fine, live/total coarse.
+extern "C" int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11, int white_bkgd,
                                              const float* g_rgb, const float* g_rgb0, const float* noise0, const float* noise1,
                                              const float* z0, const float* raw0, const float* z1, const float* raw1,
                                              const float* params_c, const float* packed_fwd_c, const float* packed_bwd_c,
                                              const float* params_f, const float* packed_fwd_f, const float* packed_bwd_f,
                                              float* draw_ws, float* act_ws, float* dact_ws, float* partial_ws, int32_t* live_ws,
                                              float* grads_c, float* grads_f, int32_t* counts_out, fn_stream_t stream) {
-  if (n <= 0 || N_samples < 2 || N_importance < 0) {
-    fn::set_error("fastnerf_render_rays_bwd_live: bad argument: n>0, N_samples>=2, N_importance>=0");
+  if ((math_mode != 0 && math_mode != 1) || n <= 0 || N_samples < 2 || N_importance < 0) {
+    fn::set_error("fastnerf_render_rays_bwd_live: bad argument: math_mode in {0,1}, n>0, N_samples>=2, N_importance>=0");
     return -1;
   }
   if (!rays11 || !z0 || !raw0 || !params_c || !packed_fwd_c || !packed_bwd_c || !draw_ws || !act_ws || !dact_ws ||
@@ -118,8 +118,12 @@ extern "C" int fastnerf_render_rays_bwd_live(int64_t n, int N_samples, int N_imp
                   const float* pf, const float* pb, float* grads, int32_t* cnt_out) -> int {
     if ((rc = fastnerf_raw2outputs_bwd(n, S, raw, z, rays11, noise, white_bkgd, g, draw_ws, stream))) return rc;
     if ((rc = fastnerf_compact_live(n * (int64_t)S, draw_ws, idx, cnt_out, cws, stream))) return rc;
-    if ((rc = fastnerf_mlp_bf16_fwd_live(0, n, S, rays11, z, params, pf, act_ws, idx, cnt_out, stream))) return rc;
-    return fastnerf_mlp_bf16_bwd_live(0, n, S, draw_ws, act_ws, params, pb, dact_ws, partial_ws, grads, idx, cnt_out, stream);
+    if (math_mode) {
+      if ((rc = fastnerf_mlp_bf16_fwd_live(0, n, S, rays11, z, params, pf, act_ws, idx, cnt_out, stream))) return rc;
+      return fastnerf_mlp_bf16_bwd_live(0, n, S, draw_ws, act_ws, params, pb, dact_ws, partial_ws, grads, idx, cnt_out, stream);
+    }
+    if ((rc = fastnerf_mlp_fwd_live_ex(0, n, S, rays11, z, params, pf, act_ws, idx, cnt_out, stream))) return rc;
+    return fastnerf_mlp_bwd_live_ex(0, n, S, draw_ws, act_ws, params, pb, dact_ws, partial_ws, grads, idx, cnt_out, stream);
   };
   const float* g_coarse = g_rgb;
   int32_t* c_fine = counts_out ? counts_out : cnt;

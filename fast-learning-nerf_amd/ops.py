@@ -280,25 +280,26 @@ def compact_live(draw):
 
 
 def mlp_fwd_live(rays11, z, params, packed_fwd, act, live_idx, live_cnt, kind=0):
-    """Training forward over a live list (split-bf16 mode): saves the activations of points live_idx[0:live_cnt[0]]."""
+    """Training forward over a live list: saves the activations of points live_idx[0:live_cnt[0]] (current math mode)."""
     require_gpu(rays11, z, params, packed_fwd, act, live_idx, live_cnt)
-    assert _split(kind), 'live-list kernels exist in the bf16x3 math mode'
     n, S = z.shape
+    tag = 'bf16x3' if _split(kind) else 'fp32'
     assert act.numel() >= act_floats(n * S, kind) and live_idx.dtype == torch.int32 and live_cnt.dtype == torch.int32
-    assert packed_fwd.numel() == packed_floats(kind, 1) and getattr(packed_fwd, '_fn_math', None) == 'bf16x3'
-    check(lib().fastnerf_mlp_bf16_fwd_live(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(act),
-                                           ptr(live_idx), ptr(live_cnt), stream()), 'fastnerf_mlp_bf16_fwd_live')
+    assert packed_fwd.numel() == packed_floats(kind, 1) and getattr(packed_fwd, '_fn_math', None) == tag
+    fn = lib().fastnerf_mlp_bf16_fwd_live if _split(kind) else lib().fastnerf_mlp_fwd_live_ex
+    check(fn(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(act), ptr(live_idx), ptr(live_cnt), stream()),
+          'fastnerf_mlp_fwd_live')
 
 
 def mlp_bwd_live(draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, kind=0):
     require_gpu(draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt)
-    assert _split(kind), 'live-list kernels exist in the bf16x3 math mode'
     n, S = draw.shape[0], draw.shape[1]
+    tag = 'bf16x3' if _split(kind) else 'fp32'
     assert dact.numel() >= dact_floats(n * S, kind) and grads.numel() == net_floats(kind, 0)
-    assert packed_bwd.numel() == packed_floats(kind, 2) and getattr(packed_bwd, '_fn_math', None) == 'bf16x3'
-    check(lib().fastnerf_mlp_bf16_bwd_live(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
-                                           ptr(partial), ptr(grads), ptr(live_idx), ptr(live_cnt), stream()),
-          'fastnerf_mlp_bf16_bwd_live')
+    assert packed_bwd.numel() == packed_floats(kind, 2) and getattr(packed_bwd, '_fn_math', None) == tag
+    fn = lib().fastnerf_mlp_bf16_bwd_live if _split(kind) else lib().fastnerf_mlp_bwd_live_ex
+    check(fn(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact), ptr(partial), ptr(grads), ptr(live_idx),
+             ptr(live_cnt), stream()), 'fastnerf_mlp_bwd_live')
     return grads
 
 
@@ -314,15 +315,15 @@ def render_rays_bwd_live(rays11, white_bkgd, g_rgb, g_rgb0, noise0, noise1, z0, 
     tensor receiving (live, total) of the fine and of the coarse pass."""
     require_gpu(rays11, g_rgb, g_rgb0, z0, raw0, z1, raw1, params_c, params_f, draw_ws, act_ws, dact_ws, partial, live_ws,
                 grads_c, grads_f, counts)
-    assert _split(0), 'live-list kernels exist in the bf16x3 math mode'
     n = rays11.shape[0]
     S1 = N_samples + N_importance
+    tag = 'bf16x3' if _split(0) else 'fp32'
     for pk in (packed_c, packed_f):
-        assert pk is None or all(getattr(t, '_fn_math', None) == 'bf16x3' for t in pk)
+        assert pk is None or all(getattr(t, '_fn_math', None) == tag for t in pk)
     assert draw_ws.numel() >= n * S1 * 4 and dact_ws.numel() >= dact_floats(n * S1) and act_ws.numel() >= act_floats(n * S1)
     assert live_ws.dtype == torch.int32 and live_ws.numel() >= live_ws_ints(n * S1)
     check(lib().fastnerf_render_rays_bwd_live(
-        n, int(N_samples), int(N_importance), ptr(rays11), int(bool(white_bkgd)), ptr(g_rgb), ptr(g_rgb0), ptr(noise0), ptr(noise1),
+        1 if _split(0) else 0, n, int(N_samples), int(N_importance), ptr(rays11), int(bool(white_bkgd)), ptr(g_rgb), ptr(g_rgb0), ptr(noise0), ptr(noise1),
         ptr(z0), ptr(raw0), ptr(z1), ptr(raw1), ptr(params_c), ptr(packed_c[0]), ptr(packed_c[1]),
         ptr(params_f), ptr(None if packed_f is None else packed_f[0]), ptr(None if packed_f is None else packed_f[1]),
         ptr(draw_ws), ptr(act_ws), ptr(dact_ws), ptr(partial), ptr(live_ws), ptr(grads_c), ptr(grads_f), ptr(counts), stream()),

@@ -63,7 +63,8 @@ class _Workspace:
 # ---- exact zero-gradient point compaction of the training backward (csrc/train.hip, render.cpp) ----
 # FASTNERF_COMPACT = auto (default) | 1 | 0.  The compacted backward recomputes the forward of the live points
 # (forward work 1 + f, backward work f for a live fraction f), the plain one saves every activation in the first
-# forward (1, 1): compaction wins below f ~ 0.73.  `auto` starts compacted and follows the measured fraction.
+# forward (1, 1): compaction wins below f ~ 0.76 (split-bf16) / 0.69 (exact fp32).  `auto` starts compacted and follows
+# the measured fraction.  Both math modes have the live-list kernels.
 _COMPACT = os.environ.get('FASTNERF_COMPACT', 'auto')
 assert _COMPACT in ('auto', '0', '1'), 'FASTNERF_COMPACT must be auto, 0 or 1'
 
@@ -81,7 +82,10 @@ def get_compact():
 class LivePolicy:
     """Decides per step whether the backward runs compacted; fed with the (live, total) counters of compacted steps
     through pinned-memory copies that are only read once their event has completed (never stalls the stream)."""
-    SWITCH_OFF, SWITCH_ON, EVERY, PROBE = 0.78, 0.70, 16, 256
+    EVERY, PROBE = 16, 256
+    # break-even live fractions from the measured kernel times (forward without saving + f x (saving forward + backward)
+    # against saving forward + backward): 0.76 in the split-bf16 mode, 0.69 in the exact-fp32 mode; hysteresis around them
+    THRESHOLDS = {'bf16x3': (0.78, 0.70), 'fp32': (0.70, 0.62)}
 
     def __init__(self):
         self.frac = None          # last measured live fraction (both passes together)
@@ -90,7 +94,7 @@ class LivePolicy:
         self._pending = None      # (pinned host tensor, event)
 
     def available(self, net_c, net_f, N_importance):
-        return ops.get_math() == 'bf16x3' and (N_importance == 0 or (net_f is not None and net_f is not net_c))
+        return N_importance == 0 or (net_f is not None and net_f is not net_c)
 
     def use_live(self, net_c, net_f, N_importance):
         if _COMPACT == '0' or not self.available(net_c, net_f, N_importance):
@@ -109,9 +113,10 @@ class LivePolicy:
             tot = c[1] + c[3]
             if tot > 0:
                 self.frac = (c[0] + c[2]) / tot
-                if self.on and self.frac > self.SWITCH_OFF:
+                off, on = self.THRESHOLDS[ops.get_math()]
+                if self.on and self.frac > off:
                     self.on = False
-                elif not self.on and self.frac < self.SWITCH_ON:
+                elif not self.on and self.frac < on:
                     self.on = True
 
     def after_live_step(self, counts):

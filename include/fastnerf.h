@@ -262,11 +262,19 @@ int fastnerf_mlp_bf16_fwd_live(int kind, int64_t n, int S, const float* rays11, 
 int fastnerf_mlp_bf16_bwd_live(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                                const float* packed_bwd, float* dact, float* partial, float* grads,
                                const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream);
+/* the exact-fp32 twins (v_mfma_f32_32x32x2_f32 kernels; act sized by fastnerf_mlp_act_floats) */
+int fastnerf_mlp_fwd_live_ex(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                             const float* packed_fwd, float* act, const int32_t* live_idx, const int32_t* live_cnt,
+                             fn_stream_t stream);
+int fastnerf_mlp_bwd_live_ex(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                             const float* packed_bwd, float* dact, float* partial, float* grads,
+                             const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream);
 /* the whole backward of render_rays (render.py:238-299 under loss.backward()) with compaction, for a forward that
- * saved nothing: per pass compositing backward -> live list -> saving forward over the list -> dX / dW.
+ * saved nothing: per pass compositing backward -> live list -> saving forward over the list -> dX / dW
+ * (math_mode 1: split-bf16, 0: exact fp32).
  * live_ws: 4 + n*(N_samples+N_importance) + fastnerf_compact_ws_ints(...) int32; counts_out: NULL or 4 int32
  * (live, total of the fine pass; live, total of the coarse pass). */
-int fastnerf_render_rays_bwd_live(int64_t n, int N_samples, int N_importance, const float* rays11, int white_bkgd,
+int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11, int white_bkgd,
                                   const float* g_rgb, const float* g_rgb0, const float* noise0, const float* noise1,
                                   const float* z0, const float* raw0, const float* z1, const float* raw1,
                                   const float* params_c, const float* packed_fwd_c, const float* packed_bwd_c,

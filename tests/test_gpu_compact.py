@@ -34,14 +34,6 @@ def weights(golden_dir):
     return {k[2:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith('c.')}
 
 
-@pytest.fixture()
-def bf16(fn):
-    old = fn.ops.get_math()
-    fn.ops.set_math('bf16x3')
-    yield
-    fn.ops.set_math(old)
-
-
 def flat_of(sd):
     return torch.cat([sd[n].reshape(-1) for n, _ in O.nerf_param_shapes()])
 
@@ -102,7 +94,7 @@ def _live(fn, rb, z, cot, flat, pf, pb, idx=None, cnt=None):
 
 
 @pytest.mark.parametrize('n,S,dead_frac', [(9, 50, 0.5), (64, 192, 0.55), (300, 64, 0.97), (7, 9, 0.4)])
-def test_dead_points_contribute_exact_zeros_and_live_kernels_are_the_plain_kernels(fn, weights, bf16, n, S, dead_frac):
+def test_dead_points_contribute_exact_zeros_and_live_kernels_are_the_plain_kernels(fn, weights, math_mode, n, S, dead_frac):
     rb, z, cot, dead, flat, pf, pb = _setup(fn, weights, n, S, 11 * n + S, dead_frac)
     g_plain = _plain(fn, rb, z, cot, flat, pf, pb)
     assert torch.isfinite(g_plain).all()
@@ -137,7 +129,7 @@ def test_dead_points_contribute_exact_zeros_and_live_kernels_are_the_plain_kerne
             off += kk
 
 
-def test_live_list_of_everything_and_of_nothing(fn, weights, bf16):
+def test_live_list_of_everything_and_of_nothing(fn, weights, math_mode):
     rb, z, cot, dead, flat, pf, pb = _setup(fn, weights, 33, 40, 5, 0.0)
     g_plain = _plain(fn, rb, z, cot, flat, pf, pb)
     g_live, idx, cnt = _live(fn, rb, z, cot, flat, pf, pb)
@@ -165,7 +157,7 @@ def _trainer(fn, golden_dir, compact):
     return fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0), K
 
 
-def test_training_steps_with_and_without_compaction(fn, golden_dir, bf16):
+def test_training_steps_with_and_without_compaction(fn, golden_dir, math_mode):
     old = fn.render.get_compact()
     try:
         imgs, poses, focal = fn.synthetic.make_dataset(n_images=2, H=48, W=48)
@@ -205,7 +197,7 @@ def test_training_steps_with_and_without_compaction(fn, golden_dir, bf16):
         fn.render.set_compact(old)
 
 
-def test_autograd_route_and_policy(fn, golden_dir, bf16):
+def test_autograd_route_and_policy(fn, golden_dir, math_mode):
     """render(...); loss.backward() picks the compacted backward too; `auto` follows the measured live fraction."""
     old = fn.render.get_compact()
     try:
@@ -233,14 +225,16 @@ def test_autograd_route_and_policy(fn, golden_dir, bf16):
         pol = fn.render.LivePolicy()
         fn.render.set_compact('auto')
         assert pol.use_live(tr.net_c, tr.net_f, 128)
-        for frac, want in ((0.9, False), (0.75, False), (0.5, True), (0.74, True)):
+        seq = ((0.9, False), (0.75, False), (0.5, True), (0.74, True)) if math_mode == 'bf16x3' else \
+              ((0.9, False), (0.66, False), (0.5, True), (0.66, True))
+        for frac, want in seq:
             pol._pending = (torch.tensor([int(frac * 1000), 1000, 0, 0], dtype=torch.int32), torch.cuda.Event())
             pol._pending[1].record(); torch.cuda.synchronize()
             pol.step = 1
             assert pol.use_live(tr.net_c, tr.net_f, 128) == want and abs(pol.frac - frac) < 1e-3
         pol.on, pol.step = False, pol.PROBE
         assert pol.use_live(tr.net_c, tr.net_f, 128)                       # probe step
-        fn.ops.set_math('fp32')
-        assert not pol.use_live(tr.net_c, tr.net_f, 128)                   # the exact-fp32 mode keeps the plain backward
+        assert not pol.use_live(tr.net_c, tr.net_c, 128)                   # one shared net for both passes: plain backward
+        assert pol.use_live(tr.net_c, None, 0)
     finally:
         fn.render.set_compact(old)
