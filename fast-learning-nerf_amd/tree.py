@@ -338,13 +338,23 @@ class QuadTreeManager:
             self._dev_poses = self.poses.to(self.device)
         return self._dev_images, self._dev_poses
 
+    def _all_rays(self):
+        """[n,H,W,3] origins / directions of every pixel of every view (tree.py:170-180).  Nothing on the hot path
+        needs them (rays are generated from the picks); they exist for the reference driver's warm-up, which indexes
+        `treeManager.origins[i][rows, cols]` (run_nerf.py:386-388).  Built once on first use, on the device:
+        2 x 768 MB at 100 x 800 x 800."""
+        if getattr(self, '_rays_cache', None) is None:
+            rays = [ops.gen_rays(self.h, self.w, self.K, self.poses[i]) for i in range(self.n_images)]
+            self._rays_cache = (torch.stack([r[0] for r in rays], 0), torch.stack([r[1] for r in rays], 0))
+        return self._rays_cache
+
     @property
     def origins(self):
-        return torch.stack([ops.gen_rays(self.h, self.w, self.K, self.poses[i])[0] for i in range(self.n_images)], 0)
+        return self._all_rays()[0]
 
     @property
     def dirs(self):
-        return torch.stack([ops.gen_rays(self.h, self.w, self.K, self.poses[i])[1] for i in range(self.n_images)], 0)
+        return self._all_rays()[1]
 
     def gather(self, pix):
         """pix [N,3] int64/int32 (image,row,col) -> rays_o, rays_d, rgb on the device."""
