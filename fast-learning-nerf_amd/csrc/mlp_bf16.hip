@@ -60,6 +60,10 @@ typedef unsigned long long u64;
 #ifndef BF_PF
 #define BF_PF 2   // weight fragments two k-steps ahead in the fwd / dX k-loops (1: one ahead)
 #endif
+#ifndef BF_LATE_SAVE
+#define BF_LATE_SAVE 0   // experiment: keep a layer's 16 saved-tensor stores per wave in registers and issue them at the END of the
+                         // next k-loop (no weight load queues behind them in the in-order vmcnt queue); costs 64 VGPRs
+#endif
 #ifndef BF_PRE_STEPS
 #define BF_PRE_STEPS 1   // k-steps of the next layer prefetched ahead of an epilogue (PRE): 2 costs 16 more VGPRs -> scratch spills in dX
 #endif
@@ -450,6 +454,25 @@ __device__ __forceinline__ void gstore16(uint4* p, const uint4& v) {
 #endif
 }
 
+// stores of one 256-wide layer held back (BF_LATE_SAVE): index ((mt*2 + nt)*2 + k2)*2 + part
+struct BPend {
+  uint4 v[16];
+  uint4* base;   // tensor tile base + this lane's (half*32 + j); the per-store offset is a constant of (wn, index)
+};
+__device__ __forceinline__ void bpend_flush(const BPend& pd, int wn) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          const int ct = wn * 2 + nt, ks = mt * 2 + k2;
+          gstore16(pd.base + ((ct * 4 + ks) * 2 + part) * 64, pd.v[((mt * 2 + nt) * 2 + k2) * 2 + part]);
+        }
+}
+
 struct EpiArgs {
   const float* bias;          // BIAS
   const float* dalpha4;       // RANK1: LDS float4 rows, .w = dalpha
@@ -505,9 +528,9 @@ __device__ __forceinline__ float mask_get(unsigned m, int k, float v) {
 //   - LDS: the column pair is one packed 32-bit store per plane and row,
 //   - global: 4 consecutive rows of one column = 8 bytes of a K-fragment element (see the file header),
 //   - sign bits (forward, ReLU layers): 64 per thread and layer, order mt, r, nt.
-template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE>
+template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE, bool LATESAVE = false>
 __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs& ea, char* Hhi, char* Hlo, int wn,
-                                        int lane) {
+                                        int lane, BPend& pend) {
   asm volatile("" : "+v"(lane));
   const int j = lane & 31, half = lane >> 5;
   const int n0 = wn * 64 + 2 * j;
@@ -568,8 +591,13 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
               const auto r = __builtin_amdgcn_permlane32_swap(xe[part][w], xo[part][w], false, false);
               xe[part][w] = r[0]; xo[part][w] = r[1];
             }
-            uint4* p4 = reinterpret_cast<uint4*>(ea.gsave) + (((ct * 4 + ks) * 2 + part) * 64 + half * 32 + j);
-            gstore16(p4, make_uint4(xe[part][0], xe[part][1], xo[part][0], xo[part][1]));
+            if (LATESAVE) {
+              pend.v[((mt * 2 + nt) * 2 + k2) * 2 + part] = make_uint4(xe[part][0], xe[part][1], xo[part][0], xo[part][1]);
+              pend.base = reinterpret_cast<uint4*>(ea.gsave) + half * 32 + j;
+            } else {
+              uint4* p4 = reinterpret_cast<uint4*>(ea.gsave) + (((ct * 4 + ks) * 2 + part) * 64 + half * 32 + j);
+              gstore16(p4, make_uint4(xe[part][0], xe[part][1], xo[part][0], xo[part][1]));
+            }
           }
         }
 #else
@@ -792,8 +820,10 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     f32x16 acc[2][2];
     EpiArgs ea{};
     constexpr bool PRE = !BG && (BF_PF == 2) && BF_PRE_FWD;   // (the background variant has no registers to spare)
-    constexpr int KPF = BG ? 1 : BF_PF;   // background net: weight fragments one k-step ahead (two would spill: 256 VGPRs + scratch)
+    constexpr bool LATE = BF_LATE_SAVE && SAVE && !BG;
+    constexpr int KPF = (BG || (LATE && BF_LATE_SAVE == 2)) ? 1 : BF_PF;   // background net: weight fragments one k-step ahead (two would spill: 256 VGPRs + scratch)
     BPre<2> pre;
+    BPend pend;
     // L0
     ea.bias = params + lay.LB[0];
     bepi256_preload<true, false, false>(ea, wn, lane);
@@ -810,7 +840,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       ea.mask_out = maskw_all + (tile * 8 + 0) * 256;
     }
     if (PRE) bprefetch<2>(pre, pk + boff.off[1], 16, 0, wn * 2, lane);
-    bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<true, true, false, false, SAVE, SAVE, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
@@ -835,6 +865,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         bgemm<2, 0, PRE, KPF>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane, &pre);
       }
       TR(4 * l + 1);
+      if (LATE) bpend_flush(pend, wn);   // h_{l-1}: behind this k-loop's last weight load, in front of a whole epilogue
       __syncthreads();
       TR(4 * l + 2);
       if (SAVE) {
@@ -845,7 +876,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         const int ln = l + 1;
         bprefetch<2>(pre, pk + boff.off[ln], ln == 5 ? 20 : 16, 0, wn * 2, lane);
       }
-      bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+      bepi256<true, true, false, false, SAVE, SAVE, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
       TR(4 * l + 3);
       __syncthreads();
     }
@@ -901,11 +932,12 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     bepi256_preload<true, false, false>(ea, wn, lane);
     bzero<2>(acc);
     bgemm<2, 0, PRE, KPF>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane, &pre);
+    if (LATE) bpend_flush(pend, wn);     // h7
     __syncthreads();
     if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(nt_lay) + tile * 4096);
     BPre<1> prev;
     if (PRE) bprefetch<1>(prev, pk + boff.off[9], 18, 0, wn, lane);
-    bepi256<true, false, false, false, false, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<true, false, false, false, false, SAVE>(acc, ea, Hhi, Hlo, wn, lane, pend);
     __syncthreads();
     // view layer: [feat256 | vpe32] -> 128, ReLU
     {
@@ -1055,8 +1087,11 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     }
     __syncthreads();
     EpiArgs ea{};
-    constexpr bool PRE = (BF_PF == 2) && BF_PRE_DX;
+    constexpr int DXPF = (BF_LATE_SAVE == 2) ? 1 : BF_PF;
+    constexpr bool PRE = (DXPF == 2) && BF_PRE_DX;
     BPre<2> pre;
+    constexpr bool LATE = BF_LATE_SAVE;
+    BPend pend;
     // ---- dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] ---------------------------------------------------
     {
       f32x16 av[2][1];
@@ -1080,11 +1115,11 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     f32x16 acc[2][2];
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ----------------------------------------------------------
     bzero<2>(acc);
-    bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane, &pre);
+    bgemm<2, 0, PRE, DXPF>(acc, Hhi, Hlo, 0, 8, pkt + boff.off[0], 8, 0, wn * 2, lane, &pre);
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(nt_lay) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[1], 16, 0, wn * 2, lane);
-    bepi256<false, false, false, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<false, false, false, false, false, true, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ---------------------------------------------------
     ea.mask_in = maskw_all + (tile * 8 + 7) * 256;
@@ -1092,11 +1127,12 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     ea.wa = params + lay.AW;
     bepi256_preload<false, true, true>(ea, wn, lane);
     bzero<2>(acc);
-    bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane, &pre);
+    bgemm<2, 0, PRE, DXPF>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane, &pre);
+    if (LATE) bpend_flush(pend, wn);   // dfeat
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, 7) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[2], 16, 0, wn * 2, lane);
-    bepi256<false, false, true, true, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+    bepi256<false, false, true, true, false, true, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
     __syncthreads();
     // ---- dY_{l-1} = (dY_l . W_l[:, h part]) * [h_{l-1} > 0],  l = 7..1 ---------------------------------
 #pragma unroll 1
@@ -1104,13 +1140,15 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
       ea.mask_in = maskw_all + (tile * 8 + (l - 1)) * 256;
       bepi256_preload<false, true, false>(ea, wn, lane);
       bzero<2>(acc);
-      bgemm<2, 0, PRE>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane, &pre);
+      bgemm<2, 0, PRE, DXPF>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane, &pre);
+      if (LATE) bpend_flush(pend, wn);   // dY_l
       __syncthreads();
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, l - 1) + tile * 4096);
       if (PRE && l > 1) bprefetch<2>(pre, pkt + boff.off[10 - l], 16, 0, wn * 2, lane);
-      bepi256<false, false, true, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
+      bepi256<false, false, true, false, false, true, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
       if (l > 1) __syncthreads();
     }
+    if (LATE) bpend_flush(pend, wn);     // dY_0: nothing follows in this tile
     tile = b_next_tile(sched, sched_word, tid);   // (contains the tile's closing barrier)
   }
   b_sched_exit(sched, tid);
