@@ -74,7 +74,20 @@ def render_rays(rays_o, rays_d, near=2.0, far=6.0, n_quad=128):
     return (w[..., None] * col).sum(-2) + (1 - w.sum(-1, keepdim=True))
 
 
-def make_dataset(n_images=8, H=32, W=32, fov=0.6911112070083618, radius=4.0, phi=-30.0):
+def make_dataset(n_images=8, H=32, W=32, fov=0.6911112070083618, radius=4.0, phi=-30.0, device=None):
+    """Cameras on a circle around the analytic scene and their images.  device=None: fp64 quadrature on the host (what the
+    tests and goldens use); device='cuda': the same scene rendered on the GPU with render_rays (fp32, 256 steps) -- for
+    full-resolution probes, where the host version takes minutes."""
     focal = 0.5 * W / np.tan(0.5 * fov)
     poses = torch.stack([pose_spherical(-180.0 + 360.0 * k / n_images, phi, radius)[:3, :4] for k in range(n_images)], 0)
-    return render_images(H, W, focal, poses), poses, focal
+    if device is None:
+        return render_images(H, W, focal, poses), poses, focal
+    from . import ops
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+    imgs = []
+    for i in range(n_images):
+        ro, rd = ops.gen_rays(H, W, K, poses[i].to(device))
+        flat_o, flat_d = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        rows = [render_rays(flat_o[s:s + 65536], flat_d[s:s + 65536], n_quad=256) for s in range(0, H * W, 65536)]
+        imgs.append(torch.cat(rows, 0).reshape(H, W, 3).cpu())
+    return torch.stack(imgs, 0), poses, focal

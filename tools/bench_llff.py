@@ -1,7 +1,7 @@
 """BASELINE configs[3] shape on one GPU: LLFF-like forward-facing cameras, 1008x756, NDC rays, 64 + 64 samples,
 raw_noise_std = 1, 4096 rays / step.  Not the headline bench (bench.py is); DESIGN.md cites it."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import fastnerf as fn
 from fastnerf import ops
 N = 4096
@@ -28,4 +28,6 @@ for mode in ('fp32', 'bf16x3'):
     Kst = 20
     for _ in range(Kst): loss, _ = tr.step(ro, rd, tgt)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / Kst
-    print('%-7s ndc=%s 64+64: %.2f ms/step  %.0f rays/s  loss %s' % (mode, tr.ndc, dt * 1e3, N / dt, [round(float(x), 5) for x in loss]))
+    c = tr.live_counts.cpu().tolist()
+    print('%-7s ndc=%s 64+64: %.2f ms/step  %.0f rays/s  loss %s  backward %s live %s' % (mode, tr.ndc, dt * 1e3, N / dt, [round(float(x), 5) for x in loss],
+          'compacted' if tr.last_step_live else 'plain', [round(c[0] / max(1, c[1]), 3), round(c[2] / max(1, c[3]), 3)]))

@@ -1,7 +1,7 @@
 """nerf++ (BASELINE configs[4]) cascade step throughput on one GPU, both math modes: 2 levels x (fg + bg) nets,
 64 / 128 samples, synthetic cameras inside the unit sphere.  Not the headline bench (bench.py is); DESIGN.md cites it."""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import fastnerf as fn
 from fastnerf import ops, nerfpp
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1920

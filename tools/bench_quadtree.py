@@ -2,11 +2,11 @@
 ray generation from the leaf plans, fused steps feeding the on-device leaf-error table, tree adjustment) on a synthetic
 multi-view scene.  Reports end-to-end rays/s per epoch (host quadtree work included).  DESIGN.md cites it."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import fastnerf as fn
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n_images = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-imgs, poses, focal = fn.synthetic.make_dataset(n_images=n_images, H=H, W=W)
+imgs, poses, focal = fn.synthetic.make_dataset(n_images=n_images, H=H, W=W, device='cuda' if H >= 400 else None)
 torch.manual_seed(0); np.random.seed(0)
 args = fn.run_nerf.make_args(N_importance=128, N_samples=64, perturb=1.0, white_bkgd=True, no_reload=True, N_rand=4096,
                              n_epoch=5, init_level=2, subdivide_every=1, subdivide_thres=0.02, lrate=5e-4, lrate_decay=500)
