@@ -15,7 +15,8 @@ blobs on a white background; targets by quadrature along each batch's rays): the
 their random initialisation for --scene-steps (300) untimed steps, then W warm-up and K timed steps follow on the
 same stream of batches.  The round-1 protocol -- random-init nets, U[0,1) noise targets, no scene -- is timed
 too and reported as `init_state` (there 84 % of the samples are live and the plain backward is used), as is the
-steady state with the compaction switched off (`steady_state_plain`).  The GPU legs import nothing from
+steady state with the compaction switched off (`steady_state_plain`: the floor -- how many samples die is a property
+of the training trajectory, DESIGN.md section 4a: a field that explains empty space as thin white fog keeps them all).  The GPU legs import nothing from
 oracle/; only `cpu_baseline` does.
 
   python bench.py --gpus N --steps K --warmup W

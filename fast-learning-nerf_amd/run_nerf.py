@@ -401,7 +401,9 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
         loss2, it = run_batches(ro, rd, tgt, tags, True, table, max_leaves)
         psnr = mse2psnr(loss2[:1].cpu())
         history.append((epoch_id, it, float(loss2[0]), float(psnr[0]), time.time() - t0))
-        log('epoch {}: {} iters, fine mse {:.5f} psnr {:.2f}, {:.1f}s'.format(*history[-1]))
+        log('epoch {}: {} iters, fine mse {:.5f} psnr {:.2f}, {:.1f}s'.format(*history[-1]) +
+            ('' if trainer.live.frac is None else ' (live samples {:.2f}, backward {})'.format(
+                trainer.live.frac, 'compacted' if trainer.live.on else 'plain')))
         if args.subdivide_every > 0 and epoch_id % args.subdivide_every == 0 and epoch_id < args.n_epoch - 1:
             if world > 1:
                 parallel.all_reduce_max_int(table)
