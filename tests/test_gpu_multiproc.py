@@ -58,8 +58,8 @@ tgt = imgs.reshape(-1, 3).cuda()
 ml = 16
 table = torch.zeros(2 * ml, device='cuda', dtype=torch.int32)
 losses = []
-for it in range(3):
-    N = 512 if it < 2 else 511                  # the last batch does not divide evenly
+for it in range(4):
+    N = (512, 512, 511, 1)[it]                  # a batch that does not divide evenly, then one whose shard is EMPTY on rank 1
     sel = torch.randint(0, ro.shape[0], (N,), generator=gen)
     t_rand, u = torch.rand(N, 32, generator=gen).cuda(), torch.rand(N, 32, generator=gen).cuda()
     tag = torch.stack([sel // 1024, ((sel %% 1024) // 32 // 8) * 4 + (sel %% 32) // 8], 1).int().cuda()
@@ -105,7 +105,7 @@ def test_sharded_trainer_equals_single_rank_on_the_union(tmp_path, compact):
     # after three steps the weights differ in their last bits (fp32 summation order of the gradients), the errors with them
     ta, tb = a['table'].view(torch.float32), b['table'].view(torch.float32)
     assert torch.equal(ta != 0, tb != 0) and (ta - tb).abs().max().item() < 1e-5
-    assert a['adam_t'] == b['adam_t'] == 3 and a['lr'] == b['lr']
+    assert a['adam_t'] == b['adam_t'] == 4 and a['lr'] == b['lr']   # the rank with the empty shard stepped too
     # step 1's all-reduced gradient == the single rank's gradient on the union batch (only fp32 summation order differs)
     relg = (a['grad0'] - b['grad0']).abs().max().item() / a['grad0'].abs().max().item()
     assert relg < 2e-6, relg
@@ -114,4 +114,4 @@ def test_sharded_trainer_equals_single_rank_on_the_union(tmp_path, compact):
     d = (a['flat'] - b['flat']).abs()
     scale = a['flat'].abs().max().item()
     assert float((d > 1e-6 * scale).float().mean()) < 0.10, float((d > 1e-6 * scale).float().mean())   # measured 2-4 %
-    assert d.max().item() <= 3 * 5e-4 * 2.001
+    assert d.max().item() <= 4 * 5e-4 * 2.001

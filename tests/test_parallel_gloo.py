@@ -63,8 +63,14 @@ def _worker(rank, world, port, q):
     parallel.all_reduce_max_int(tab)
     tab_full = O.leaf_loss_max(tgt, rgb_full, tag, 2, 5).view(-1)
     same = torch.equal(tab.view(torch.float32), tab_full)
+    # epoch seed broadcast (train() calls it before every host-side random decision): ranks start from DIFFERENT generator
+    # states and end up drawing identical torch / numpy numbers
+    torch.manual_seed(1000 + 17 * rank)
+    np.random.seed(5 + rank)
+    seed = parallel.sync_seed()
+    draws = (torch.randint(0, 10 ** 9, (4,)).tolist(), np.random.randint(0, 10 ** 9, 4).tolist(), int(seed))
     parallel.barrier()
-    q.put((rank, err, bool(same), n_local))
+    q.put((rank, err, bool(same), n_local, draws))
     torch.distributed.destroy_process_group()
 
 
@@ -81,10 +87,11 @@ def test_world2_gradient_allreduce_and_table_max():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
-    for rank, err, same, n_local in res:
+    for rank, err, same, n_local, draws in res:
         assert err < 1e-5, (rank, err)      # summation order only
         assert same, rank
         assert n_local == 6
+    assert res[0][4] == res[1][4]           # same seed, same torch and numpy draws on both ranks
 
 
 def test_shard_covers_batch():
