@@ -369,6 +369,9 @@ def sample_pdf(bins, weights, Ni, det=False, u=None, seed=0):
 
 def mse_leafmax(rgb, rgb0, target, grad_scale=1.0, want_grads=True, leaf_tag=None, max_leaves=0, table=None):
     require_gpu(rgb, rgb0, target, leaf_tag, table)
+    rgb, target = _f32(rgb), _f32(target)
+    rgb0 = None if rgb0 is None else _f32(rgb0)
+    leaf_tag = None if leaf_tag is None else leaf_tag.contiguous()
     n = rgb.shape[0]
     dev = rgb.device
     g = torch.empty(n, 3, device=dev, dtype=torch.float32) if want_grads else None

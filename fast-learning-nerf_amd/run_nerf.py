@@ -364,7 +364,9 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
         for b0 in range(0, n_total, N_rand):
             b1 = min(b0 + N_rand, n_total)
             sl = slice(b0 + rank, b1, world) if world > 1 else slice(b0, b1)
-            loss2, _ = trainer.step(rays_o[sl], rays_d[sl], tgt[sl], leaf_tag=None if tags is None else tags[sl],
+            # (a rank's rows r::world of the global batch are a strided view: the kernels take contiguous buffers)
+            loss2, _ = trainer.step(rays_o[sl].contiguous(), rays_d[sl].contiguous(), tgt[sl].contiguous(),
+                                    leaf_tag=None if tags is None else tags[sl].contiguous(),
                                     table=table, max_leaves=max_leaves, n_global=(b1 - b0) if world > 1 else None,
                                     decay=decay)
             it += 1

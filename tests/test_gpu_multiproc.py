@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -115,3 +116,48 @@ def test_sharded_trainer_equals_single_rank_on_the_union(tmp_path, compact):
     scale = a['flat'].abs().max().item()
     assert float((d > 1e-6 * scale).float().mean()) < 0.10, float((d > 1e-6 * scale).float().mean())   # measured 2-4 %
     assert d.max().item() <= 4 * 5e-4 * 2.001
+
+
+_TRAIN_WORKER = r"""
+import os, sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+import fastnerf
+from fastnerf import parallel
+rank, world, local = parallel.init_from_env('cuda')
+torch.cuda.set_device(0 if torch.cuda.device_count() < world else local)
+imgs, poses, focal = fastnerf.synthetic.make_dataset(n_images=3, H=32, W=32)
+np.random.seed(7 + rank)               # ranks start from DIFFERENT numpy states (the warm-up coordinates are drawn with numpy):
+                                       # train() must synchronise them itself (parallel.sync_seed)
+args = fastnerf.run_nerf.make_args(N_importance=16, N_samples=16, perturb=1.0, white_bkgd=True, no_reload=True, N_rand=250,
+                                   n_epoch=3, init_level=2, subdivide_every=1, subdivide_thres=0.05, lrate=5e-4, lrate_decay=500)
+torch.manual_seed(0)                   # identical initial weights, as every data-parallel run needs
+logs = []
+_, _, trainer, mgr, hist = fastnerf.run_nerf.train(imgs, poses, 32, 32, focal, args, log=logs.append)
+torch.cuda.synchronize()
+digest = hashlib.sha1(trainer.flat.cpu().numpy().tobytes()).hexdigest()
+leaves = [mgr.leaves(i).tolist() for i in range(3)]
+torch.save({'digest': digest, 'leaves': leaves, 'hist': hist, 'adam_t': trainer.adam_t}, %(out)r %% rank)
+if world > 1:
+    parallel.barrier(); torch.distributed.destroy_process_group()
+"""
+
+
+def test_train_driver_on_two_ranks(tmp_path):
+    """run_nerf.train() under two ranks: every rank builds the same epoch ray lists (seed broadcast from rank 0), takes rows
+    r::2 of every global batch -- the last batch of an epoch can leave a rank without rays -- and all ranks hold bit-identical
+    parameters and trees at the end."""
+    script = str(tmp_path / 'train_worker.py')
+    out = str(tmp_path / 'train_%d.pt')
+    with open(script, 'w') as f:
+        f.write(_TRAIN_WORKER % {'root': ROOT, 'out': out})
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env['FASTNERF_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29547', script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    assert a['digest'] == b['digest'] and a['leaves'] == b['leaves'] and a['adam_t'] == b['adam_t']
+    assert len(a['hist']) == 3 and all(np.isfinite(h[2]) for h in a['hist']) and a['hist'][-1][2] < 0.1
+    assert [h[1] for h in a['hist']] == [h[1] for h in b['hist']]            # same number of steps on both ranks
