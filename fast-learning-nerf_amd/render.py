@@ -82,6 +82,7 @@ def get_compact():
 class LivePolicy:
     """Decides per step whether the backward runs compacted; fed with the (live, total) counters of compacted steps
     through pinned-memory copies that are only read once their event has completed (never stalls the stream)."""
+    MAX_LAG = 6
     EVERY, PROBE = 4, 256   # (a measurement is a 16-byte asynchronous copy: cheap enough to follow fast changes early in training)
     # break-even live fractions from the measured kernel times (forward without saving + f x (saving forward + backward)
     # against saving forward + backward): 0.76 in the split-bf16 mode, 0.69 in the exact-fp32 mode; hysteresis around them
@@ -107,6 +108,11 @@ class LivePolicy:
         return self.step % self.PROBE == 0     # an occasional compacted step keeps the measurement alive
 
     def poll(self):
+        # The host enqueues steps faster than the GPU runs them, so a measurement can stay "pending" for as many steps as the
+        # queue is deep.  Decisions are never taken more than MAX_LAG steps blind: waiting for that event then only holds
+        # the HOST back -- the GPU still has MAX_LAG steps of work queued behind it.
+        if self._pending is not None and self.step - self._pending[2] >= self.MAX_LAG:
+            self._pending[1].synchronize()
         if self._pending is not None and self._pending[1].query():
             c = self._pending[0].tolist()
             self._pending = None
@@ -125,7 +131,7 @@ class LivePolicy:
             host.copy_(counts, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._pending = (host, ev)
+            self._pending = (host, ev, self.step)
 
     def tick(self):
         self.step += 1

@@ -228,7 +228,7 @@ def test_autograd_route_and_policy(fn, golden_dir, math_mode):
         seq = ((0.9, False), (0.75, False), (0.5, True), (0.74, True)) if math_mode == 'bf16x3' else \
               ((0.9, False), (0.66, False), (0.5, True), (0.66, True))
         for frac, want in seq:
-            pol._pending = (torch.tensor([int(frac * 1000), 1000, 0, 0], dtype=torch.int32), torch.cuda.Event())
+            pol._pending = (torch.tensor([int(frac * 1000), 1000, 0, 0], dtype=torch.int32), torch.cuda.Event(), 0)
             pol._pending[1].record(); torch.cuda.synchronize()
             pol.step = 1
             assert pol.use_live(tr.net_c, tr.net_f, 128) == want and abs(pol.frac - frac) < 1e-3
