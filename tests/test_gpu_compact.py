@@ -197,6 +197,41 @@ def test_training_steps_with_and_without_compaction(fn, golden_dir, math_mode):
         fn.render.set_compact(old)
 
 
+def test_compaction_with_density_noise_and_ndc(fn, golden_dir, math_mode):
+    """BASELINE configs[3] shape: NDC rays, raw_noise_std = 1 (render.py:170-180: alpha = 1 - exp(-relu(sigma + noise) * dist)):
+    the dead set is where sigma + NOISE <= 0, about half of all samples at initialisation.  Same noise in both backward modes
+    (seeded) -> identical losses, gradients to summation grouping."""
+    old = fn.render.get_compact()
+    try:
+        H, W, focal = 756, 1008, 815.13
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        gen = torch.Generator().manual_seed(4)
+        pix = torch.stack([torch.zeros(512, dtype=torch.int64), torch.randint(0, H, (512,), generator=gen),
+                           torch.randint(0, W, (512,), generator=gen)], 1).int().cuda()
+        poses = torch.eye(4)[None, :3, :4].contiguous().cuda()
+        ro, rd = fn.ops.gen_rays_pixels(pix, poses, K)
+        tgt = torch.rand(512, 3, generator=gen).cuda()
+        res = {}
+        for mode in ('0', '1'):
+            fn.render.set_compact(mode)
+            torch.manual_seed(0)
+            args = fn.run_nerf.make_args(N_importance=64, N_samples=64, perturb=1.0, raw_noise_std=1.0, no_reload=True, dataset_type='llff')
+            ktr, _, _, _, _, _ = fn.run_nerf.create_nerf(args)
+            assert 'ndc' not in ktr                                  # LLFF kwargs: render() / Trainer default to ndc=True
+            tr = fn.run_nerf.Trainer(ktr, H, W, K, 0.0, 1.0)
+            t_rand, u = torch.rand(512, 64, generator=torch.Generator().manual_seed(8)).cuda(), torch.rand(512, 64, generator=torch.Generator().manual_seed(9)).cuda()
+            torch.manual_seed(77)                                    # the sigma noise of this step
+            loss2, _ = tr.forward_backward(ro, rd, tgt, t_rand=t_rand, u=u)
+            res[mode] = (loss2.cpu(), tr.grad.clone(), tr.live_counts.cpu().tolist() if mode == '1' else None)
+        assert torch.equal(res['0'][0], res['1'][0])
+        ga, gb = res['0'][1], res['1'][1]
+        assert (ga - gb).abs().max().item() < 3e-6 * ga.abs().max().item()
+        c = res['1'][2]
+        assert 0.35 < c[0] / c[1] < 0.65 and 0.35 < c[2] / c[3] < 0.65         # sigma ~ 0.02 against unit noise: half are dead
+    finally:
+        fn.render.set_compact(old)
+
+
 def test_autograd_route_and_policy(fn, golden_dir, math_mode):
     """render(...); loss.backward() picks the compacted backward too; `auto` follows the measured live fraction."""
     old = fn.render.get_compact()
