@@ -43,7 +43,11 @@ typedef unsigned long long u64;
 #define DW_AUX 2   // cache-policy bits of the dW operand DMA (saved tensors are read exactly once)
 #endif
 #ifndef DW_CFG
-#define DW_CFG 2, 2, 4, 4
+#define DW_CFG 4, 2, 2, 4   // WO, WI, TO, TI of the 256 x 256 dW jobs: 8 waves (two per SIMD) x (2 x 4) tiles.  Round 1 ran 4 waves x
+                            // (4 x 4) tiles = ONE wave per SIMD, where nothing hides the operand DMA issue, the fragment reads and
+                            // the bias sums behind the MFMAs: the loop is issue-bound, not HBM-bound (round-2 ablations: no gain from
+                            // contiguous operand runs or a 4th ring stage, and only -0.5 ms without ANY operand DMA); with two waves
+                            // per SIMD on today's LDS-DMA ring the fine-pass backward goes 6.14 -> 5.88 ms (16 waves: equal)
 #endif
 #ifndef BF_PRIO
 #define BF_PRIO 1   // s_setprio level of a wave inside the k-loops (0: none); +1..2 % with two workgroups per CU
@@ -1209,7 +1213,19 @@ __device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&
   for (int i = 0; i < TO; ++i)
 #pragma unroll
     for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(al[i], xh[j], acc[i][j]);
-  if (BIAS && wi == wo % WI) {
+  // column sums of dY (bias gradient): ~23 VALU per tile and k-step that nothing hides inside a single wave per SIMD.  The WI
+  // waves of a row group hold the same dY tiles: without a rank-1 row to balance against they split the tiles between them
+  // (tile i belongs to wave i % WI) instead of leaving all of them to one wave and the others at the barrier.
+  constexpr bool SPLITB = BIAS && !RANK1 && WI > 1 && TO % WI == 0;
+  if (SPLITB) {
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+      if (i % WI == wi) {
+        float v[8];
+        unpk8v(ah[i], al[i], v);
+        bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+  } else if (BIAS && wi == wo % WI) {
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
       float v[8];
@@ -1236,7 +1252,7 @@ __device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&
 // the hand-over is a raw s_barrier behind a counted vmcnt wait so that the newest stage stays in flight across it.
 // dW is HBM bound (matrix pipe ~35% busy), so the DMA issue cost is irrelevant here.
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
-__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
+__global__ void __launch_bounds__(WO * WI * 64, 1)   // (HIP: second argument = minimum waves per SIMD; the LDS ring allows one workgroup per CU)
 mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ dY, const uint4* __restrict__ X,
                            const float* __restrict__ dalpha, float* __restrict__ partial_w, float* __restrict__ partial_b,
                            float* __restrict__ partial_r, const int* __restrict__ live_cnt) {
@@ -1281,8 +1297,13 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
       const int p = i * NW + wave;
       if (NPIECE % NW == 0 || p < NPIECE) {
         const int ct = p >> 1, half = p & 1;
+#ifdef DW_ABL_CONTIG   // timing-only ablation: a k-step's operand tiles contiguous in memory (16 KiB runs instead of 2 KiB at 8 KiB stride)
+        const uint4* src = (ct < CTO) ? dY + ((tile * 4 + ks) * CTO + ct) * 128 + half * 64 + lane
+                                      : X + ((tile * 4 + ks) * CTI + (ct - CTO)) * 128 + half * 64 + lane;
+#else
         const uint4* src = (ct < CTO) ? dY + ((tile * CTO + ct) * 4 + ks) * 128 + half * 64 + lane
                                       : X + ((tile * CTI + (ct - CTO)) * 4 + ks) * 128 + half * 64 + lane;
+#endif
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, DW_AUX);
       }
@@ -1310,7 +1331,11 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       const int bn = (buf >= 1) ? buf - 1 : DW_NST - 1;   // (buf + DW_NST - 1) % DW_NST: the stage consumed at step q-1
+#ifdef DW_ABL_NODMA   // timing-only ablation: no operand DMA after the prologue (what do issue + HBM cost the loop?)
+      const int64_t qn = nq;
+#else
       const int64_t qn = q + DW_NST - 1;
+#endif
 #if DW_DMA_LATE
       dw_stage_compute<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, reinterpret_cast<const uint4*>(dsm) + buf * STAGE_U4, wo, wi,
                                                     lane, d0, d1, [&]() __attribute__((always_inline)) { if (qn < nq) dma_stage(qn, bn); });
@@ -1339,9 +1364,11 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
         const int c = (wi * TI + j) * 32 + (lane & 31);
         pw[(int64_t)o * KI + c] = acc[i][j][r];
       }
-  if (BIAS && wi == wo % WI) {
+  constexpr bool SPLITB = BIAS && !RANK1 && WI > 1 && TO % WI == 0;   // (see dw_stage_compute)
+  if (BIAS && (SPLITB || wi == wo % WI)) {
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
+      if (SPLITB && i % WI != wi) continue;
       const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
       if (lane < 32) partial_b[(int64_t)blockIdx.x * NO + (wo * TO + i) * 32 + lane] = s;
     }
@@ -1525,7 +1552,7 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
   };
   const uint4* a_pe = act + ba_pe(nt);
   // L0
-  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 2, nullptr, region(0), nwg, st, live_cnt);
+  if (PEP == 64) rc = b_launch_dw<4, 2, 2, 1, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 2, nullptr, region(0), nwg, st, live_cnt);
   else rc = b_launch_dw<4, 1, 2, 3, true, false>(P, nt, dact + bd_y(nt, 0), 8, a_pe, 3, nullptr, region(0), nwg, st, live_cnt);
   if (rc) return rc;
   segs(0, L.LW[0], L.in_pe, L.in_pe, 1, L.LB[0], 0);
@@ -1535,7 +1562,7 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, 3, L.LB[l], 0);
   }
   // L5 pe part
-  if (PEP == 64) rc = b_launch_dw<4, 1, 2, 2, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st, live_cnt);
+  if (PEP == 64) rc = b_launch_dw<4, 2, 2, 1, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 2, nullptr, region(8), nwg, st, live_cnt);
   else rc = b_launch_dw<4, 1, 2, 3, false, false>(P, nt, dact + bd_y(nt, 5), 8, a_pe, 3, nullptr, region(8), nwg, st, live_cnt);
   if (rc) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 1, 0, 0);
@@ -1544,7 +1571,7 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
                                                  reinterpret_cast<const float*>(dact + bd_alpha(nt)), region(9), nwg, st, live_cnt))) return rc;
   segs(9, L.FW, 256, 256, 3, L.FB, L.AW);
   // view layer
-  if ((rc = b_launch_dw<2, 2, 2, 4, true, false>(P, nt, dact + bd_yv(nt), 4, act + ba_feat(nt), 8, nullptr, region(10), nwg, st, live_cnt))) return rc;
+  if ((rc = b_launch_dw<4, 2, 1, 4, true, false>(P, nt, dact + bd_yv(nt), 4, act + ba_feat(nt), 8, nullptr, region(10), nwg, st, live_cnt))) return rc;
   segs(10, L.VW, 283, 256, 2, L.VB, 0);
   if ((rc = b_launch_dw<4, 1, 1, 1, false, false>(P, nt, dact + bd_yv(nt), 4, act + ba_vpe(nt), 1, nullptr, region(11), nwg, st, live_cnt))) return rc;
   segs(11, L.VW + 256, 283, 27, 0, 0, 0);
