@@ -1349,7 +1349,9 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
       if (newer >= DW_NST - 2) wait_stages(DW_NST - 2);
       else if (newer == 1) wait_stages(1);
       else wait_stages(0);
+#ifndef DW_ABL_NOBAR   // timing-only ablation (with DW_ABL_NODMA): how much does the per-k-step lockstep of the waves cost?
       __builtin_amdgcn_s_barrier();
+#endif
       buf = (buf == DW_NST - 1) ? 0 : buf + 1;
     }
   }
