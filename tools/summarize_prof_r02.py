@@ -89,8 +89,8 @@ def sq_tables():
         label[tail[2]] = 'dX (786 432 points)'
         label[tail[15]] = 'forward, saving, live list (52.5 %)'
         label[tail[16]] = 'dX, live list (52.5 %)'
-        dw_plain = [d for d in tail[3:15] if '<2, 2, 4, 4, true, false>' in names[d]]
-        dw_live = [d for d in tail[17:29] if '<2, 2, 4, 4, true, false>' in names[d]]
+        dw_plain = [d for d in tail[3:15] if '<4, 2, 2, 4, true, false>' in names[d]]
+        dw_live = [d for d in tail[17:29] if '<4, 2, 2, 4, true, false>' in names[d]]
         if dw_plain:
             label[dw_plain[0]] = 'dW 256x256 job (786 432 points)'
         if dw_live:
@@ -180,7 +180,7 @@ def main():
 
     def share(k):
         d = sq[k]
-        wps = 1.0 if k.startswith('dW') else 2.0        # waves per SIMD: dW runs one 4-wave workgroup per CU, fwd / dX two
+        wps = 2.0                                       # waves per SIMD: fwd / dX run two 4-wave workgroups per CU, dW one 8-wave workgroup
         return d['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * d['SQ_WAVE_CYCLES'] / wps)
     md.append('| **matrix pipe busy, share of SIMD time** (MFMA_BUSY / (4 x WAVE_CYCLES / waves per SIMD)) | ' +
               ' | '.join('**%.0f %%**' % (100 * share(k)) for k in cols) + ' |')
