@@ -33,6 +33,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
+#ifndef DW_PIPE
+#define DW_PIPE 0   // 1: read the LDS fragments of k-step q+1 under the MFMAs of k-step q (needs DW_NST >= 4)
+#endif
 #ifndef DW_NST
 #define DW_NST 3   // LDS stages of the dW operand ring (DW_NST - 1 k-steps prefetched)
 #endif
@@ -1174,45 +1177,53 @@ __device__ __forceinline__ void unpk8v(const u32x4& h, const u32x4& l, float (&o
     o[2 * q + 1] = __uint_as_float(h[q] & 0xffff0000u) + __uint_as_float(l[q] & 0xffff0000u);
   }
 }
-// `between` runs after the fragment reads have been ISSUED and before they are waited for: the caller puts the DMA issue of
-// a later stage there, so its ~80 issue cycles per piece cover the LDS read latency instead of preceding it.
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, class F>
-__device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&bsum)[TO], float (&rsum)[TI], const uint4* st, int wo,
-                                                 int wi, int lane, const float4& d0, const float4& d1, F&& between) {
-  constexpr int CTO = WO * TO;
-  // The fragment reads are inline asm: for a plain LDS load hipcc inserts s_waitcnt vmcnt(0) while an LDS-DMA is
-  // pending (it cannot see that the DMA targets another stage), which would drain the prefetch every k-step.
-  // The hand-over in the caller (counted vmcnt + s_barrier) is what orders these reads behind the DMA of THIS stage.
-  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(const char*)st + lane * 16;
+// One k-step of the dW tile product in three pieces, so that a caller can run the LDS fragment reads of step q+1 under the
+// MFMAs of step q (DW_PIPE) or all three back to back with the DMA issue between issue and wait.
+// The fragment reads are inline asm: for a plain LDS load hipcc inserts s_waitcnt vmcnt(0) while an LDS-DMA is
+// pending (it cannot see that the DMA targets another stage), which would drain the prefetch every k-step.
+// The hand-over in the caller (counted vmcnt + s_barrier) is what orders these reads behind the DMA of THIS stage.
+template <int TO, int TI>
+struct DwFrag {
   u32x4 ah[TO], al[TO], xh[TI], xl[TI];
+};
+template <int WO, int WI, int TO, int TI>
+__device__ __forceinline__ void dw_issue_reads(DwFrag<TO, TI>& f, const uint4* st, int wo, int wi, int lane) {
+  constexpr int CTO = WO * TO;
+  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(const char*)st + lane * 16;
 #pragma unroll
   for (int i = 0; i < TO; ++i) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(ah[i]) : "v"(lbase + ((wo * TO + i) * 128) * 16));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(al[i]) : "v"(lbase + ((wo * TO + i) * 128 + 64) * 16));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.ah[i]) : "v"(lbase + ((wo * TO + i) * 128) * 16));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.al[i]) : "v"(lbase + ((wo * TO + i) * 128 + 64) * 16));
   }
 #pragma unroll
   for (int j = 0; j < TI; ++j) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(xh[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128) * 16));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(xl[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128 + 64) * 16));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.xh[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128) * 16));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.xl[j]) : "v"(lbase + ((CTO + wi * TI + j) * 128 + 64) * 16));
   }
-  between();
-  // wait for the reads; tying the registers to the wait keeps every consumer behind it
+}
+// wait for the reads; tying the registers to the wait keeps every consumer behind it
+template <int TO, int TI>
+__device__ __forceinline__ void dw_wait_reads(DwFrag<TO, TI>& f) {
 #pragma unroll
-  for (int i = 0; i < TO; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
+  for (int i = 0; i < TO; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.ah[i]), "+v"(f.al[i]));
 #pragma unroll
-  for (int j = 0; j < TI; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[j]), "+v"(xl[j]));
-#pragma unroll
-  for (int i = 0; i < TO; ++i)
-#pragma unroll
-    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(ah[i], xh[j], acc[i][j]);
-#pragma unroll
-  for (int i = 0; i < TO; ++i)
-#pragma unroll
-    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(ah[i], xl[j], acc[i][j]);
+  for (int j = 0; j < TI; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.xh[j]), "+v"(f.xl[j]));
+}
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+__device__ __forceinline__ void dw_mfma(f32x16 (&acc)[TO][TI], float (&bsum)[TO], float (&rsum)[TI], const DwFrag<TO, TI>& f, int wo,
+                                        int wi, const float4& d0, const float4& d1) {
 #pragma unroll
   for (int i = 0; i < TO; ++i)
 #pragma unroll
-    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(al[i], xh[j], acc[i][j]);
+    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(f.ah[i], f.xh[j], acc[i][j]);
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(f.ah[i], f.xl[j], acc[i][j]);
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = bmfma4(f.al[i], f.xh[j], acc[i][j]);
   // column sums of dY (bias gradient): ~23 VALU per tile and k-step that nothing hides inside a single wave per SIMD.  The WI
   // waves of a row group hold the same dY tiles: without a rank-1 row to balance against they split the tiles between them
   // (tile i belongs to wave i % WI) instead of leaving all of them to one wave and the others at the barrier.
@@ -1222,14 +1233,14 @@ __device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&
     for (int i = 0; i < TO; ++i)
       if (i % WI == wi) {
         float v[8];
-        unpk8v(ah[i], al[i], v);
+        unpk8v(f.ah[i], f.al[i], v);
         bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       }
   } else if (BIAS && wi == wo % WI) {
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
       float v[8];
-      unpk8v(ah[i], al[i], v);
+      unpk8v(f.ah[i], f.al[i], v);
       bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
   }
@@ -1238,11 +1249,22 @@ __device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&
 #pragma unroll
     for (int j = 0; j < TI; ++j) {
       float v[8];
-      unpk8v(xh[j], xl[j], v);
+      unpk8v(f.xh[j], f.xl[j], v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) rsum[j] = fmaf(da[e], v[e], rsum[j]);
     }
   }
+}
+// `between` runs after the fragment reads have been ISSUED and before they are waited for: the caller puts the DMA issue of
+// a later stage there, so its ~80 issue cycles per piece cover the LDS read latency instead of preceding it.
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, class F>
+__device__ __forceinline__ void dw_stage_compute(f32x16 (&acc)[TO][TI], float (&bsum)[TO], float (&rsum)[TI], const uint4* st, int wo,
+                                                 int wi, int lane, const float4& d0, const float4& d1, F&& between) {
+  DwFrag<TO, TI> f;
+  dw_issue_reads<WO, WI, TO, TI>(f, st, wo, wi, lane);
+  between();
+  dw_wait_reads<TO, TI>(f);
+  dw_mfma<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, f, wo, wi, d0, d1);
 }
 
 // Every operand byte is fetched from HBM exactly once per workgroup (a first version that loaded fragments straight
@@ -1315,8 +1337,60 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
     auto wait_stages = [&](int n) __attribute__((always_inline)) {
       if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (n == 1) { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW - 1) : "memory"); }
-      else { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PPW - 1)) : "memory"); }
+      else if (n == 2) { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PPW - 1)) : "memory"); }
+      else { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (PPW - 1)) : "memory"); }
     };
+    static_assert(DW_NST <= 5 && 3 * PPW < 64, "wait_stages counts up to three stages in flight (vmcnt is 6 bits)");
+    // `newer` stages were issued after the one that has to be complete: let min(newer, cap) of them stay in flight
+    auto wait_newer = [&](int64_t newer, int cap) __attribute__((always_inline)) {
+      if (newer >= cap) wait_stages(cap);
+      else if (newer == 2) wait_stages(2);
+      else if (newer == 1) wait_stages(1);
+      else wait_stages(0);
+    };
+#if DW_PIPE
+    // Software pipeline: the fragment reads of k-step q+1 are issued before the MFMAs of k-step q and waited for after
+    // them, so the matrix pipe does not idle for the LDS round trip every k-step.  The ring is one stage deeper than the
+    // plain loop's for the same DMA lead: stage q+2 has to be complete at the END of k-step q.
+    //   k-step q:  reads(q+1) -> set B | DMA(q+NST-1) -> stage (q-1) % NST | MFMAs(q) from set A | wait B | wait DMA(q+2) | barrier
+    // stage q-1 is free at k-step q: its reads were waited for before the barrier that ended k-step q-2.
+    static_assert(DW_NST >= 4, "DW_PIPE needs a ring of >= 4 stages");
+#pragma unroll
+    for (int i = 0; i < DW_NST - 1; ++i) dma_stage(i, i);
+    const uint4* ring = reinterpret_cast<const uint4*>(dsm);
+    DwFrag<TO, TI> fa, fb;
+    wait_stages(DW_NST - 2);   // stage 0 landed (own pieces)
+    __builtin_amdgcn_s_barrier();
+    dw_issue_reads<WO, WI, TO, TI>(fa, ring, wo, wi, lane);
+    wait_stages(DW_NST - 3);   // stage 1
+    dw_wait_reads<TO, TI>(fa);
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;               // stage of k-step q
+    auto kstep = [&](int64_t q, DwFrag<TO, TI>& cur, DwFrag<TO, TI>& nxt) __attribute__((always_inline)) {
+      float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+      if (RANK1 && wo == (wi + 1) % WO) {   // before the DMA issue: its wait must not drain the newest stage
+        const float4* dp = reinterpret_cast<const float4*>(dalpha + (t0 + (q >> 2)) * 64 + (q & 3) * 16 + (lane >> 5) * 8);
+        d0 = dp[0]; d1 = dp[1];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const int b1 = (buf == DW_NST - 1) ? 0 : buf + 1;
+      const int bn = (buf >= 1) ? buf - 1 : DW_NST - 1;
+      if (q + 1 < nq) dw_issue_reads<WO, WI, TO, TI>(nxt, ring + b1 * STAGE_U4, wo, wi, lane);
+      if (q + DW_NST - 1 < nq) dma_stage(q + DW_NST - 1, bn);
+      dw_mfma<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, cur, wo, wi, d0, d1);
+      dw_wait_reads<TO, TI>(nxt);
+      const int64_t newer = (nq - 1 - (q + 2));   // stages issued after q+2 (clamped)
+      wait_newer(newer, DW_NST - 3);
+      __builtin_amdgcn_s_barrier();
+      buf = b1;
+    };
+#pragma unroll 1
+    for (int64_t q = 0; q < nq; q += 2) {   // nq is even: the register sets swap roles by unrolling
+      kstep(q, fa, fb);
+      kstep(q + 1, fb, fa);
+    }
+  }
+#else
 #pragma unroll
     for (int i = 0; i < DW_NST - 1; ++i) dma_stage(i, i);
     wait_stages(DW_NST - 2);   // stage 0 landed (own pieces)
@@ -1346,15 +1420,14 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
 #endif
       // stage q+1 must have landed; the newer ones may stay in flight
       const int64_t newer = (nq - 1 - (q + 1));   // stages issued after q+1 (clamped below)
-      if (newer >= DW_NST - 2) wait_stages(DW_NST - 2);
-      else if (newer == 1) wait_stages(1);
-      else wait_stages(0);
+      wait_newer(newer, DW_NST - 2);
 #ifndef DW_ABL_NOBAR   // timing-only ablation (with DW_ABL_NODMA): how much does the per-k-step lockstep of the waves cost?
       __builtin_amdgcn_s_barrier();
 #endif
       buf = (buf == DW_NST - 1) ? 0 : buf + 1;
     }
   }
+#endif
   float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
 #pragma unroll
   for (int i = 0; i < TO; ++i)
