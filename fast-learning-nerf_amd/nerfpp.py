@@ -262,6 +262,7 @@ class CascadeTrainer:
         fg_far = ops.pp_intersect_sphere(rays11)
         losses, ret = [], None
         fg_z = bg_z = None
+        self.last_depths = []      # (fg_z, bg_z) of every level: what a checker needs to re-evaluate the batch
         for m, net in enumerate(self.nets):
             N = self.cascade_samples[m]
             r = rand[m] if rand is not None else {}
@@ -272,6 +273,7 @@ class CascadeTrainer:
             else:
                 fg_z, _ = ops.pp_sample_pdf_merge(fg_z, ret[1], N, u=r.get('fg_u'), seed=_next_seed())
                 bg_z, _ = ops.pp_sample_pdf_merge(bg_z, ret[5], N, u=r.get('bg_u'), seed=_next_seed())
+            self.last_depths.append((fg_z, bg_z))
             outs, saved = _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save=True)
             fg_rgb, fg_w, fg_depth, lam, bg_rgb, bg_w, bg_depth = outs
             rgb = fg_rgb + lam[:, None] * bg_rgb
