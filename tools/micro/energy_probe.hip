@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NL, int NG, int NV, int NS>
+template <int NL, int NG, int NV, int NS, int ND = 0>
 __global__ void __launch_bounds__(256, 2) k(long long* out, const uint4* __restrict__ data, uint4* __restrict__ sink, int iters) {
   extern __shared__ uint4 lds[];
   for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = data[i];
@@ -29,6 +29,10 @@ __global__ void __launch_bounds__(256, 2) k(long long* out, const uint4* __restr
     uint4 l[NL > 0 ? NL : 1], g[NG > 0 ? NG : 1];
 #pragma unroll
     for (int i = 0; i < NL; ++i) l[i] = lds[(it * 64 + i * 256 + threadIdx.x) & 2047];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)   // LDS-DMA of 1 KiB per wave instruction from the L2-resident table into a private ring slot
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(data + ((((it * 4 + w) * (ND > 0 ? ND : 1) + i) * 64 + lane) & 0x1ffff)),
+                                       (__attribute__((address_space(3))) void*)((char*)lds + 32768 + ((w * 4 + ((it * ND + i) & 3)) * 1024)), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < NG; ++i) g[i] = data[(((it * 4 + w) * (NG > 0 ? NG : 1) + i) * 64 + lane) & 0x1ffff];
 #pragma unroll
@@ -56,11 +60,11 @@ __global__ void __launch_bounds__(256, 2) k(long long* out, const uint4* __restr
   if (threadIdx.x == 0) { out[blockIdx.x * 4] = t1 - t0; out[blockIdx.x * 4 + 1] = w1 - w0; out[blockIdx.x * 4 + 2] = (long long)s + x; }
 }
 
-template <int NL, int NG, int NV, int NS>
+template <int NL, int NG, int NV, int NS, int ND = 0>
 void run(long long* out, long long* h, const uint4* data, uint4* sink, int wpc, const char* what) {
   const int grid = 256 * wpc, iters = NS ? 8000 : 30000;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<NL, NG, NV, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<NL, NG, NV, NS>), dim3(grid), dim3(256), 65536, 0, out, data, sink, iters);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<NL, NG, NV, NS, ND>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<NL, NG, NV, NS, ND>), dim3(grid), dim3(256), 65536, 0, out, data, sink, iters);
   (void)hipDeviceSynchronize();
   (void)hipMemcpy(h, out, grid * 4 * 8, hipMemcpyDeviceToHost);
   double t = 0, w = 0;
@@ -96,6 +100,10 @@ int main() {
     run<8, 2, 72, 1>(out, h, data, sink, wpc, "+ 8 ds_read + 2 L2 + 72 VALU + 1 store");
     run<8, 0, 36, 0>(out, h, data, sink, wpc, "+ 8 ds_read + 36 VALU (weights through LDS)");
     run<8, 0, 72, 1>(out, h, data, sink, wpc, "+ 8 ds_read + 72 VALU + 1 store (weights through LDS)");
+    run<6, 2, 36, 0, 2>(out, h, data, sink, wpc, "+ 6 ds_read + 2 L2 + 2 LDS-DMA + 36 VALU (lo weight plane via DMA)");
+    run<6, 2, 72, 1, 2>(out, h, data, sink, wpc, "+ 6 ds_read + 2 L2 + 2 LDS-DMA + 72 VALU + 1 store");
+    run<8, 0, 36, 0, 4>(out, h, data, sink, wpc, "+ 8 ds_read + 4 LDS-DMA + 36 VALU (all weights via DMA)");
+    run<8, 0, 72, 1, 4>(out, h, data, sink, wpc, "+ 8 ds_read + 4 LDS-DMA + 72 VALU + 1 store");
   }
   return 0;
 }
