@@ -27,6 +27,7 @@ import argparse
 import json
 import os
 import sys
+import math
 import time
 
 import numpy as np
@@ -163,7 +164,10 @@ def main():
         k_train, k_test, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
         return fastnerf.run_nerf.Trainer(k_train, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500), k_test
 
+    n_opt = {}              # optimisation steps applied per trainer (for the PSNR@iterations figure)
+
     def step(trainer, i, noise=False):
+        n_opt[id(trainer)] = n_opt.get(id(trainer), 0) + 1
         ro, rd, tgt, tgt_noise, tag = batches[i % n_batches]
         return trainer.step(ro, rd, tgt_noise if noise else tgt, leaf_tag=tag, table=table, max_leaves=max_leaves, n_global=n_global)
 
@@ -344,8 +348,14 @@ def main():
                 fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kte)
             torch.cuda.synchronize()
             dt_i = (time.perf_counter() - t1) / n_rep
+            rgb_i = fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kte)[0]
+            mse_i = float(torch.mean((rgb_i - synthetic.render_rays(ro_i, rd_i)) ** 2))
         infer = {'value': n_inf / dt_i, 'unit': 'rays/s', 'rays_per_call': n_inf, 'ms_per_call': 1e3 * dt_i,
-                 'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), 1 GPU'}
+                 'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), 1 GPU',
+                 # the metric's second half: PSNR of the nets this run trained, on rays that were never in a batch
+                 'psnr_db': -10.0 * math.log10(max(mse_i, 1e-12)), 'psnr_after_optimisation_steps': n_opt.get(id(tr), 0),
+                 'psnr_what': 'held-out rays of the analytic scene (32768 random pixels of the 100 views, seed 7) against its '
+                              'quadrature colours; %d rays per step per GPU' % N_RAYS}
 
     if rank == 0:
         rays_per_s = N_RAYS * world * a.steps / dt
@@ -361,6 +371,9 @@ def main():
                                    'white_bkgd, perturb=1, leaf-error table on (BASELINE configs[1]); steady state of training '
                                    'the analytic Lego-like scene (%d untimed optimisation steps from random init, then W + K)' % a.scene_steps,
                        'rays_per_gpu_per_step': N_RAYS, 'parallelism': f'dp{world}', 'scene_steps': a.scene_steps},
+            'device': {'name': torch.cuda.get_device_name(dev), 'compute_units': torch.cuda.get_device_properties(dev).multi_processor_count,
+                       'note': 'the chip is power-managed under these kernels (DESIGN section 9): the same tree measured 384 k .. 429 k rays/s on '
+                               'different boxes of the pool, every leg moving together'},
             'final_loss': [float(x) for x in loss2.tolist()],
             'backward': ('compacted: samples with an exactly-zero gradient skipped (FASTNERF_COMPACT=%s)' % fastnerf.render.get_compact())
             if backward_kind == 'compacted' else 'plain (every sample)',
