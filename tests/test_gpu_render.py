@@ -283,3 +283,55 @@ def test_llff_ndc_noise_g11(fn, golden_dir):
     for k, got in (('rgb', rgb), ('acc', acc), ('rgb0', ex['rgb0']), ('acc0', ex['acc0'])):
         assert np.abs(got.cpu().numpy() - g[k]).max() < TOL_RGB, k
     assert np.abs(ex['z_std'].cpu().numpy() - g['z_std']).max() < 1e-3
+
+
+def test_config1_coarse_only_step(fn, golden_dir, math_mode):
+    """BASELINE configs[0]: the 64 x 64 centre crop of frame 0, 1024 rays per batch, 32 coarse samples, N_importance = 0 (one
+    net, loss = the single MSE term, run_nerf.py:483-490).  Identical sample depths on both sides (injected jitter), so
+    every tensor's gradient is compared with the oracle's autograd tightly, then five fused steps follow the oracle's Adam."""
+    ktr, kte, _, _ = build(fn, golden_dir, N_importance=0, N_samples=32)
+    assert ktr['network_fine'] is None
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    c2w = fn.synthetic.pose_spherical(-180.0, -30.0, 4.0)[:3, :4]
+    ro_all, rd_all = fn.run_nerf_helpers.get_rays(800, 800, K, c2w.cuda())
+    gen = torch.Generator().manual_seed(11)
+    sel = torch.randperm(64 * 64, generator=gen)[:1024]
+    rows, cols = 368 + sel // 64, 368 + sel % 64
+    ro, rd = ro_all[rows.cuda(), cols.cuda()].contiguous(), rd_all[rows.cuda(), cols.cuda()].contiguous()
+    wts = np.load(os.path.join(golden_dir, 'g7_weights.npz'))
+    sd = {k[2:]: torch.from_numpy(wts[k]).clone() for k in wts.files if k.startswith('c.')}
+    rb = O.make_ray_batch(ro.cpu(), rd.cpu(), 2.0, 6.0)
+    tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+    opt = O.Adam(list(sd.values()), lr=5e-4) if hasattr(O, 'Adam') else None
+    for it in range(5 if opt is not None else 1):
+        tgt = torch.rand(1024, 3, generator=gen)
+        t_rand = torch.rand(1024, 32, generator=gen)
+        if it == 0:
+            loss2, out = tr.forward_backward(ro, rd, tgt.cuda(), t_rand=t_rand.cuda())
+            ps = list(sd.values())
+            for q in ps:
+                q.requires_grad_(True)
+            ret = O.render_rays(rb, sd, None, 32, 0, False, True, t_rand, None)
+            gr = torch.autograd.grad(O.img2mse(ret['rgb_map'], tgt), ps)
+            for q in ps:
+                q.requires_grad_(False)
+            assert 'rgb0' not in out and float(loss2[1]) == 0.0
+            assert abs(float(loss2[0]) - float(O.img2mse(ret['rgb_map'], tgt).detach())) < 1e-5
+            assert (out['rgb_map'].cpu() - ret['rgb_map'].detach()).abs().max() < TOL_RGB
+            grad = tr.grad.cpu()
+            assert grad.numel() == fn.ops.NET_PARAMS     # one net
+            off = 0
+            for (n, shp), gg in zip(O.nerf_param_shapes(), gr):
+                got = grad[off:off + gg.numel()].view(shp)
+                assert (got - gg).norm() < 2e-3 * gg.norm() + 1e-12, (n, float((got - gg).norm() / gg.norm()))
+                off += gg.numel()
+        if opt is not None:
+            l_dev, _ = tr.step(ro, rd, tgt.cuda(), t_rand=t_rand.cuda(), decay=False)
+            l_ref, l0, _, _ = O.train_step(sd, None, opt, rb, tgt, 32, 0, True, t_rand, None)
+            assert l0 is None and abs(float(l_dev[0]) - float(l_ref)) < 2e-5, (it, float(l_dev[0]), float(l_ref))
+    if opt is not None:
+        flat = torch.cat([v.reshape(-1) for v in sd.values()])
+        d = (tr.flat.cpu() - flat).abs()
+        # Adam's first steps move every weight by ~lr whatever the gradient's size: entries whose gradient is rounding noise
+        # may differ by O(lr); the bulk must agree
+        assert float((d > 2e-5).float().mean()) < 0.02, float((d > 2e-5).float().mean())
