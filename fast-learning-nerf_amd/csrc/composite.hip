@@ -150,7 +150,12 @@ __global__ void __launch_bounds__(256) raw2outputs_fwd_kernel(int64_t n, int S, 
         sr = fadd(sr, bg); sg = fadd(sg, bg); sb = fadd(sb, bg);
       }
       rgb_map[r * 3 + 0] = sr; rgb_map[r * 3 + 1] = sg; rgb_map[r * 3 + 2] = sb;
-      if (disp) disp[r] = 1.0f / fmaxf(1e-10f, sd / sa);
+      if (disp) {
+        // torch.max propagates NaN (render.py:186): a ray that hits nothing (acc == 0 exactly) has depth / acc = 0 / 0 and the
+        // reference's disparity is NaN there; fmaxf alone would return 1e-10 and report 1e10
+        const float q = sd / sa;
+        disp[r] = (q != q) ? q : 1.0f / fmaxf(1e-10f, q);
+      }
       if (acc) acc[r] = sa;
       if (depth) depth[r] = sd;
     }

@@ -257,7 +257,7 @@ class _RenderRaysFn(torch.autograd.Function):
         if counts is not None:
             _POLICY.after_live_step(counts)
         _POLICY.tick()
-        grads = list(_grad_views(out_c)) + (list(_grad_views(out_f)) if two else [])
+        grads = saved['net_c'].param_grads_from(out_c) + (saved['net_f'].param_grads_from(out_f) if two else [])
         assert len(grads) == ctx.n_params
         return (None,) + tuple(grads)
 
@@ -284,10 +284,16 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     net_f = getattr(network_fine, 'module', network_fine) if network_fine is not None else None
     if not isinstance(net_c, NeRF) or (net_f is not None and not isinstance(net_f, NeRF)):
         raise TypeError('render_rays needs fastnerf NeRF modules (the HIP path has no generic fallback)')
-    if ray_batch.shape[-1] != 11:
-        raise NotImplementedError('the HIP renderer implements use_viewdirs=True ray batches [N,11]')
+    if ray_batch.shape[-1] not in (8, 11):
+        raise ValueError('ray batches are [N,8] (o, d, near, far) or [N,11] (+ view directions), render.py:216-219')
+    if ray_batch.shape[-1] == 11 and not net_c.use_viewdirs:
+        raise ValueError('a ray batch with view directions needs networks built with use_viewdirs=True')
+    if ray_batch.shape[-1] == 8 and net_c.use_viewdirs:
+        raise ValueError('networks built with use_viewdirs=True need ray batches with view directions [N,11]')
     ops.require_gpu(ray_batch)
     rays11 = ray_batch.contiguous().float()
+    if rays11.shape[-1] == 8:      # no view directions: the kernels' direction slots stay zero (their weights are zero too)
+        rays11 = torch.cat([rays11, torch.zeros(rays11.shape[0], 3, device=rays11.device)], -1)
     n = rays11.shape[0]
     dev = rays11.device
     t_rand = u = noise0 = noise1 = None
@@ -337,18 +343,16 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
         rays_o, rays_d = get_rays(H, W, K, c2w)
     else:
         rays_o, rays_d = rays
-    if not use_viewdirs:
-        raise NotImplementedError('the HIP renderer implements use_viewdirs=True (all nerf-ours configs)')
     ops.require_gpu(rays_o, rays_d)
     view_o, view_d = rays_o, rays_d
-    if c2w_staticcam is not None:
+    if use_viewdirs and c2w_staticcam is not None:   # (render.py:59-66: the static camera only exists inside this branch)
         rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
     sh = rays_d.shape
-    if c2w_staticcam is None:
-        rays11 = ops.pack_rays(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=float(K[0][0]))
-    else:
-        # viewdirs come from the moving camera, origins/directions from the static one (render.py:59-66)
-        rays11 = ops.pack_rays(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=float(K[0][0]))
+    rays11 = ops.pack_rays(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=float(K[0][0]))
+    if not use_viewdirs:
+        rays11 = rays11[:, :8].contiguous()           # [N,8]: o, d, near, far (render.py:74-78)
+    elif c2w_staticcam is not None:
+        # viewdirs come from the moving camera, origins/directions from the static one
         rays11[:, 8:11] = ops.pack_rays(view_o, view_d, near, far)[:, 8:11]
     all_ret = batchify_rays(rays11, chunk, **kwargs)
     for k in all_ret:

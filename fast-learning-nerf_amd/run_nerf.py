@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import ops, parallel
-from .model import NeRF
+from .model import NeRF, noview_slices
 from .render import LivePolicy, _backward_core, _forward_core, render, render_path  # noqa: F401
 from .run_nerf_helpers import get_embedder, img2mse, mse2psnr
 from .tree import QuadTreeManager
@@ -39,12 +39,15 @@ def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk
     if not isinstance(net, NeRF):
         raise TypeError('run_network needs a fastnerf NeRF module')
     ops.require_gpu(inputs, viewdirs)
+    if (viewdirs is not None) != net.use_viewdirs:
+        raise ValueError('viewdirs must be given exactly when the network was built with use_viewdirs=True')
     sh = inputs.shape
     pts = inputs.reshape(-1, 3).float()
     P = pts.shape[0]
     rays11 = torch.zeros(P, 11, device=pts.device, dtype=torch.float32)
     rays11[:, 0:3] = pts
-    rays11[:, 8:11] = viewdirs[:, None].expand(sh).reshape(-1, 3)
+    if viewdirs is not None:
+        rays11[:, 8:11] = viewdirs[:, None].expand(sh).reshape(-1, 3)
     z = torch.zeros(P, 1, device=pts.device, dtype=torch.float32)
     raw = ops.mlp_fwd(rays11, z, net.flat, net.packed()[0])
     return raw.reshape(list(sh[:-1]) + [4])
@@ -74,24 +77,27 @@ def create_nerf(args, device='cuda'):
     """run_nerf.py:67-153 -> (render_kwargs_train, render_kwargs_test, start_epoch, start_iter,
     grad_vars, optimizer).  Both nets live in ONE flat parameter / gradient buffer (coarse first,
     as in `grad_vars`), which is what the fused Trainer and the RCCL all-reduce operate on."""
-    if not args.use_viewdirs or args.multires != 10 or args.multires_views != 4 or args.i_embed != 0:
-        raise NotImplementedError('HIP path implements use_viewdirs with multires=10, multires_views=4')
+    if args.multires != 10 or (args.use_viewdirs and args.multires_views != 4) or args.i_embed != 0:
+        raise NotImplementedError('HIP path implements multires=10, multires_views=4, i_embed=0')
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
-    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    embeddirs_fn, input_ch_views = None, 0                    # run_nerf.py:73-76
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
     two = args.N_importance > 0
     n_nets = 2 if two else 1
     dev = torch.device(device)
-    flat_all = torch.empty(n_nets * ops.NET_PARAMS, device=dev, dtype=torch.float32)
-    grad_all = torch.zeros(n_nets * ops.NET_PARAMS, device=dev, dtype=torch.float32)
-    N = ops.NET_PARAMS
     output_ch = 5 if two else 4
+    N = ops.NET_PARAMS if args.use_viewdirs else noview_slices(output_ch)[1]   # parameters per net
+    flat_all = torch.empty(n_nets * N, device=dev, dtype=torch.float32)
+    grad_all = torch.zeros(n_nets * N, device=dev, dtype=torch.float32)
     model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=[4],
-                 input_ch_views=input_ch_views, use_viewdirs=True, device=dev, flat=flat_all[:N], flat_grad=grad_all[:N])
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, device=dev, flat=flat_all[:N],
+                 flat_grad=grad_all[:N])
     grad_vars = list(model.parameters())
     model_fine = None
     if two:
         model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
-                          skips=[4], input_ch_views=input_ch_views, use_viewdirs=True, device=dev,
+                          skips=[4], input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, device=dev,
                           flat=flat_all[N:], flat_grad=grad_all[N:])
         grad_vars += list(model_fine.parameters())
     network_query_fn = lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn,
@@ -149,6 +155,7 @@ class Trainer:
         self.perturb, self.white_bkgd = kw['perturb'], kw['white_bkgd']
         self.raw_noise_std = kw.get('raw_noise_std', 0.)
         self.ndc, self.lindisp = kw.get('ndc', True), kw.get('lindisp', False)
+        self.use_viewdirs = self.net_c.use_viewdirs
         self.H, self.W, self.K, self.near, self.far = H, W, K, near, far
         self.flat = self.net_c._flat_all
         self.grad = self.net_c._grad_all
@@ -175,6 +182,8 @@ class Trainer:
         dev = rays_o.device
         rays11 = ops.pack_rays(rays_o, rays_d, self.near, self.far, ndc=self.ndc, H=self.H, W=self.W,
                                focal=float(self.K[0][0]))
+        if not self.use_viewdirs:
+            rays11[:, 8:11] = 0.
         noise0 = noise1 = None
         if self.raw_noise_std > 0.:
             noise0 = torch.randn(n, self.N_samples, device=dev) * self.raw_noise_std
@@ -187,6 +196,9 @@ class Trainer:
         loss2, g, g0 = ops.mse_leafmax(out['rgb_map'], out.get('rgb0'), target, grad_scale=scale, leaf_tag=leaf_tag,
                                        max_leaves=max_leaves, table=table)
         _backward_core(saved, g, g0, counts=self.live_counts if live else None)
+        self.net_c.collect_grads()          # (no-ops with view directions: the kernels write the parameters' gradients)
+        if self.net_f is not None and self.net_f is not self.net_c:
+            self.net_f.collect_grads()
         if live:
             self.live.after_live_step(self.live_counts)
         self.live.tick()

@@ -158,6 +158,8 @@ def nerf_forward(sd, x, D=8, input_ch=63, input_ch_views=27, skips=(4,)):
         h = torch.relu(h)
         if i in skips:
             h = torch.cat([pts, h], -1)
+    if 'output_linear.weight' in sd:   # use_viewdirs=False (model.py:35-36, 60-61): [.., output_ch] straight from the trunk
+        return torch.nn.functional.linear(h, sd['output_linear.weight'], sd['output_linear.bias'])
     alpha = torch.nn.functional.linear(h, sd['alpha_linear.weight'], sd['alpha_linear.bias'])
     feat = torch.nn.functional.linear(h, sd['feature_linear.weight'], sd['feature_linear.bias'])
     h = torch.cat([feat, views], -1)
@@ -171,6 +173,9 @@ def run_network(sd, pts, viewdirs, multires=10, multires_views=4):
     change results and is not restated."""
     flat = pts.reshape(-1, 3)
     emb = posenc(flat, multires)
+    if viewdirs is None:               # run_nerf.py:55-59: no direction encoding without use_viewdirs
+        out = nerf_forward(sd, emb, input_ch=posenc_dim(multires), input_ch_views=0)
+        return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
     dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)
     emb = torch.cat([emb, posenc(dirs, multires_views)], -1)
     out = nerf_forward(sd, emb, input_ch=posenc_dim(multires), input_ch_views=posenc_dim(multires_views))
@@ -248,7 +253,7 @@ def render_rays(ray_batch, sd_coarse, sd_fine, N_samples, N_importance=0, lindis
     injected: t_rand [N,Sc] (None <=> perturb==0), u [N,Ni] (None <=> det),
     noise0/noise1 = scaled sigma noise for the coarse / fine pass."""
     rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
-    viewdirs = ray_batch[:, -3:]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None   # render.py:218
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
     z = coarse_z(near, far, N_samples, lindisp, t_rand)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
@@ -276,8 +281,8 @@ def render_rays(ray_batch, sd_coarse, sd_fine, N_samples, N_importance=0, lindis
     return ret
 
 
-def make_ray_batch(rays_o, rays_d, near, far, H=None, W=None, focal=None, ndc=False):
-    """Pack [N,11] = o(3) d(3) near far viewdir(3) (render.py:59-80).
+def make_ray_batch(rays_o, rays_d, near, far, H=None, W=None, focal=None, ndc=False, use_viewdirs=True):
+    """Pack [N,11] = o(3) d(3) near far viewdir(3) (render.py:59-80); [N,8] without view directions.
     viewdirs are normalised BEFORE the ndc warp."""
     viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     if ndc:
@@ -286,6 +291,8 @@ def make_ray_batch(rays_o, rays_d, near, far, H=None, W=None, focal=None, ndc=Fa
     rays_d = rays_d.reshape(-1, 3).float()
     nr = near * torch.ones_like(rays_d[..., :1])
     fr = far * torch.ones_like(rays_d[..., :1])
+    if not use_viewdirs:
+        return torch.cat([rays_o, rays_d, nr, fr], -1)
     return torch.cat([rays_o, rays_d, nr, fr, viewdirs.reshape(-1, 3).float()], -1)
 
 

@@ -142,6 +142,21 @@ def test_raw2outputs_noise_and_small(fn, golden_dir):
         ok, e = close(out[3], r[3], 2e-6, 2e-6); assert ok, (S, e)
         dr = fn.ops.raw2outputs_bwd(raw.detach().cuda(), z.cuda(), rays11, cot.cuda(), None, True)
         ok, e = close(dr, gr, 2e-6, 1e-4); assert ok, (S, e)
+    # rays that hit nothing (every sigma <= 0): acc = depth = 0 exactly, the white background shows, and the disparity is
+    # 1 / max(1e-10, 0 / 0) = NaN in the reference because torch.max propagates NaN (render.py:186) -- not 1e10
+    raw = torch.randn(5, 12, 4, generator=gen)
+    raw[1, :, 3] = -raw[1, :, 3].abs() - 0.1
+    raw[3, :, 3] = 0.0
+    z = torch.sort(torch.rand(5, 12, generator=gen) * 4 + 2, -1).values
+    rd = torch.randn(5, 3, generator=gen)
+    r = O.raw2outputs(raw, z, rd, None, True)
+    rays11 = torch.zeros(5, 11).cuda(); rays11[:, 3:6] = rd.cuda()
+    out = fn.ops.raw2outputs_fwd(raw.cuda(), z.cuda(), rays11, None, True)
+    want_nan = torch.isnan(r[1])
+    assert want_nan.tolist() == [False, True, False, True, False]
+    assert torch.equal(torch.isnan(out[1]).cpu(), want_nan)
+    assert float((out[1].cpu()[~want_nan] - r[1][~want_nan]).abs().max()) < 1e-5 * float(r[1][~want_nan].abs().max())
+    assert torch.equal(out[2].cpu()[want_nan], torch.zeros(2)) and torch.equal(out[0].cpu()[want_nan], torch.ones(2, 3))
 
 
 def test_sample_pdf_g6(fn, golden_dir):

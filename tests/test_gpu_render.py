@@ -335,3 +335,92 @@ def test_config1_coarse_only_step(fn, golden_dir, math_mode):
         # Adam's first steps move every weight by ~lr whatever the gradient's size: entries whose gradient is rounding noise
         # may differ by O(lr); the bulk must agree
         assert float((d > 2e-5).float().mean()) < 0.02, float((d > 2e-5).float().mean())
+
+
+def test_no_view_directions_g19(fn, golden_dir, math_mode):
+    """use_viewdirs=False end to end on the product surface (create_nerf -> render -> loss.backward() -> fused Trainer):
+    reference state_dict names / order, [N,8] ray batches, G19's renders, loss and gradients; the fused step's gradients are
+    the autograd route's, and the oracle evaluated at the device's own sample depths pins every tensor."""
+    from conftest import noview_state_dicts
+    g = np.load(os.path.join(golden_dir, 'g19_noview.npz'))
+    args = fn.run_nerf.make_args(N_importance=32, N_samples=32, perturb=1.0, white_bkgd=True, use_viewdirs=False,
+                                 no_reload=True, lrate=5e-4, lrate_decay=500)
+    ktr, kte, _, _, grad_vars, optim = fn.run_nerf.create_nerf(args)
+    sds = noview_state_dicts(golden_dir)
+    for key, sd in zip(('network_fn', 'network_fine'), sds):
+        net = ktr[key]
+        assert list(net.state_dict().keys()) == list(sd.keys())
+        assert [tuple(v.shape) for v in net.state_dict().values()] == [v.shape for v in sd.values()]
+        net.load_state_dict({'module.' + k: torch.from_numpy(v) for k, v in sd.items()})   # a DataParallel-style checkpoint
+    K = g['K']
+    H = fn.run_nerf_helpers
+    rays = torch.stack([torch.from_numpy(g['ro']), torch.from_numpy(g['rd'])], 0).cuda()
+    tgt = torch.from_numpy(g['target']).cuda()
+
+    def close(got, want, tol, what):
+        got = got.detach().cpu().numpy()
+        nan = np.isnan(want)               # disp of a ray that hits nothing: 0 / 0 on both sides (render.py:186)
+        assert np.array_equal(np.isnan(got), nan), what
+        assert np.abs(got[~nan] - want[~nan]).max() < tol, (what, np.abs(got[~nan] - want[~nan]).max())
+
+    with torch.no_grad():
+        rgb, disp, acc, ex = fn.render.render(800, 800, K, chunk=32768, rays=rays, near=2.0, far=6.0, **kte)
+    close(rgb, g['test_rgb'], TOL_RGB, 'test rgb'); close(acc, g['test_acc'], TOL_RGB, 'test acc')
+    close(disp, g['test_disp'], 5e-3 * np.nanmax(np.abs(g['test_disp'])), 'test disp')
+    # train mode through the reference's pytest hook; loss.backward() as the reference's loop does
+    rgb, disp, acc, ex = fn.render.render(800, 800, K, chunk=32768, rays=rays, retraw=True, near=2.0, far=6.0, pytest=True, **ktr)
+    close(rgb, g['rgb'], TOL_RGB, 'rgb'); close(ex['rgb0'], g['rgb0'], TOL_RGB, 'rgb0')
+    close(acc, g['acc'], TOL_RGB, 'acc'); close(ex['acc0'], g['acc0'], TOL_RGB, 'acc0')
+    assert ex['raw'].shape == (64, 64, 4)      # the reference's fifth channel is never read (render.py:169-171)
+    close(ex['raw'], g['raw'][..., :4], 5e-2 * np.abs(g['raw'][..., :4]).max(), 'raw')
+    optim.zero_grad()
+    l1, l0 = H.img2mse(rgb, tgt), H.img2mse(ex['rgb0'], tgt)
+    (l1 + l0).backward()
+    assert abs(float(l1.detach()) - float(g['loss'])) < 1e-5 and abs(float(l0.detach()) - float(g['loss0'])) < 1e-5
+    names = [pre + k for pre, sd in zip(('c.', 'f.'), sds) for k in sd.keys()]
+    assert len(names) == len(grad_vars)
+    ag = {}
+    for n, p in zip(names, grad_vars):
+        ag[n] = p.grad.detach().clone()
+        if 'views_linears' in n:
+            assert float(p.grad.abs().max()) == 0.0            # unused by this model (None in the reference)
+        elif 'grad.' + n in g.files:
+            ref = g['grad.' + n]
+            assert np.abs(ag[n].cpu().numpy() - ref).max() < 3e-2 * max(np.abs(ref).max(), 1e-6), n
+    assert float(ag['c.output_linear.weight'][4].abs().max()) == 0.0 and float(ag['c.output_linear.weight'][3].abs().max()) > 0.0
+    # fused Trainer on the same batch and draws: the same gradients
+    np.random.seed(0); t_rand = torch.from_numpy(np.random.rand(64, 32).astype(np.float32)).cuda()
+    np.random.seed(0); u = torch.from_numpy(np.random.rand(64, 32).astype(np.float32)).cuda()
+    assert np.array_equal(t_rand.cpu().numpy(), g['t_rand'])
+    tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+    loss2, out = tr.forward_backward(rays[0], rays[1], tgt, t_rand=t_rand, u=u)
+    assert abs(float(loss2[0]) - float(g['loss'])) < 1e-5 and abs(float(loss2[1]) - float(g['loss0'])) < 1e-5
+    offs = np.cumsum([0] + [p.numel() for p in grad_vars[:-1]])      # parameters() order == the flat buffers' order
+    assert int(offs[-1]) + grad_vars[-1].numel() == tr.grad.numel() == tr.flat.numel()
+    fused = {n: tr.grad[o:o + p.numel()].view(p.shape).clone() for n, p, o in zip(names, grad_vars, offs)}
+    for n in names:
+        assert (fused[n] - ag[n]).abs().max() <= 1e-5 * max(float(ag[n].abs().max()), 1e-8), n
+    # oracle autograd at the device's own depths: every used tensor within 2e-3 relative L2
+    rb = O.make_ray_batch(rays[0].cpu(), rays[1].cpu(), 2.0, 6.0, use_viewdirs=False)
+    for pre, sd_np, zkey in (('c.', sds[0], 'z0'), ('f.', sds[1], 'z_vals')):
+        sd = {k: torch.from_numpy(v).clone() for k, v in sd_np.items()}
+        used = [k for k in sd if not k.startswith('views_linears.')]
+        for k in used:
+            sd[k].requires_grad_(True)
+        zz = out[zkey].cpu()
+        pts = rb[:, None, 0:3] + rb[:, None, 3:6] * zz[..., None]
+        rgbm = O.raw2outputs(O.run_network(sd, pts, None), zz, rb[:, 3:6], None, True)[0]
+        gr = torch.autograd.grad(O.img2mse(rgbm, tgt.cpu()), [sd[k] for k in used])
+        for k, gg in zip(used, gr):
+            got = fused[pre + k].cpu()
+            assert (got - gg).norm() < 2e-3 * gg.norm() + 1e-12, (pre + k, float((got - gg).norm() / (gg.norm() + 1e-12)))
+    # one fused optimisation step moves the reference's parameters (and only the used ones)
+    before = tr.flat.clone()
+    tr.step(rays[0], rays[1], tgt, t_rand=t_rand, u=u)
+    moved = {n: float((p.detach() - before[o:o + p.numel()].view(p.shape)).abs().max()) for n, p, o in zip(names, grad_vars, offs)}
+    assert moved['c.views_linears.0.weight'] == 0.0 and 0.0 < moved['c.output_linear.weight'] <= 5e-4 * 1.001
+    assert moved['f.pts_linears.3.weight'] > 0.0
+    # the kernels' network follows the parameters: a fresh render uses the updated weights
+    with torch.no_grad():
+        rgb2 = fn.render.render(800, 800, K, chunk=32768, rays=rays, near=2.0, far=6.0, **kte)[0]
+    assert float((rgb2.cpu() - torch.from_numpy(g['test_rgb'])).abs().max()) > 1e-4

@@ -184,3 +184,43 @@ def test_compute_ssim_g13(golden_dir):
     assert np.allclose(H.compute_ssim(c, d).numpy(), g['ssim_cd'], rtol=0, atol=2e-6)
     assert np.allclose(H.compute_ssim(c, d, max_val=2.0, filter_size=7, filter_sigma=1.0, k1=0.02, k2=0.05).numpy(),
                        g['ssim_cd_k'], rtol=0, atol=2e-6)
+
+
+def test_g19_no_view_directions(golden_dir):
+    """use_viewdirs=False (model.py:35-36,60-61; render.py:218): [N,8] ray batches, `output_linear` 256 -> 5, raw with five
+    channels of which compositing reads four."""
+    from conftest import noview_state_dicts
+    g = L(golden_dir, 'g19_noview.npz')
+    sdc, sdf = [{k: torch.from_numpy(v).clone() for k, v in sd.items()} for sd in noview_state_dicts(golden_dir)]
+    assert tuple(sdc['views_linears.0.weight'].shape) == (128, 256) and tuple(sdc['output_linear.weight'].shape) == (5, 256)
+    rb = O.make_ray_batch(torch.from_numpy(g['ro']), torch.from_numpy(g['rd']), 2.0, 6.0, use_viewdirs=False)
+    assert rb.shape[1] == 8
+    used = [k for k in sdc if not k.startswith('views_linears.')]
+    ps = [sdc[k] for k in used] + [sdf[k] for k in used]
+    for q in ps:
+        q.requires_grad_(True)
+    ret = O.render_rays(rb, sdc, sdf, 32, 32, False, True, torch.from_numpy(g['t_rand']), torch.from_numpy(g['u']), retraw=True)
+    tgt = torch.from_numpy(g['target'])
+    l1, l0 = O.img2mse(ret['rgb_map'], tgt), O.img2mse(ret['rgb0'], tgt)
+    gr = torch.autograd.grad(l1 + l0, ps)
+    assert ret['raw'].shape == (64, 64, 5)
+    for k, ref in (('rgb_map', 'rgb'), ('disp_map', 'disp'), ('acc_map', 'acc'), ('raw', 'raw'), ('rgb0', 'rgb0'),
+                   ('disp0', 'disp0'), ('acc0', 'acc0'), ('z_std', 'z_std')):
+        got, want = ret[k].detach().numpy(), g[ref]
+        nan = np.isnan(want)               # disp of a ray that hits nothing is 0 / 0 in the reference too (render.py:186)
+        assert np.array_equal(np.isnan(got), nan), k
+        assert np.abs(got[~nan] - want[~nan]).max() < 2e-5 * max(1.0, np.abs(want[~nan]).max()), k
+    assert abs(float(l1) - float(g['loss'])) < 1e-6 and abs(float(l0) - float(g['loss0'])) < 1e-6
+    n_checked = 0
+    for (pre, k), gg in zip([('c.', k) for k in used] + [('f.', k) for k in used], gr):
+        key = 'grad.' + pre + k
+        if key in g.files:
+            scale = max(np.abs(g[key]).max(), 1e-8)
+            assert np.abs(gg.numpy() - g[key]).max() < 2e-4 * scale, (key, np.abs(gg.numpy() - g[key]).max() / scale)
+            n_checked += 1
+    assert n_checked == 2 * (8 + 1 + 1 + 2)    # biases of 8 trunk layers + output bias, output weight, trunk 0 / 7 weights
+    for q in ps:
+        q.requires_grad_(False)
+    rt = O.render_rays(rb, sdc, sdf, 32, 32, False, True, None, None)
+    assert np.abs(rt['rgb_map'].numpy() - g['test_rgb']).max() < 2e-5
+    assert np.abs(rt['acc_map'].numpy() - g['test_acc']).max() < 2e-5
