@@ -18,6 +18,11 @@ extern "C" int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples,
     fn::set_error("fastnerf_render_rays_fwd: bad argument: math_mode in {0,1}, n>=0, N_samples>=2, N_importance>=0");
     return -1;
   }
+  if (N_importance > 0 && N_samples < 3) {
+    // the reference fails here too: weights[..., 1:-1] is empty and sample_pdf indexes an empty cdf (run_nerf_helpers.py:147)
+    fn::set_error("fastnerf_render_rays_fwd: hierarchical sampling needs N_samples >= 3 (the inner weights of 2 samples are empty)");
+    return -1;
+  }
   if (n == 0) return 0;
   if (!rays11 || !params_c || !packed_c || !z0 || !raw0 || !rgb0 || !disp0 || !acc0 || !w0 || !depth0) {
     fn::set_error("fastnerf_render_rays_fwd: null pointer (coarse pass)");

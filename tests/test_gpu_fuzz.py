@@ -1,0 +1,116 @@
+"""Randomised end-to-end configurations of render_rays on the HIP path against the oracle (which oracle/fuzz_vs_reference.py
+holds bit-identical to the reference over the same configuration space): odd sample counts, one importance sample, lindisp,
+black / white background, sigma noise, NDC rays, no view directions, one shared net for both passes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def fn():
+    import fastnerf
+    return fastnerf
+
+
+def _configs():
+    rng = np.random.RandomState(3)
+    out = []
+    for ci in range(14):
+        use_viewdirs = bool(rng.rand() < 0.7)
+        Ns = int(rng.choice([2, 3, 8, 17, 32, 64, 65]))
+        Ni = int(rng.choice([0, 1, 5, 16, 33, 64, 127])) if Ns >= 3 else 0
+        ndc = bool(rng.rand() < 0.3)
+        lindisp = bool(rng.rand() < 0.4) and not ndc
+        out.append(dict(ci=ci, use_viewdirs=use_viewdirs, Ns=Ns, Ni=Ni, ndc=ndc, lindisp=lindisp, white=bool(rng.rand() < 0.5),
+                        perturb=float(rng.choice([0.0, 1.0])), noise=float(rng.choice([0.0, 0.0, 1.0])),
+                        shared=bool(Ni > 0 and rng.rand() < 0.25)))
+    return out
+
+
+@pytest.mark.parametrize('cfg', _configs(), ids=lambda c: 'v{use_viewdirs:d}-{Ns}+{Ni}-ndc{ndc:d}-lin{lindisp:d}-sh{shared:d}'.format(**c))
+def test_random_configuration(fn, golden_dir, math_mode, cfg):
+    from conftest import noview_state_dicts
+    n = 40
+    gen = torch.Generator().manual_seed(50 + cfg['ci'])
+    args = fn.run_nerf.make_args(N_importance=cfg['Ni'], N_samples=cfg['Ns'], perturb=cfg['perturb'], white_bkgd=cfg['white'],
+                                 use_viewdirs=cfg['use_viewdirs'], no_reload=True, raw_noise_std=cfg['noise'], lindisp=cfg['lindisp'])
+    ktr = fn.run_nerf.create_nerf(args)[0]
+    wts = np.load(os.path.join(golden_dir, 'g7_weights.npz'))
+    if cfg['use_viewdirs']:
+        sds = [{k[2:]: wts[k] for k in wts.files if k.startswith(pre)} for pre in ('c.', 'f.')]
+    else:
+        sds = noview_state_dicts(golden_dir)
+        if cfg['Ni'] == 0:   # output_ch = 4 without a fine pass
+            sds = [{k: (v[:4] if k.startswith('output_linear') else v) for k, v in sd.items()} for sd in sds]
+    net_c, net_f = ktr['network_fn'], ktr['network_fine']
+    net_c.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sds[0].items()})
+    if net_f is not None:
+        net_f.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sds[1].items()})
+    if cfg['shared']:
+        net_f = None
+    if cfg['ndc']:
+        Hh, Ww, focal, near, far = 378, 504, 400.0, 0.0, 1.0
+        ro = torch.rand(n, 3, generator=gen) * 0.2 - 0.1
+        rd = torch.cat([(torch.rand(n, 2, generator=gen) - 0.5) * 0.8, -torch.ones(n, 1)], -1)
+    else:
+        Hh, Ww, focal, near, far = 800, 800, 1111.1, 2.0, 6.0
+        g8 = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+        ro, rd = torch.from_numpy(g8['ro'][:n]), torch.from_numpy(g8['rd'][:n])
+    tgt = torch.rand(n, 3, generator=gen)
+    Ns, Ni = cfg['Ns'], cfg['Ni']
+    t_rand = torch.rand(n, Ns, generator=gen) if cfg['perturb'] > 0 else None
+    u = torch.rand(n, Ni, generator=gen) if (cfg['perturb'] > 0 and Ni > 0) else None
+    n0 = torch.randn(n, Ns, generator=gen) * cfg['noise'] if cfg['noise'] > 0 else None
+    n1 = torch.randn(n, Ns + Ni, generator=gen) * cfg['noise'] if (cfg['noise'] > 0 and Ni > 0) else None
+    C = lambda t: None if t is None else t.cuda()
+    rays11 = fn.ops.pack_rays(ro.cuda(), rd.cuda(), near, far, ndc=cfg['ndc'], H=Hh, W=Ww, focal=focal)
+    if not cfg['use_viewdirs']:
+        rays11[:, 8:11] = 0.
+    out, saved = fn.render._forward_core(rays11, net_c, net_f, Ns, Ni, cfg['lindisp'], cfg['perturb'], cfg['white'], C(t_rand), C(u),
+                                         C(n0), C(n1), save=True)
+    # ---- forward vs the oracle on the same draws ----
+    sd_t = [{k: torch.from_numpy(np.ascontiguousarray(v)).clone() for k, v in sd.items()} for sd in sds]
+    rb = O.make_ray_batch(ro, rd, near, far, Hh, Ww, focal, ndc=cfg['ndc'], use_viewdirs=cfg['use_viewdirs'])
+    ref = O.render_rays(rb, sd_t[0], None if (cfg['shared'] or Ni == 0) else sd_t[1], Ns, Ni, cfg['lindisp'], cfg['white'], t_rand, u,
+                        n0, n1)
+    keys = [('rgb_map', 'rgb_map'), ('acc_map', 'acc_map')] + ([('rgb0', 'rgb0'), ('acc0', 'acc0')] if Ni > 0 else [])
+    for a, b in keys:
+        assert (out[a].cpu() - ref[b]).abs().max() < 1e-4, (a, float((out[a].cpu() - ref[b]).abs().max()))
+    assert torch.equal(torch.isnan(out['disp_map']).cpu(), torch.isnan(ref['disp_map']))
+    # ---- backward vs the oracle's autograd at the device's own depths ----
+    grads_c = torch.zeros_like(net_c.flat)
+    grads_f = torch.zeros_like(net_c.flat) if (net_f is not None and Ni > 0) else None
+    loss2, g1, g0 = fn.ops.mse_leafmax(out['rgb_map'], out.get('rgb0'), tgt.cuda())
+    fn.render._backward_core(saved, g1, g0, out_c=grads_c, out_f=grads_f)
+    passes = [('z0', 'c', 0, n0)] if Ni == 0 else [('z0', 'c', 0, n0), ('z_vals', 'c' if cfg['shared'] else 'f', 0 if cfg['shared'] else 1, n1)]
+    want = {}
+    for sd in sd_t:
+        for k, v in sd.items():
+            if not k.startswith('views_linears.') or cfg['use_viewdirs']:
+                v.requires_grad_(True)
+    total = {0: 0., 1: 0.}
+    for zkey, _, which, nz in passes:
+        zz = out[zkey].cpu()
+        pts = rb[:, None, 0:3] + rb[:, None, 3:6] * zz[..., None]
+        raw = O.run_network(sd_t[which], pts, rb[:, 8:11] if cfg['use_viewdirs'] else None)
+        total[which] = total[which] + O.img2mse(O.raw2outputs(raw, zz, rb[:, 3:6], nz, cfg['white'])[0], tgt)
+    bound = 2e-3 if math_mode == 'fp32' else 1e-2
+    for which, (net, got_flat) in enumerate(((net_c, grads_c), (net_f, grads_f))):
+        if got_flat is None or not torch.is_tensor(total[which]):
+            continue
+        used = [k for k, v in sd_t[which].items() if v.requires_grad]
+        gr = dict(zip(used, torch.autograd.grad(total[which], [sd_t[which][k] for k in used], allow_unused=True)))
+        got = dict(zip([nm for nm, _ in net.named_parameters()], net.param_grads_from(got_flat)))
+        num = den = 0.0
+        for k in used:
+            if gr[k] is None:
+                continue
+            gg = gr[k][:got[k].shape[0]] if k.startswith('output_linear') else gr[k]
+            num += float((got[k].cpu() - gg).pow(2).sum()); den += float(gg.pow(2).sum())
+        assert den > 0 and (num / den) ** 0.5 < bound, (which, (num / den) ** 0.5)
