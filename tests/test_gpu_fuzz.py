@@ -79,16 +79,33 @@ def test_random_configuration(fn, golden_dir, math_mode, cfg):
     rb = O.make_ray_batch(ro, rd, near, far, Hh, Ww, focal, ndc=cfg['ndc'], use_viewdirs=cfg['use_viewdirs'])
     ref = O.render_rays(rb, sd_t[0], None if (cfg['shared'] or Ni == 0) else sd_t[1], Ns, Ni, cfg['lindisp'], cfg['white'], t_rand, u,
                         n0, n1)
-    keys = [('rgb_map', 'rgb_map'), ('acc_map', 'acc_map')] + ([('rgb0', 'rgb0'), ('acc0', 'acc0')] if Ni > 0 else [])
-    for a, b in keys:
-        assert (out[a].cpu() - ref[b]).abs().max() < 1e-4, (a, float((out[a].cpu() - ref[b]).abs().max()))
-    assert torch.equal(torch.isnan(out['disp_map']).cpu(), torch.isnan(ref['disp_map']))
+    # the coarse pass sees the same depths on both sides (injected jitter): direct comparison
+    for a in (('rgb0', 'acc0') if Ni > 0 else ('rgb_map', 'acc_map')):
+        assert (out[a].cpu() - ref[a]).abs().max() < 1e-4, (a, float((out[a].cpu() - ref[a]).abs().max()))
+    if Ni > 0:
+        # the fine depths come out of the inverse CDF, which is discontinuous where u meets a cdf value: a 1-ulp difference in
+        # the running sums moves such a sample to the neighbouring bin (with 8 coarse samples that is 2e-4 of colour; found
+        # by this test).  So: nearly all depths agree, every one stays inside the coarse range, and the colours are compared
+        # with the oracle evaluated AT the device's depths.
+        dz = (out['z_vals'].cpu() - ref['z_vals']).abs()
+        assert float((dz > 2e-5 * max(1.0, far)).float().mean()) < 0.03, float((dz > 2e-5).float().mean())
+        zc = out['z0'].cpu()
+        assert bool((out['z_vals'].cpu() >= zc[:, :1] - 1e-6).all()) and bool((out['z_vals'].cpu() <= zc[:, -1:] + 1e-6).all())
+        zz = out['z_vals'].cpu()
+        pts = rb[:, None, 0:3] + rb[:, None, 3:6] * zz[..., None]
+        sdx = sd_t[0] if (cfg['shared']) else sd_t[1]
+        raw = O.run_network(sdx, pts, rb[:, 8:11] if cfg['use_viewdirs'] else None)
+        rgbm, dispm, accm = O.raw2outputs(raw, zz, rb[:, 3:6], n1, cfg['white'])[:3]
+        assert (out['rgb_map'].cpu() - rgbm).abs().max() < 1e-4 and (out['acc_map'].cpu() - accm).abs().max() < 1e-4
+        assert torch.equal(torch.isnan(out['disp_map']).cpu(), torch.isnan(dispm))
+    else:
+        assert torch.equal(torch.isnan(out['disp_map']).cpu(), torch.isnan(ref['disp_map']))
     # ---- backward vs the oracle's autograd at the device's own depths ----
     grads_c = torch.zeros_like(net_c.flat)
     grads_f = torch.zeros_like(net_c.flat) if (net_f is not None and Ni > 0) else None
     loss2, g1, g0 = fn.ops.mse_leafmax(out['rgb_map'], out.get('rgb0'), tgt.cuda())
     fn.render._backward_core(saved, g1, g0, out_c=grads_c, out_f=grads_f)
-    passes = [('z0', 'c', 0, n0)] if Ni == 0 else [('z0', 'c', 0, n0), ('z_vals', 'c' if cfg['shared'] else 'f', 0 if cfg['shared'] else 1, n1)]
+    passes = [('z_vals', 'c', 0, n0)] if Ni == 0 else [('z0', 'c', 0, n0), ('z_vals', 'c' if cfg['shared'] else 'f', 0 if cfg['shared'] else 1, n1)]
     want = {}
     for sd in sd_t:
         for k, v in sd.items():
@@ -113,4 +130,7 @@ def test_random_configuration(fn, golden_dir, math_mode, cfg):
                 continue
             gg = gr[k][:got[k].shape[0]] if k.startswith('output_linear') else gr[k]
             num += float((got[k].cpu() - gg).pow(2).sum()); den += float(gg.pow(2).sum())
-        assert den > 0 and (num / den) ** 0.5 < bound, (which, (num / den) ** 0.5)
+        if den == 0.0:      # every sample of every ray dead (sigma <= 0): no gradient at all, on both sides
+            assert num == 0.0, (which, num)
+        else:
+            assert (num / den) ** 0.5 < bound, (which, (num / den) ** 0.5)
