@@ -134,3 +134,58 @@ def test_random_configuration(fn, golden_dir, math_mode, cfg):
             assert num == 0.0, (which, num)
         else:
             assert (num / den) ** 0.5 < bound, (which, (num / den) ** 0.5)
+
+
+@pytest.mark.parametrize('S0,S1,N', [(3, 5, 7), (8, 5, 24), (17, 33, 12), (64, 33, 5), (32, 128, 24), (65, 1, 9)])
+def test_random_cascade_nerfpp(fn, golden_dir, math_mode, S0, S1, N):
+    """nerf++ train_step batch with odd cascade sample counts against the oracle (which oracle/fuzz_pp_vs_reference.py holds
+    bit-identical to the reference's train_step): level-0 colour directly, every level's colour and gradients at the device's
+    own depths."""
+    from oracle import nerfpp_oracle as PP
+    w = np.load(os.path.join(golden_dir, 'g10_pp_weights.npz'))
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    levels = [({k[len(f'l{m}.fg_net.'):]: T(w[k]).clone() for k in w.files if k.startswith(f'l{m}.fg_net.')},
+               {k[len(f'l{m}.bg_net.'):]: T(w[k]).clone() for k in w.files if k.startswith(f'l{m}.bg_net.')}) for m in range(2)]
+    nets = []
+    for fg, bg in levels:
+        net = fn.nerfpp.NerfNetWithAutoExpo(None)
+        sd = {'fg_net.' + k: v for k, v in fg.items()}
+        sd.update({'bg_net.' + k: v for k, v in bg.items()})
+        net.nerf_net.load_state_dict(sd)
+        nets.append(net)
+    gen = torch.Generator().manual_seed(S0 * 131 + S1)
+    ro = (torch.rand(N, 3, generator=gen) - 0.5) * 0.9
+    rd = torch.randn(N, 3, generator=gen)
+    tgt = torch.rand(N, 3, generator=gen)
+    rand = [{'fg_t': torch.rand(N, S0, generator=gen), 'bg_t': torch.rand(N, S0, generator=gen)},
+            {'fg_u': torch.rand(N, S1, generator=gen), 'bg_u': torch.rand(N, S1, generator=gen)}]
+    tr = fn.nerfpp.CascadeTrainer(nets, cascade_samples=(S0, S1), lrate=5e-4)
+    losses, rgb = tr.step(ro.cuda(), rd.cuda(), tgt.cuda(), rand=[{k: v.cuda() for k, v in r.items()} for r in rand], update=False)
+    ref = PP.cascade_step(levels, ro, rd, tgt, [S0, S1], rand)
+    assert abs(float(losses[0]) - float(ref[0][0])) < 2e-5
+    fg_far = PP.intersect_sphere(ro, rd)
+    bound = 2e-3 if math_mode == 'fp32' else 1e-2
+    for m in range(2):
+        sd_fg, sd_bg = levels[m]
+        params = list(sd_fg.values()) + list(sd_bg.values())
+        for p in params:
+            p.requires_grad_(True)
+        fz, bz = (z.cpu() for z in tr.last_depths[m])
+        assert fz.shape == (N, S0 if m == 0 else S0 + S1) and bz.shape == fz.shape
+        if m == 0:
+            assert (fz - ref[0][3]).abs().max() < 2e-6 and (bz - ref[0][4]).abs().max() < 2e-6
+        ret = PP.nerfnet_forward(sd_fg, sd_bg, ro, rd, fg_far, fz, bz)
+        if m == 1:
+            assert (rgb.cpu() - ret['rgb'].detach()).abs().max() < 1e-4
+        gr = torch.autograd.grad(torch.mean((ret['rgb'] - tgt) ** 2), params)
+        for p in params:
+            p.requires_grad_(False)
+        flat_g = nets[m].nerf_net.flat_grad.cpu()
+        off, it, num, den = 0, iter(gr), 0.0, 0.0
+        for kind in (1, 2):
+            for name, o, shape in fn.nerfpp.mlpnet_slices(kind):
+                gg = next(it)
+                got = flat_g[off + o: off + o + gg.numel()].view(gg.shape)
+                num += float((got - gg).pow(2).sum()); den += float(gg.pow(2).sum())
+            off += fn.ops.net_floats(kind, 0)
+        assert (num / den) ** 0.5 < bound, (m, (num / den) ** 0.5)
