@@ -189,3 +189,34 @@ def test_random_cascade_nerfpp(fn, golden_dir, math_mode, S0, S1, N):
                 num += float((got - gg).pow(2).sum()); den += float(gg.pow(2).sum())
             off += fn.ops.net_floats(kind, 0)
         assert (num / den) ** 0.5 < bound, (m, (num / den) ** 0.5)
+
+
+def test_random_cameras_and_ndc(fn):
+    """get_rays / ndc_rays / pack_rays on random cameras and odd image sizes (off-centre principal points, anisotropic
+    focal lengths, 1 x 1 and 3 x 7 images, near planes other than 1) against the oracle."""
+    gen = torch.Generator().manual_seed(123)
+    for case in range(10):
+        H = int(torch.randint(1, 70, (1,), generator=gen)) if case else 1
+        W = int(torch.randint(1, 90, (1,), generator=gen)) if case else 1
+        fx, fy = (float(v) for v in (torch.rand(2, generator=gen) * 900 + 20))
+        cx, cy = float(torch.rand(1, generator=gen) * W), float(torch.rand(1, generator=gen) * H)
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]])
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=gen))
+        c2w = torch.cat([q, torch.randn(3, 1, generator=gen)], 1).float()
+        o_ref, d_ref = O.get_rays(H, W, K, c2w)
+        o, d = fn.run_nerf_helpers.get_rays(H, W, K, c2w.cuda())
+        assert o.shape == (H, W, 3) and torch.equal(o.cpu(), o_ref)
+        assert (d.cpu() - d_ref).abs().max() <= 2e-6 * d_ref.abs().max()
+        # NDC on forward-facing rays (d_z < 0), any near plane
+        n = 64
+        ro = torch.rand(n, 3, generator=gen) * 0.4 - 0.2
+        rd = torch.cat([torch.rand(n, 2, generator=gen) - 0.5, -torch.rand(n, 1, generator=gen) - 0.2], -1)
+        near = float(torch.rand(1, generator=gen) * 2 + 0.1)
+        no_ref, nd_ref = O.ndc_rays(H + 10, W + 10, fx, near, ro, rd)
+        no, nd = fn.run_nerf_helpers.ndc_rays(H + 10, W + 10, fx, near, ro.cuda(), rd.cuda())
+        assert (no.cpu() - no_ref).abs().max() <= 2e-6 * max(1.0, float(no_ref.abs().max()))
+        assert (nd.cpu() - nd_ref).abs().max() <= 2e-6 * max(1.0, float(nd_ref.abs().max()))
+        for ndc in (False, True):
+            rb_ref = O.make_ray_batch(ro, rd, 0.25, 3.5, H + 10, W + 10, fx, ndc=ndc)
+            rb = fn.ops.pack_rays(ro.cuda(), rd.cuda(), 0.25, 3.5, ndc=ndc, H=H + 10, W=W + 10, focal=fx)
+            assert (rb.cpu() - rb_ref).abs().max() <= 2e-6 * max(1.0, float(rb_ref.abs().max()))
