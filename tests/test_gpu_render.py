@@ -475,3 +475,22 @@ def test_shared_network_both_passes(fn, golden_dir, math_mode, lindisp, white):
     H = fn.run_nerf_helpers
     (H.img2mse(ret['rgb_map'], tgt) + H.img2mse(ret['rgb0'], tgt)).backward()
     assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in net.parameters())
+
+
+def test_full_chunk_equals_small_chunks(fn, golden_dir, math_mode):
+    """render()'s default chunk (32 768 rays = 6.3 M fine-pass points = 98 304 tiles in one launch, the size render_path and the
+    bench's inference leg use) gives bit for bit what eight launches of 4096 rays give."""
+    _, kte, _, _ = build(fn, golden_dir)
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    gen = torch.Generator().manual_seed(77)
+    n = 32768
+    poses = torch.stack([fn.synthetic.pose_spherical(-180.0 + 36.0 * k, -30.0, 4.0)[:3, :4] for k in range(10)], 0).cuda()
+    pix = torch.stack([torch.randint(0, 10, (n,), generator=gen), torch.randint(0, 800, (n,), generator=gen),
+                       torch.randint(0, 800, (n,), generator=gen)], 1).int().cuda()
+    ro, rd = fn.ops.gen_rays_pixels(pix, poses, K)
+    with torch.no_grad():
+        big = fn.render.render(800, 800, K, chunk=n, rays=(ro, rd), near=2.0, far=6.0, **kte)
+        small = fn.render.render(800, 800, K, chunk=4096, rays=(ro, rd), near=2.0, far=6.0, **kte)
+    for a, b in zip(big[:3], small[:3]):
+        assert a.shape[0] == n and torch.equal(a, b)
+    assert torch.equal(big[3]['z_std'], small[3]['z_std']) and torch.isfinite(big[0]).all()
