@@ -494,3 +494,39 @@ def test_full_chunk_equals_small_chunks(fn, golden_dir, math_mode):
     for a, b in zip(big[:3], small[:3]):
         assert a.shape[0] == n and torch.equal(a, b)
     assert torch.equal(big[3]['z_std'], small[3]['z_std']) and torch.isfinite(big[0]).all()
+
+
+def test_batch_beyond_int32_offsets(fn, golden_dir, math_mode):
+    """8192 rays per step: the fine pass saves 1 572 864 points x 2528 floats = 3.98e9 elements, past 2^31 (the bench's 4096
+    rays stay just below).  Its gradient must be the sum of the gradients of the two halves (each scaled for the global
+    batch), and its colours the halves' colours bit for bit."""
+    ktr, _, _, _ = build(fn, golden_dir)
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    gen = torch.Generator().manual_seed(31)
+    n = 8192
+    poses = torch.stack([fn.synthetic.pose_spherical(-180.0 + 36.0 * k, -30.0, 4.0)[:3, :4] for k in range(10)], 0).cuda()
+    pix = torch.stack([torch.randint(0, 10, (n,), generator=gen), torch.randint(0, 800, (n,), generator=gen),
+                       torch.randint(0, 800, (n,), generator=gen)], 1).int().cuda()
+    ro, rd = fn.ops.gen_rays_pixels(pix, poses, K)
+    tgt = torch.rand(n, 3, generator=gen).cuda()
+    t_rand, u = torch.rand(n, 64, generator=gen).cuda(), torch.rand(n, 128, generator=gen).cuda()
+    old = fn.render.get_compact()
+    try:
+        for mode in ('0', '1'):       # plain backward (saves every point) and compacted backward
+            fn.render.set_compact(mode)
+            tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0)
+            loss_full, out_full = tr.forward_backward(ro, rd, tgt, t_rand=t_rand, u=u)
+            g_full = tr.grad.clone()
+            rgb_full = out_full['rgb_map'].clone()
+            g_sum = torch.zeros_like(g_full)
+            for h in range(2):
+                sl = slice(h * 4096, (h + 1) * 4096)
+                _, out_h = tr.forward_backward(ro[sl].contiguous(), rd[sl].contiguous(), tgt[sl].contiguous(),
+                                               t_rand=t_rand[sl].contiguous(), u=u[sl].contiguous(), n_global=n)
+                g_sum += tr.grad
+                assert torch.equal(out_h['rgb_map'], rgb_full[sl]), (mode, h)
+            rel = float((g_full - g_sum).norm() / g_sum.norm())
+            assert torch.isfinite(g_full).all() and rel < 2e-5, (mode, rel)
+            del tr, out_full
+    finally:
+        fn.render.set_compact(old)
