@@ -1,0 +1,32 @@
+#!/bin/bash
+# (build container only: needs /root/reference)  Regenerate EVERY fixture of tests/golden/ from the reference into a scratch
+# directory and compare with the committed files: arrays bit for bit (npz members), other files byte for byte.
+set -e
+cd "$(dirname "$0")/.."
+D=$(mktemp -d /tmp/goldens.XXXXXX)
+export FASTNERF_GOLDEN_OUT="$D"
+for g in make_golden make_golden_pp make_golden_pp_render make_golden_ssim make_golden_loaders make_golden_treepkl \
+         make_golden_pp_loader make_golden_render_path make_golden_noview; do
+  python oracle/$g.py > "$D/$g.log" 2>&1 || { echo "FAILED $g (see $D/$g.log)"; exit 1; }
+done
+python - "$D" <<'PY'
+import os, sys
+import numpy as np
+new, old = sys.argv[1], 'tests/golden'
+bad = 0
+names = sorted(f for f in os.listdir(old) if not f.startswith('.'))
+for f in names:
+    a, b = os.path.join(old, f), os.path.join(new, f)
+    if not os.path.exists(b):
+        print('NOT REGENERATED', f); bad += 1; continue
+    if f.endswith('.npz'):
+        x, y = np.load(a, allow_pickle=False), np.load(b, allow_pickle=False)
+        same = sorted(x.files) == sorted(y.files) and all(
+            x[k].dtype == y[k].dtype and x[k].shape == y[k].shape and x[k].tobytes() == y[k].tobytes() for k in x.files)
+    else:
+        same = open(a, 'rb').read() == open(b, 'rb').read()
+    print('ok ' if same else 'DIFFERS', f)
+    bad += not same
+print(f'{len(names) - bad} of {len(names)} fixtures reproduce bit for bit')
+sys.exit(1 if bad else 0)
+PY

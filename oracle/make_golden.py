@@ -17,7 +17,10 @@ import numpy as np
 import torch
 
 REF = '/root/reference/nerf-ours'
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')   # the committed fixtures
+# FASTNERF_GOLDEN_OUT=<dir> writes somewhere else (oracle/check_goldens.sh regenerates everything there and compares);
+# generators that build on an earlier fixture (g7_weights.npz) read it from the same directory, so run make_golden.py first
+OUT = os.environ.get('FASTNERF_GOLDEN_OUT', GOLDEN)
 
 
 def install_stubs():
