@@ -599,6 +599,11 @@ class QuadTreeManager:
         self.result_leaf_tag = self._tags_i32.to(self.device).contiguous()
         return self.gather(pix)
 
+    def gen_rays_v3_1(self, down_scale=16, debug=False, last_epoch=False):
+        """tree.py:309-375: the single-thread twin of gen_rays_v3_multiThread(prob=False) -- the same draws in the same order
+        (oracle/fuzz_tree_vs_reference.py checks both against the reference)."""
+        return self.gen_rays_v3_multiThread(down_scale, prob=False, debug=debug, last_epoch=last_epoch, compat_rng=True)
+
     # ---- adjustment -----------------------------------------------------------------------------
     def adjust_tree_from_table(self, table, thres=0.001):
         """Split rule of tree.py:629-652 driven by the reduced per-(image, leaf) table.
@@ -626,6 +631,18 @@ class QuadTreeManager:
         self._version += 1
         self.cur_level += 1
         return int(tot)
+
+    def adjust_tree(self, rgb_gt, rgb_pred, thres=0.01, debug=False):
+        """tree.py:493-531: the older single-thread adjustment.  It splits a bottom-level leaf when the MEAN absolute error of
+        its rays exceeds `thres` (the multiThread version the driver calls uses the max); the reduction runs on the device."""
+        dev = self.device
+        gt = torch.as_tensor(rgb_gt, dtype=torch.float32).to(dev).contiguous()
+        pred = torch.as_tensor(rgb_pred, dtype=torch.float32).to(dev).contiguous()
+        ml = self.max_leaves()
+        sums = torch.zeros(self.n_images * ml, device=dev, dtype=torch.float64)
+        counts = torch.zeros(self.n_images * ml, device=dev, dtype=torch.int32)
+        ops.leaf_sumcount(pred, gt, self.result_leaf_tag, ml, sums, counts)
+        return self.adjust_tree_from_sumcount(sums, counts, thres)
 
     def adjust_tree_multiThread(self, rgb_gt, rgb_pred, thres=0.001, debug=False):
         """tree.py:533-557 with the reference's arguments: the epoch's gt / predicted colours in

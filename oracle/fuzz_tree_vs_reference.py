@@ -76,6 +76,25 @@ def main():
                 break
             pred = torch.clamp(rgbt + (torch.rand(rgbt.shape, generator=g) - 0.5) * 0.3 *
                                (torch.rand(rgbt.shape[0], 1, generator=g) < 0.05).float(), 0, 1)
+            if ci % 4 == 3:
+                # the older single-thread pair gen_rays_v3_1 / adjust_tree (mean rule): v3_1 must draw what multiThread drew,
+                # and the mean-rule split must match the product's sum / count path
+                st = torch.get_rng_state()
+                torch.manual_seed(1000 + rnd)
+                _, _, rgb31 = ref.gen_rays_v3_1(down_scale=1, last_epoch=False)
+                torch.set_rng_state(st)
+                if not torch.equal(rgb31, rgbt):
+                    errs.append(f'r{rnd}:v3_1')
+                thres_m = thres * 0.1
+                ref.adjust_tree(rgbt, pred, thres=thres_m)
+                ml = own.max_leaves()
+                tags = own.result_leaf_id.long()
+                slot = tags[:, 0] * ml + tags[:, 1]
+                sums = torch.zeros(nimg * ml, dtype=torch.float64).index_add_(0, slot, (rgbt - pred).abs().double().sum(-1))
+                counts = torch.zeros(nimg * ml, dtype=torch.int32).index_add_(0, slot, torch.ones(slot.shape[0], dtype=torch.int32))
+                own.adjust_tree_from_sumcount(sums, counts, thres_m)
+                same_trees(f'r{rnd}-mean')
+                continue
             ref.adjust_tree_multiThread(rgbt, pred, thres=thres)
             # (the product's adjust_tree_multiThread reduces on the GPU; here the same per-(image, leaf) max is formed on the
             # host and handed to the native split logic -- the part under test)
