@@ -2,6 +2,8 @@
 cameras on a sphere (`pose_spherical`, load_blender.py:29-34) looking at an analytic scene of
 coloured Gaussian density blobs over a white background.  Used by bench / tests / examples to
 produce identical training targets for the HIP path and the CPU oracle."""
+import os
+
 import numpy as np
 import torch
 
@@ -22,12 +24,20 @@ BLOBS = [  # centre, sigma, peak density, colour
 ]
 
 
+# FASTNERF_SCENE_CUTOFF=c (experiments): density exactly zero beyond c standard deviations of a blob's centre -- solid bodies
+# with empty space around them instead of Gaussian tails that never vanish (tools/live_trajectory.py)
+CUTOFF = float(os.environ.get('FASTNERF_SCENE_CUTOFF', '0') or 0)
+
+
 def scene(pts):
     """pts [..,3] float64 -> (sigma [..], rgb [..,3])."""
     sig = torch.zeros(pts.shape[:-1], dtype=pts.dtype)
     col = torch.zeros(pts.shape, dtype=pts.dtype)
     for c, s, d, rgb in BLOBS:
-        w = d * torch.exp(-((pts - torch.tensor(c, dtype=pts.dtype)) ** 2).sum(-1) / (2 * s * s))
+        r2 = ((pts - torch.tensor(c, dtype=pts.dtype)) ** 2).sum(-1)
+        w = d * torch.exp(-r2 / (2 * s * s))
+        if CUTOFF > 0:
+            w = torch.where(r2 <= (CUTOFF * s) ** 2, w, torch.zeros_like(w))
         sig = sig + w
         col = col + w[..., None] * torch.tensor(rgb, dtype=pts.dtype)
     return sig, col / (sig[..., None] + 1e-12)
@@ -54,17 +64,22 @@ def render_images(H, W, focal, poses, near=2.0, far=6.0, n_quad=256):
     return torch.stack(out, 0)
 
 
-def render_rays(rays_o, rays_d, near=2.0, far=6.0, n_quad=128):
+def render_rays(rays_o, rays_d, near=2.0, far=6.0, n_quad=128, cutoff=None):
     """Colours [N,3] of the analytic scene along arbitrary rays, by the same quadrature as render_images, on the
-    rays' device (fp32 is plenty for training targets).  Used by bench.py's trained-scene leg."""
+    rays' device (fp32 is plenty for training targets).  Used by bench.py's trained-scene legs.  cutoff = c > 0: the density is
+    exactly zero beyond c standard deviations of each blob's centre (solid bodies in empty space instead of Gaussian tails)."""
     dev, dt_ = rays_o.device, rays_o.dtype
+    cutoff = CUTOFF if cutoff is None else cutoff
     t = torch.linspace(near, far, n_quad, device=dev, dtype=dt_)
     step = (far - near) / (n_quad - 1)
     pts = rays_o[:, None, :] + rays_d[:, None, :] * t[None, :, None]
     sig = torch.zeros(pts.shape[:-1], device=dev, dtype=dt_)
     col = torch.zeros(pts.shape, device=dev, dtype=dt_)
     for c, s, d, rgb in BLOBS:
-        w = d * torch.exp(-((pts - torch.tensor(c, device=dev, dtype=dt_)) ** 2).sum(-1) / (2 * s * s))
+        r2 = ((pts - torch.tensor(c, device=dev, dtype=dt_)) ** 2).sum(-1)
+        w = d * torch.exp(-r2 / (2 * s * s))
+        if cutoff > 0:
+            w = torch.where(r2 <= (cutoff * s) ** 2, w, torch.zeros_like(w))
         sig = sig + w
         col = col + w[..., None] * torch.tensor(rgb, device=dev, dtype=dt_)
     col = col / (sig[..., None] + 1e-12)

@@ -8,7 +8,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_r2
 mkdir -p $O
-python tools/prof_step.py train $O/scene.pt 300 > $O/train.log 2>&1
+python tools/prof_step.py train $O/scene.pt 600 > $O/train.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- \
   python bench.py --steps 20 --warmup 5 --sustained-steps 50 --no-cpu-baseline < /dev/null > $O/bench.log 2>&1
 for mode in 1 0; do
@@ -27,6 +27,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/sq$i -o pmc -- python tools/prof_step.py kernels $O/scene.pt 1 \
     < /dev/null > $O/sq$i.log 2>&1
 done
-rm -f $O/scene.pt
+rm -f $O/scene.pt $O/bench/bench_kernel_trace.csv $O/sq*/pmc_kernel_trace.csv $O/pmc_*/pmc_kernel_trace.csv   # (not read by the summariser; gpurun copies back at most 64 MiB)
 find $O -name "*.csv" | head -40
 du -sh $O

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Whole optimisation steps at the bench size for rocprofv3 (kernel trace / PMC passes), in the steady state of training the
-analytic scene -- the regime bench.py's `value` is measured in.
+"""Whole optimisation steps at the bench size for rocprofv3 (kernel trace / PMC passes), in the stationary state of training the
+analytic solid-body scene -- the regime bench.py's `value` is measured in.
 
-  prof_step.py train <state.pt> [n]     n (300) optimisation steps from random init on the analytic scene; saves the trainer state
+  prof_step.py train <state.pt> [n]     n (600) optimisation steps from random init on the analytic scene; saves the trainer state
   prof_step.py steps <state.pt> <k>     loads the state, runs exactly k steps (FASTNERF_COMPACT = 1 / 0 / auto picks the backward)
   prof_step.py kernels <state.pt> [r]   stand-alone fine-pass launches on the trained fine net: forward without saving, saving
                                         forward, saving forward over the live list, backward plain / over the live list (r reps)
@@ -18,6 +18,7 @@ import fastnerf  # noqa: E402
 from fastnerf import ops, synthetic  # noqa: E402
 
 N_RAYS, NS, NI = 4096, 64, 128
+SCENE_CUTOFF = 1.5   # bench.py's solid-body scene
 
 
 def setup():
@@ -36,7 +37,7 @@ def setup():
         ro, rd = ops.gen_rays_pixels(pix.to(dev), poses, K)
         tag = torch.stack([pix[:, 0], (pix[:, 1] // 50) * 16 + pix[:, 2] // 50], 1).int().to(dev).contiguous()
         torch.rand(N_RAYS, 3, generator=gen)   # (bench.py draws its noise targets here: keep the streams aligned)
-        batches.append((ro, rd, synthetic.render_rays(ro, rd).contiguous(), tag))
+        batches.append((ro, rd, synthetic.render_rays(ro, rd, cutoff=SCENE_CUTOFF).contiguous(), tag))
     torch.manual_seed(0)
     ktr, _, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
     tr = fastnerf.run_nerf.Trainer(ktr, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
@@ -52,7 +53,7 @@ def main():
         ro, rd, tgt, tag = batches[i % 64]
         return tr.step(ro, rd, tgt, leaf_tag=tag, table=table, max_leaves=256)
     if what == 'train':
-        n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+        n = int(sys.argv[3]) if len(sys.argv) > 3 else 600
         for i in range(n):
             loss2, _ = step(i)
         torch.cuda.synchronize()

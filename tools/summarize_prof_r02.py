@@ -87,8 +87,8 @@ def sq_tables():
         label[tail[0]] = 'forward, no save (786 432 points)'
         label[tail[1]] = 'forward, saving (786 432 points)'
         label[tail[2]] = 'dX (786 432 points)'
-        label[tail[15]] = 'forward, saving, live list (52.5 %)'
-        label[tail[16]] = 'dX, live list (52.5 %)'
+        label[tail[15]] = 'forward, saving, live list'
+        label[tail[16]] = 'dX, live list'
         dw_plain = [d for d in tail[3:15] if '<4, 2, 2, 4, true, false>' in names[d]]
         dw_live = [d for d in tail[17:29] if '<4, 2, 2, 4, true, false>' in names[d]]
         if dw_plain:
@@ -109,7 +109,7 @@ def main():
     comp, plain = step_traffic(1), step_traffic(0)
     traffic = {'_how': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate run, --pmc WRITE_SIZE) -- python tools/prof_step.py '
                        'steps <state> 4 with FASTNERF_COMPACT=1 / 0: four optimisation steps (4096 rays x (64+128) samples) of nets '
-                       'trained for 300 steps on the analytic scene; counters are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md '
+                       'trained for 600 steps on the analytic solid-body scene of bench.py; counters are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md '
                        '(gfx950 reports 1/2 of wide coalesced reads); per-step = sum over every kernel of the step / 4',
                'kernels': {}, 'step_traffic': {
                    'compacted': {k: comp[k] for k in ('fetch_bytes_per_step', 'write_bytes_per_step', 'hbm_bytes_per_step')},
@@ -132,16 +132,18 @@ def main():
           'Collected by `tools/collect_profiles_r02.sh` (through gpurun), summarised by `tools/summarize_prof_r02.py`.', '',
           '## bench.py under the profiler', '',
           '`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --sustained-steps 50 --no-cpu-baseline`', '',
-          'bench line: **%.0f rays/s, %.2f ms/step** (steady state of training the analytic scene, compacted backward, live fraction '
+          'bench line: **%.0f rays/s, %.2f ms/step** (nets trained on the analytic solid-body scene, stationary live fraction; compacted backward, live fraction '
           'fine %.3f / coarse %.3f); same state with the plain backward %.0f rays/s (%.2f ms); round-1 protocol (random init, noise '
-          'targets) %.0f rays/s (%.2f ms).' % (j['value'], j['ms_per_step'], j['live_fraction']['fine'], j['live_fraction']['coarse'],
-                                               j['steady_state_plain']['value'], j['steady_state_plain']['ms_per_step'],
-                                               j['init_state']['value'], j['init_state']['ms_per_step']), '',
+          'targets) %.0f rays/s (%.2f ms); the blobs with their Gaussian tails after 300 steps %.0f rays/s (%.2f ms).' % (
+              j['value'], j['ms_per_step'], j['live_fraction']['fine'], j['live_fraction']['coarse'],
+              j['steady_state_plain']['value'], j['steady_state_plain']['ms_per_step'],
+              j['init_state']['value'], j['init_state']['ms_per_step'],
+              j['gaussian_tails_scene']['value'], j['gaussian_tails_scene']['ms_per_step']), '',
           'roofline leg (HIP events inside bench.py): `%s` %.3f ms/launch = %.1f TFLOP/s algorithmic = frac %.3f of 2500/3.' % (
               j['roofline']['kernel'], j['roofline']['avg_launch_ms'], j['roofline']['achieved'], j['roofline']['frac']), '']
     t, rows = stats_table(os.path.join(SRC, 'bench', 'bench_kernel_stats.csv'))
     md += t + ['']
-    md += ['(The bench process runs every leg: 300 + 5 + 20 + 50 steady-state steps, 23 plain steps on the trained nets, 23 steps of '
+    md += ['(The bench process runs every leg: 600 + 5 + 20 + 50 steps on the solid-body scene, 23 plain steps on the trained nets, 323 steps on the Gaussian-tail scene, 23 steps of '
            'the round-1 protocol, 23 steps of the exact-fp32 mode, the stand-alone roofline launches and the inference leg -- the table '
            'mixes them; the two step traces below are the clean per-step view.)', '']
     for tag, mode in (('compacted', 1), ('plain', 0)):
@@ -167,8 +169,8 @@ def main():
     open(os.path.join(DST, 'r02_summary.md'), 'w').write('\n'.join(md) + '\n')
 
     sq = sq_tables()
-    cols = ['forward, no save (786 432 points)', 'forward, saving (786 432 points)', 'forward, saving, live list (52.5 %)',
-            'dX (786 432 points)', 'dX, live list (52.5 %)', 'dW 256x256 job (786 432 points)', 'dW 256x256 job, live list']
+    cols = ['forward, no save (786 432 points)', 'forward, saving (786 432 points)', 'forward, saving, live list',
+            'dX (786 432 points)', 'dX, live list', 'dW 256x256 job (786 432 points)', 'dW 256x256 job, live list']
     cols = [c for c in cols if c in sq]
     counters = sorted({c for d in sq.values() for c in d})
     md = ['# r02 -- SQ counters of the split-bf16 MLP kernels (stand-alone fine-pass launches on the trained fine net)', '',
@@ -187,6 +189,10 @@ def main():
     md.append('| other instructions issued per MFMA | ' + ' | '.join(
         '%.1f' % ((sq[k]['SQ_INSTS_VALU'] + sq[k].get('SQ_INSTS_LDS', 0) + sq[k].get('SQ_INSTS_VMEM_RD', 0) + sq[k].get('SQ_INSTS_VMEM_WR', 0)
                    - sq[k]['SQ_INSTS_MFMA']) / sq[k]['SQ_INSTS_MFMA']) for k in cols) + ' |')
+    full = {'forward, saving, live list': 'forward, saving (786 432 points)', 'dX, live list': 'dX (786 432 points)',
+            'dW 256x256 job, live list': 'dW 256x256 job (786 432 points)'}
+    md.append('| share of the full launch (MFMA count: the live fraction of the trained state) | ' + ' | '.join(
+        ('%.1f %%' % (100 * sq[k]['SQ_INSTS_MFMA'] / sq[full[k]]['SQ_INSTS_MFMA'])) if k in full and full[k] in sq else '100 %' for k in cols) + ' |')
     md.append('| cycles the pipe is held per MFMA | ' + ' | '.join('%.1f' % (sq[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / sq[k]['SQ_INSTS_MFMA']) for k in cols) + ' |')
     open(os.path.join(DST, 'r02_sq_counters.md'), 'w').write('\n'.join(md) + '\n')
     print(open(os.path.join(DST, 'r02_summary.md')).read()[:6000])
