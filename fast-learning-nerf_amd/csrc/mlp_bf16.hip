@@ -58,6 +58,9 @@ typedef unsigned long long u64;
 #ifndef BF_BUFLD
 #define BF_BUFLD 1   // weight fragments via buffer_load_dwordx4 (scalar offsets) instead of 64-bit vector pointers
 #endif
+#ifndef BF_SKIP_DEAD
+#define BF_SKIP_DEAD 1   // FN_FWD_SKIP_DEAD_RGB support in the inference forward (0: compiled out, for A/B timing)
+#endif
 #ifndef BF_PRE_FWD
 #define BF_PRE_FWD 0   // forward: next layer's first weight fragments loaded ahead of the epilogue (measured -1 %: spills)
 #endif
@@ -715,7 +718,7 @@ __global__ void __launch_bounds__(BNTHR, 2)
 mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                     const float* __restrict__ params, const uint4* __restrict__ pk, float* __restrict__ raw,
                     uint4* __restrict__ act, NetLayout lay, BOff boff, unsigned* __restrict__ sched,
-                    const int* __restrict__ live_idx, const int* __restrict__ live_cnt) {
+                    const int* __restrict__ live_idx, const int* __restrict__ live_cnt, int flags) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   char* Hhi = bsm;
   char* Hlo = bsm + BTM * 512;
@@ -934,6 +937,26 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       }
     }
     TR(33);
+    // FN_FWD_SKIP_DEAD_RGB (inference launches of the NeRF net only): when EVERY sample of the tile has sigma <= 0, every one
+    // of them gets alpha = 0 and weight = 0 exactly in the compositing (no sigma noise in this mode: the caller's promise), so
+    // their colour logits can reach no output and no gradient -- the feature layer, the view layer and the colour head (17 % of
+    // the tile's MACs) are skipped and the logits are written as zeros.  Rays that miss the scene are whole tiles of this kind.
+    bool skip_tail = false;
+#if BF_SKIP_DEAD
+    if (!SAVE && !BG && (flags & 1)) {
+      // (no __syncthreads_and: it brings a static LDS word, and 80 KiB + 4 bytes per workgroup means ONE workgroup per CU.)
+      // One word per wave in 16 bytes of the encoding plane that are free here: channels 56..63 of row 0 -- the point encoding
+      // was consumed by layer 5 and the direction encoding written above occupies channels 0..31.
+      const unsigned long long any_live = __ballot((pm < valid) && (alpha_val > 0.f));
+      volatile int* slot = reinterpret_cast<volatile int*>(Ehi + eoff(0, 7));
+      if (lane == 0) slot[wn] = any_live != 0ull;
+      __syncthreads();
+      skip_tail = (slot[0] | slot[1] | slot[2] | slot[3]) == 0;
+    }
+#endif
+    if (skip_tail) {
+      if (pq == 0 && pm < valid && raw) *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = make_float4(0.f, 0.f, 0.f, alpha_val);
+    } else {
     // feature layer (no ReLU)
     ea.bias = params + lay.FB;
     bepi256_preload<true, false, false>(ea, wn, lane);
@@ -988,6 +1011,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
       }
     }
+    }   // !skip_tail
     TR(34);
 #ifdef BF_TRACE
     if (trace_on && lane == 0) g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 37] = wall_clock64();
@@ -999,7 +1023,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
 
 static int b_fwd_launch(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
                         const float* packed_fwd, float* raw, float* act, const int* live_idx, const int* live_cnt,
-                        fn_stream_t stream) {
+                        fn_stream_t stream, int flags = 0) {
   const NetLayout& lay = b_layout(kind);
   const BOff O = b_offsets(lay);
   const int64_t P = n * S;
@@ -1031,11 +1055,12 @@ static int b_fwd_launch(int kind, int64_t n, int S, const float* rays11, const f
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   if (kind == 2) {
-    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
-    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt, 0);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, true>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt, 0);
   } else {
-    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
-    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt);
+    if (act) hipLaunchKernelGGL((mlp_fwd_bf16_kernel<true, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt, 0);
+    else hipLaunchKernelGGL((mlp_fwd_bf16_kernel<false, false>), g, b, BLDS_BYTES, st, P, S, rays11, z, params, pk, raw, a4, lay, O, sched, live_idx, live_cnt,
+                            (kind == 0 && !live_idx) ? flags : 0);
   }
   FN_LAUNCH_CHECK();
   return 0;
@@ -1048,6 +1073,16 @@ extern "C" int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* ra
   FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
   if (n == 0) return 0;
   return b_fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream);
+}
+
+// Inference forward with options (see fastnerf.h: FN_FWD_SKIP_DEAD_RGB)
+extern "C" int fastnerf_mlp_bf16_fwd_flags(int kind, int64_t n, int S, const float* rays11, const float* z,
+                                           const float* params, const float* packed_fwd, float* raw, int flags,
+                                           fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
+  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
+  if (n == 0) return 0;
+  return b_fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, nullptr, nullptr, nullptr, stream, flags);
 }
 
 // Training forward over a live-point list (see fastnerf.h): activations of the points live_idx[0 .. *live_cnt) are saved

@@ -6,14 +6,14 @@
 
 namespace fn { void set_error(const char* fmt, ...); }
 
-extern "C" int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11,
+extern "C" int fastnerf_render_rays_fwd_ex(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11,
                                         int lindisp, int perturb, int det, int white_bkgd, const float* t_rand, const float* u,
                                         const float* noise0, const float* noise1, uint64_t seed0, uint64_t seed1,
                                         const float* params_c, const float* packed_c, const float* params_f,
                                         const float* packed_f, float* z0, float* raw0, float* act0, float* rgb0,
                                         float* disp0, float* acc0, float* w0, float* depth0, float* z1,
                                         float* z_samples, float* z_std, float* raw1, float* act1, float* rgb1,
-                                        float* disp1, float* acc1, float* w1, float* depth1, fn_stream_t stream) {
+                                        float* disp1, float* acc1, float* w1, float* depth1, int flags, fn_stream_t stream) {
   if ((math_mode != 0 && math_mode != 1) || n < 0 || N_samples < 2 || N_importance < 0) {
     fn::set_error("fastnerf_render_rays_fwd: bad argument: math_mode in {0,1}, n>=0, N_samples>=2, N_importance>=0");
     return -1;
@@ -29,12 +29,16 @@ extern "C" int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples,
     return -1;
   }
   int rc;
-  auto mlp = [&](int64_t nn, int S, const float* z, const float* params, const float* packed, float* raw, float* act) {
+  // (options only where their precondition holds: an inference launch of the split-bf16 kernels, no sigma noise in that pass)
+  auto mlp = [&](int64_t nn, int S, const float* z, const float* params, const float* packed, float* raw, float* act,
+                 const float* noise) {
+    if (math_mode && !act && !noise && flags)
+      return fastnerf_mlp_bf16_fwd_flags(0, nn, S, rays11, z, params, packed, raw, flags, stream);
     return math_mode ? fastnerf_mlp_bf16_fwd(0, nn, S, rays11, z, params, packed, raw, act, stream)
                      : fastnerf_mlp_fwd_ex(0, nn, S, rays11, z, params, packed, raw, act, stream);
   };
   if ((rc = fastnerf_sample_coarse(n, N_samples, rays11, lindisp, perturb, t_rand, seed0, z0, stream))) return rc;
-  if ((rc = mlp(n, N_samples, z0, params_c, packed_c, raw0, act0))) return rc;
+  if ((rc = mlp(n, N_samples, z0, params_c, packed_c, raw0, act0, noise0))) return rc;
   if ((rc = fastnerf_raw2outputs_fwd(n, N_samples, raw0, z0, rays11, noise0, white_bkgd, rgb0, disp0, acc0, w0, depth0, stream)))
     return rc;
   if (N_importance == 0) return 0;
@@ -45,13 +49,27 @@ extern "C" int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples,
   const int S1 = N_samples + N_importance;
   if ((rc = fastnerf_sample_pdf_merge(n, N_samples, N_importance, z0, w0, det, u, seed1, z1, z_samples, z_std, stream)))
     return rc;
-  if ((rc = mlp(n, S1, z1, params_f, packed_f, raw1, act1))) return rc;
+  if ((rc = mlp(n, S1, z1, params_f, packed_f, raw1, act1, noise1))) return rc;
   return fastnerf_raw2outputs_fwd(n, S1, raw1, z1, rays11, noise1, white_bkgd, rgb1, disp1, acc1, w1, depth1, stream);
 }
 
 // Backward of the same chain (autograd of render.py:238-299 w.r.t. the network parameters; sample positions are
 // detached in the reference, so the coarse net only sees d(loss)/d(rgb0)): compositing backward -> MLP backward for the
 // fine pass (into grads_f) and the coarse pass (into grads_c).  draw_ws: n * (N_samples + N_importance) * 4 floats.
+extern "C" int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11,
+                                        int lindisp, int perturb, int det, int white_bkgd, const float* t_rand, const float* u,
+                                        const float* noise0, const float* noise1, uint64_t seed0, uint64_t seed1,
+                                        const float* params_c, const float* packed_c, const float* params_f,
+                                        const float* packed_f, float* z0, float* raw0, float* act0, float* rgb0,
+                                        float* disp0, float* acc0, float* w0, float* depth0, float* z1,
+                                        float* z_samples, float* z_std, float* raw1, float* act1, float* rgb1,
+                                        float* disp1, float* acc1, float* w1, float* depth1, fn_stream_t stream) {
+  return fastnerf_render_rays_fwd_ex(math_mode, n, N_samples, N_importance, rays11, lindisp, perturb, det, white_bkgd, t_rand, u,
+                                     noise0, noise1, seed0, seed1, params_c, packed_c, params_f, packed_f, z0, raw0, act0, rgb0,
+                                     disp0, acc0, w0, depth0, z1, z_samples, z_std, raw1, act1, rgb1, disp1, acc1, w1, depth1, 0,
+                                     stream);
+}
+
 extern "C" int fastnerf_render_rays_bwd(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11,
                                         int white_bkgd, const float* g_rgb, const float* g_rgb0, const float* noise0,
                                         const float* noise1, const float* z0, const float* raw0, const float* act0,

@@ -210,7 +210,7 @@ def raw2outputs_fwd(raw, z, rays11, noise=None, white_bkgd=False):
 
 
 def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N_importance, lindisp=False, perturb=False,
-                    det=True, white_bkgd=False, t_rand=None, u=None, noise0=None, noise1=None, seed0=0, seed1=0, save=False):
+                    det=True, white_bkgd=False, t_rand=None, u=None, noise0=None, noise1=None, seed0=0, seed1=0, save=False, skip_dead_rgb=False):
     """One C-ABI call for the whole forward of render_rays (render.py:238-299).  Returns a dict of the tensors the
     step-by-step ops would have produced (same kernels, same results).  params_f / packed_f may be None when
     N_importance == 0."""
@@ -239,13 +239,15 @@ def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N
                   'rgb1': torch.empty(n, 3, **f32), 'disp1': torch.empty(n, **f32), 'acc1': torch.empty(n, **f32),
                   'w1': torch.empty(n, S1, **f32), 'depth1': torch.empty(n, **f32)})
     g = o.get
-    check(lib().fastnerf_render_rays_fwd(
+    # skip_dead_rgb (FN_FWD_SKIP_DEAD_RGB): the inference launches may leave the colour logits of tiles without a live sample at
+    # zero -- every other output is bit-identical; only callers that never expose `raw0` / `raw1` ask for it
+    check(lib().fastnerf_render_rays_fwd_ex(
         1 if split else 0, n, int(N_samples), int(N_importance), ptr(rays11), int(bool(lindisp)),
         int(bool(perturb) or t_rand is not None), int(bool(det)), int(bool(white_bkgd)), ptr(t_rand), ptr(u), ptr(noise0), ptr(noise1),
         int(seed0), int(seed1), ptr(params_c), ptr(packed_c), ptr(params_f), ptr(packed_f),
         ptr(o['z0']), ptr(o['raw0']), ptr(o['act0']), ptr(o['rgb0']), ptr(o['disp0']), ptr(o['acc0']), ptr(o['w0']), ptr(o['depth0']),
         ptr(g('z1')), ptr(g('z_samples')), ptr(g('z_std')), ptr(g('raw1')), ptr(g('act1')), ptr(g('rgb1')), ptr(g('disp1')),
-        ptr(g('acc1')), ptr(g('w1')), ptr(g('depth1')), stream()), 'fastnerf_render_rays_fwd')
+        ptr(g('acc1')), ptr(g('w1')), ptr(g('depth1')), 1 if skip_dead_rgb else 0, stream()), 'fastnerf_render_rays_fwd_ex')
     return o
 
 

@@ -138,7 +138,7 @@ class LivePolicy:
 
 
 def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, perturb, white_bkgd, t_rand, u, noise0,
-                  noise1, save, packed_c=None, packed_f=None):
+                  noise1, save, packed_c=None, packed_f=None, skip_dead_rgb=False):
     """The fused forward.  Returns (outputs dict, saved-for-backward dict)."""
     pc = packed_c if packed_c is not None else net_c.packed()
     fine = pf = None
@@ -150,7 +150,8 @@ def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, pertur
                             N_samples, N_importance, lindisp=lindisp, perturb=perturb, det=(perturb == 0.),
                             white_bkgd=white_bkgd, t_rand=t_rand, u=u, noise0=noise0, noise1=noise1,
                             seed0=_next_seed() if (perturb and t_rand is None) else 0,
-                            seed1=_next_seed() if (N_importance > 0 and perturb and u is None) else 0, save=save)
+                            seed1=_next_seed() if (N_importance > 0 and perturb and u is None) else 0, save=save,
+                            skip_dead_rgb=bool(skip_dead_rgb and not save and net_c.use_viewdirs))
     out = {}
     saved = {'rays11': rays11, 'z0': o['z0'], 'raw0': o['raw0'], 'act0': o['act0'], 'noise0': noise0, 'white': white_bkgd,
              'net_c': net_c, 'net_f': None, 'pc': pc, 'live': not save}

@@ -168,6 +168,9 @@ class Trainer:
         self.global_iter = 0
         self.world = parallel.world_size()
         self.live = LivePolicy()   # exact zero-gradient point compaction of the backward (render.py)
+        # first pass of a compacted step: tiles without a live sample skip their colour branch (FN_FWD_SKIP_DEAD_RGB; the fused
+        # step never exposes raw logits, every other output and the gradients are bit-identical -- tests/test_gpu_compact.py)
+        self.skip_dead_rgb = True
         self.live_counts = torch.zeros(4, device=self.flat.device, dtype=torch.int32)
         self.last_step_live = False
         self.repack()
@@ -191,7 +194,7 @@ class Trainer:
         live = self.live.use_live(self.net_c, self.net_f, self.N_importance)
         out, saved = _forward_core(rays11, self.net_c, self.net_f, self.N_samples, self.N_importance, self.lindisp,
                                    self.perturb, self.white_bkgd, t_rand, u, noise0, noise1, save=not live,
-                                   packed_c=self.pc, packed_f=self.pf)
+                                   packed_c=self.pc, packed_f=self.pf, skip_dead_rgb=live and self.skip_dead_rgb)
         scale = 1.0 if n_global is None else float(n) / float(n_global)
         loss2, g, g0 = ops.mse_leafmax(out['rgb_map'], out.get('rgb0'), target, grad_scale=scale, leaf_tag=leaf_tag,
                                        max_leaves=max_leaves, table=table)

@@ -273,3 +273,70 @@ def test_autograd_route_and_policy(fn, golden_dir, math_mode):
         assert pol.use_live(tr.net_c, None, 0)
     finally:
         fn.render.set_compact(old)
+
+
+def test_skip_colour_of_dead_tiles(fn, math_mode):
+    """FN_FWD_SKIP_DEAD_RGB: in the first pass of a compacted step a 64-point tile whose samples all have sigma <= 0 skips the
+    feature / view / colour layers.  Those samples have weight exactly zero, so every output of the renderer and every
+    gradient must be bit-identical with and without the option; only the colour logits of such tiles differ (reported as 0)."""
+    from fastnerf import synthetic
+    dev = torch.device('cuda')
+    N = 1024
+    args = fn.run_nerf.make_args(N_importance=128, N_samples=64, perturb=1.0, white_bkgd=True, no_reload=True, lrate=5e-4, lrate_decay=500)
+    focal = 0.5 * 800 / np.tan(0.5 * 0.6911112070083618)
+    K = np.array([[focal, 0, 400.0], [0, focal, 400.0], [0, 0, 1]])
+    poses = torch.stack([synthetic.pose_spherical(-180.0 + 36.0 * k, -30.0, 4.0)[:3, :4] for k in range(10)], 0).to(dev)
+    gen = torch.Generator().manual_seed(4)
+    batches = []
+    for _ in range(16):
+        pix = torch.stack([torch.randint(0, 10, (N,), generator=gen), torch.randint(0, 800, (N,), generator=gen),
+                           torch.randint(0, 800, (N,), generator=gen)], 1).int().to(dev)
+        ro, rd = fn.ops.gen_rays_pixels(pix, poses, K)
+        batches.append((ro, rd, synthetic.render_rays(ro, rd, cutoff=1.5).contiguous()))
+    torch.manual_seed(0)
+    ktr = fn.run_nerf.create_nerf(args, device=dev)[0]
+    tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+    for i in range(250):                       # solid bodies in empty space: rays that miss them become all-dead tiles
+        tr.step(*batches[i % 16])
+    ro, rd, tgt = batches[3]
+    t_rand, u = torch.rand(N, 64, generator=gen).to(dev), torch.rand(N, 128, generator=gen).to(dev)
+    rays11 = fn.ops.pack_rays(ro, rd, 2.0, 6.0)
+    outs = {}
+    for skip in (False, True):
+        outs[skip], _ = fn.render._forward_core(rays11, tr.net_c, tr.net_f, 64, 128, False, 1.0, True, t_rand, u, None, None, save=False,
+                                                packed_c=tr.pc, packed_f=tr.pf, skip_dead_rgb=skip)
+    a, b = outs[False], outs[True]
+    for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'weights', 'z_vals', 'depth_map', 'weights0', 'z0'):
+        assert torch.equal(a[k], b[k]) or (torch.isnan(a[k]) == torch.isnan(b[k])).all() and torch.equal(a[k].nan_to_num(), b[k].nan_to_num()), k
+    ra, rb_ = a['raw'].reshape(-1, 4), b['raw'].reshape(-1, 4)          # fine pass, 1024 * 192 points = 3072 tiles
+    assert torch.equal(ra[:, 3], rb_[:, 3])
+    dead_tile = (ra[:, 3].reshape(-1, 64) <= 0).all(1)
+    frac = float(dead_tile.float().mean())
+    assert frac > 0.2, frac                                               # (measured 0.55-0.7 after 250 steps)
+    live_rows = (~dead_tile)[:, None].expand(-1, 64).reshape(-1)
+    assert torch.equal(ra[live_rows], rb_[live_rows])
+    if math_mode == 'bf16x3':
+        assert float(rb_[~live_rows][:, :3].abs().max()) == 0.0 and float(ra[~live_rows][:, :3].abs().max()) > 0.0
+    else:                                      # the exact-fp32 kernels do not implement the option: logits unchanged
+        assert torch.equal(ra, rb_)
+    # the whole compacted step: same loss, same gradient, bit for bit
+    old = fn.render.get_compact()
+    fn.render.set_compact('1')
+    try:
+        g = {}
+        for skip in (False, True):
+            tr.skip_dead_rgb = skip
+            loss2, _ = tr.forward_backward(ro, rd, tgt, t_rand=t_rand, u=u)
+            assert tr.last_step_live
+            g[skip] = (loss2.clone(), tr.grad.clone(), tr.live_counts.clone())
+        assert torch.equal(g[False][0], g[True][0]) and torch.equal(g[False][1], g[True][1]) and torch.equal(g[False][2], g[True][2])
+    finally:
+        fn.render.set_compact(old)
+    # with sigma noise the option is not applied (a dead sigma can come alive): logits stay exact
+    n1 = torch.randn(N, 192, generator=gen).to(dev)
+    n0 = torch.randn(N, 64, generator=gen).to(dev)
+    o_n, _ = fn.render._forward_core(rays11, tr.net_c, tr.net_f, 64, 128, False, 1.0, True, t_rand, u, n0, n1, save=False,
+                                     packed_c=tr.pc, packed_f=tr.pf, skip_dead_rgb=True)
+    o_r, _ = fn.render._forward_core(rays11, tr.net_c, tr.net_f, 64, 128, False, 1.0, True, t_rand, u, n0, n1, save=False,
+                                     packed_c=tr.pc, packed_f=tr.pf, skip_dead_rgb=False)
+    assert torch.equal(o_n['raw'], o_r['raw']) and torch.equal(o_n['rgb_map'], o_r['rgb_map'])

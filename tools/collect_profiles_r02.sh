@@ -19,6 +19,10 @@ for mode in 1 0; do
       python tools/prof_step.py steps $O/scene.pt 4 < /dev/null > $O/pmc_c${mode}_$c.log 2>&1
   done
 done
+# 3b. kernel trace of the stand-alone fine-pass launches (full work: no tile skips its colour branch) -- the launch bench.py's
+#     roofline leg times with HIP events
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kernels -o kernels -- python tools/prof_step.py kernels $O/scene.pt 5 \
+  < /dev/null > $O/kernels.log 2>&1
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \

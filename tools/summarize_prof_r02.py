@@ -155,8 +155,20 @@ def main():
         md += t + ['', 'Sum of the step kernels: **%.2f ms per step** of kernel time.' % tot, '']
     tr = os.path.join(SRC, 'steps_c1', 'steps_kernel_trace.csv')
     a, n = fine_launch_us(tr, 'mlp_fwd_bf16_kernel<false, false>', 'large')
-    md += ['Fine-pass launches in the compacted step trace: `mlp_fwd_bf16_kernel<false, false>` %.1f us average over %d launches '
-           '(bench roofline leg: %.1f us) -- the two measurements of the dominant kernel agree.' % (a, n, 1e3 * j['roofline']['avg_launch_ms']), '']
+    ks = os.path.join(SRC, 'kernels', 'kernels_kernel_trace.csv')
+    if os.path.exists(ks):
+        # stand-alone launches of the same kernel doing ALL the work (tools/prof_step.py kernels: 5 reps after one forward of the
+        # whole renderer, whose two launches come first)
+        rows = [r for r in csv.DictReader(open(ks)) if 'mlp_fwd_bf16_kernel<false, false>' in r['Kernel_Name']]
+        d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows][2:]
+        md += ['Dominant kernel, stand-alone fine-pass launch with every tile doing all its work (`tools/prof_step.py kernels` under '
+               '`rocprofv3 --kernel-trace`): `mlp_fwd_bf16_kernel<false, false>` **%.1f us** average over %d launches; the roofline leg '
+               'of bench.py times the same launch with HIP events: **%.1f us** (ratio %.2f: five launches of a cold process under the '
+               'profiler against the warmed-up bench process).' % (sum(d) / len(d), len(d), 1e3 * j['roofline']['avg_launch_ms'],
+                                                                  sum(d) / len(d) / (1e3 * j['roofline']['avg_launch_ms'])), '']
+    md += ['Inside the compacted step the fine-pass launch of that kernel takes %.1f us on average (%d launches): there, tiles '
+           'without a live sample skip their colour branch (FN_FWD_SKIP_DEAD_RGB, 17 %% of a tile\'s MACs; exact: those samples have '
+           'weight 0).' % (a, n), '']
     md += ['## HBM traffic per optimisation step (PMC)', '',
            '| backward | fetch GB | write GB | total GB / step |', '|---|---|---|---|']
     for tag, d in (('compacted', comp), ('plain', plain)):
