@@ -311,7 +311,9 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             noise1 = torch.randn(n, N_samples + N_importance, device=dev) * raw_noise_std
     cfg = dict(rays11=rays11, net_c=net_c, net_f=net_f, N_samples=N_samples, N_importance=N_importance,
                lindisp=lindisp, perturb=perturb, white_bkgd=white_bkgd, t_rand=t_rand, u=u, noise0=noise0,
-               noise1=noise1)
+               noise1=noise1,
+               # nobody sees the colour logits of this call: tiles without a live sample may skip them (FN_FWD_SKIP_DEAD_RGB)
+               skip_dead_rgb=not retraw)
     params = list(net_c.parameters()) + (list(net_f.parameters()) if (net_f is not None and net_f is not net_c) else [])
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         outs = _RenderRaysFn.apply(cfg, *params)

@@ -340,3 +340,34 @@ def test_skip_colour_of_dead_tiles(fn, math_mode):
     o_r, _ = fn.render._forward_core(rays11, tr.net_c, tr.net_f, 64, 128, False, 1.0, True, t_rand, u, n0, n1, save=False,
                                      packed_c=tr.pc, packed_f=tr.pf, skip_dead_rgb=False)
     assert torch.equal(o_n['raw'], o_r['raw']) and torch.equal(o_n['rgb_map'], o_r['rgb_map'])
+
+
+def test_render_without_retraw_uses_the_skip_and_matches(fn, golden_dir):
+    """render() / render_path never hand out colour logits unless retraw=True: without it the inference launches skip the colour
+    branch of tiles without a live sample, and every map is bit for bit what the retraw=True call returns."""
+    from fastnerf import synthetic
+    dev = torch.device('cuda')
+    N = 1024
+    args = fn.run_nerf.make_args(N_importance=128, N_samples=64, perturb=1.0, white_bkgd=True, no_reload=True, lrate=5e-4, lrate_decay=500)
+    focal = 0.5 * 800 / np.tan(0.5 * 0.6911112070083618)
+    K = np.array([[focal, 0, 400.0], [0, focal, 400.0], [0, 0, 1]])
+    poses = torch.stack([synthetic.pose_spherical(-180.0 + 36.0 * k, -30.0, 4.0)[:3, :4] for k in range(10)], 0).to(dev)
+    gen = torch.Generator().manual_seed(4)
+    torch.manual_seed(0)
+    ktr, kte, _, _, _, _ = fn.run_nerf.create_nerf(args, device=dev)
+    tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+    for i in range(200):                       # a field with empty space around solid bodies
+        pix = torch.stack([torch.randint(0, 10, (N,), generator=gen), torch.randint(0, 800, (N,), generator=gen),
+                           torch.randint(0, 800, (N,), generator=gen)], 1).int().to(dev)
+        ro, rd = fn.ops.gen_rays_pixels(pix, poses, K)
+        tr.step(ro, rd, synthetic.render_rays(ro, rd, cutoff=1.5).contiguous())
+    ro, rd = fn.run_nerf_helpers.get_rays(800, 800, K, poses[3])
+    rays = (ro[200:328:2, 200:328:2].reshape(-1, 3).contiguous(), rd[200:328:2, 200:328:2].reshape(-1, 3).contiguous())
+    with torch.no_grad():
+        a = fn.render.render(800, 800, K, chunk=32768, rays=rays, near=2.0, far=6.0, retraw=True, **kte)
+        b = fn.render.render(800, 800, K, chunk=32768, rays=rays, near=2.0, far=6.0, **kte)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x.nan_to_num(), y.nan_to_num()) and torch.equal(torch.isnan(x), torch.isnan(y))
+    assert 'raw' in a[3] and 'raw' not in b[3] and torch.equal(a[3]['z_std'], b[3]['z_std'])
+    dead = (a[3]['raw'][..., 3].reshape(-1, 64) <= 0).all(1).float().mean()
+    assert 0.05 < float(dead) < 0.999, float(dead)       # the option had something to skip, and something to keep
