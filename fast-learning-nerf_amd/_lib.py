@@ -51,6 +51,7 @@ SIGNATURES = {
     'fastnerf_render_rays_fwd': (I, [I, L, I, I, P, I, I, I, I, P, P, P, P, U64, U64, P, P, P, P] + [P] * 18 + [P]),
     'fastnerf_render_rays_fwd_ex': (I, [I, L, I, I, P, I, I, I, I, P, P, P, P, U64, U64, P, P, P, P] + [P] * 18 + [I, P]),
     'fastnerf_mlp_bf16_fwd_flags': (I, [I, L, I, P, P, P, P, P, I, P]),
+    'fastnerf_mlp_fwd_flags_ex': (I, [I, L, I, P, P, P, P, P, I, P]),
     'fastnerf_render_rays_bwd': (I, [I, L, I, I, P, I] + [P] * 20),
     'fastnerf_pp_intersect_sphere': (I, [L, P, P, P, P]),
     'fastnerf_pp_fg_depths': (I, [L, I, F, P, I, P, U64, P, P]),

@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                const float* __restrict__ params, const float* __restrict__ packed, float* __restrict__ raw,
                float* __restrict__ act, NetLayout lay, unsigned* __restrict__ sched, const int* __restrict__ live_idx,
-               const int* __restrict__ live_cnt) {
+               const int* __restrict__ live_cnt, int flags) {
   // live-list mode (exact zero-gradient point compaction, see mlp_bf16.hip / train.hip): row j of the launch is point
   // live_idx[j], the row count is a device value; the saved tensors keep the strides of the capacity PL they were sized for
   const int64_t PL = P;
@@ -559,6 +559,22 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         Es[eidx(pm, 6 + 6 * k + dim)] = cosf(a);
       }
     }
+    // FN_FWD_SKIP_DEAD_RGB (see mlp_bf16.hip): a tile without a live sample skips the feature / view / colour layers.  One word
+    // per wave in channels 56..63 of row 0 of the encoding tile (free since layer 5; the direction encoding uses 0..31).
+    bool skip_tail = false;
+    if (!SAVE && !BG && (flags & 1)) {
+      const unsigned long long any_live = __ballot((pm < valid) && (alpha_val > 0.f));
+      volatile int* slot = reinterpret_cast<volatile int*>(Es + 56);
+      if (lane == 0) slot[wave] = any_live != 0ull;
+      __syncthreads();
+      int any = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) any |= slot[w];
+      skip_tail = any == 0;
+    }
+    if (skip_tail) {
+      if (pq == 0 && pm < valid && raw) *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = make_float4(0.f, 0.f, 0.f, alpha_val);
+    } else {
     // ---- feature layer (no ReLU) ------------------------------------------------------
     zero_acc<2>(acc);
     load_bias<2>(bv2, params + lay.FB, wn, lane);
@@ -620,6 +636,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = o;
       }
     }
+    }   // !skip_tail
     tile = b_next_tile(sched, sched_word, tid);   // closing barrier inside: H / Es are rewritten by the next tile
   }
   b_sched_exit(sched, tid);
@@ -627,7 +644,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
 
 static int fwd_launch(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
                       const float* packed_fwd, float* raw, float* act, const int* live_idx, const int* live_cnt,
-                      fn_stream_t stream) {
+                      fn_stream_t stream, int flags = 0) {
   const NetLayout& lay = layout_of(kind);
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
@@ -649,11 +666,12 @@ static int fwd_launch(int kind, int64_t n, int S, const float* rays11, const flo
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
   if (kind == 2) {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt, 0);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt, 0);
   } else {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt);
+    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt, 0);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt,
+                            (kind == 0 && !live_idx) ? flags : 0);
   }
   FN_LAUNCH_CHECK();
   return 0;
@@ -667,6 +685,14 @@ extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays
   return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream);
 }
 // exact-fp32 twin of fastnerf_mlp_bf16_fwd_live
+extern "C" int fastnerf_mlp_fwd_flags_ex(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                                         const float* packed_fwd, float* raw, int flags, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
+  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
+  if (n == 0) return 0;
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, nullptr, nullptr, nullptr, stream, flags);
+}
+
 extern "C" int fastnerf_mlp_fwd_live_ex(int kind, int64_t n, int S, const float* rays11, const float* z,
                                         const float* params, const float* packed_fwd, float* act,
                                         const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream) {

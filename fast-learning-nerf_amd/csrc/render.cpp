@@ -29,11 +29,12 @@ extern "C" int fastnerf_render_rays_fwd_ex(int math_mode, int64_t n, int N_sampl
     return -1;
   }
   int rc;
-  // (options only where their precondition holds: an inference launch of the split-bf16 kernels, no sigma noise in that pass)
+  // (options only where their precondition holds: an inference launch, no sigma noise in that pass)
   auto mlp = [&](int64_t nn, int S, const float* z, const float* params, const float* packed, float* raw, float* act,
                  const float* noise) {
-    if (math_mode && !act && !noise && flags)
-      return fastnerf_mlp_bf16_fwd_flags(0, nn, S, rays11, z, params, packed, raw, flags, stream);
+    if (!act && !noise && flags)
+      return math_mode ? fastnerf_mlp_bf16_fwd_flags(0, nn, S, rays11, z, params, packed, raw, flags, stream)
+                       : fastnerf_mlp_fwd_flags_ex(0, nn, S, rays11, z, params, packed, raw, flags, stream);
     return math_mode ? fastnerf_mlp_bf16_fwd(0, nn, S, rays11, z, params, packed, raw, act, stream)
                      : fastnerf_mlp_fwd_ex(0, nn, S, rays11, z, params, packed, raw, act, stream);
   };

@@ -147,7 +147,7 @@ int fastnerf_mlp_bf16_fwd(int kind, int64_t n, int S, const float* rays11, const
 int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                           const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
 
-/* Inference forward (no saved activations) with options.  flags & FN_FWD_SKIP_DEAD_RGB (kind 0 only, split-bf16 kernels): a
+/* Inference forward (no saved activations) with options.  flags & FN_FWD_SKIP_DEAD_RGB (kind 0 only): a
  * 64-point tile whose samples ALL have sigma <= 0 skips the feature layer, the view layer and the colour head and reports
  * colour logits 0 -- valid when nothing reads the colour of a sample whose weight is exactly zero: compositing without sigma
  * noise (render.py:162-182: alpha = 1 - exp(-relu(sigma) * dist) = 0, weight = alpha * T = 0) and everything downstream of it
@@ -155,6 +155,8 @@ int fastnerf_mlp_bf16_bwd(int kind, int64_t n, int S, const float* draw, const f
 #define FN_FWD_SKIP_DEAD_RGB 1
 int fastnerf_mlp_bf16_fwd_flags(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
                                 const float* packed_fwd, float* raw, int flags, fn_stream_t stream);
+int fastnerf_mlp_fwd_flags_ex(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                              const float* packed_fwd, float* raw, int flags, fn_stream_t stream);   /* exact-fp32 kernels */
 
 /* ---- fused forward of render_rays (render.py:238-299): coarse sampler -> coarse MLP -> compositing ->
  * [sample_pdf + merge -> fine MLP -> compositing], enqueued by one call on `stream`.  math_mode 0 = exact fp32,
@@ -169,8 +171,8 @@ int fastnerf_render_rays_fwd(int math_mode, int64_t n, int N_samples, int N_impo
                              float* z0, float* raw0, float* act0, float* rgb0, float* disp0, float* acc0, float* w0,
                              float* depth0, float* z1, float* z_samples, float* z_std, float* raw1, float* act1,
                              float* rgb1, float* disp1, float* acc1, float* w1, float* depth1, fn_stream_t stream);
-/* The same with fastnerf_mlp_bf16_fwd_flags options for its inference launches (act0 / act1 == NULL, math_mode 1, noise0 /
- * noise1 == NULL; ignored otherwise): what the first pass of a compacted training step uses -- raw0 / raw1 then carry colour
+/* The same with fastnerf_mlp_bf16_fwd_flags options for its inference launches (act0 / act1 == NULL, noise0 / noise1 == NULL;
+ * ignored otherwise): what the first pass of a compacted training step uses -- raw0 / raw1 then carry colour
  * logits 0 on tiles without a live sample, every other output is bit-identical. */
 int fastnerf_render_rays_fwd_ex(int math_mode, int64_t n, int N_samples, int N_importance, const float* rays11, int lindisp,
                                 int perturb, int det, int white_bkgd, const float* t_rand, const float* u,
