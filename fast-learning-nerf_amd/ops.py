@@ -210,7 +210,7 @@ def raw2outputs_fwd(raw, z, rays11, noise=None, white_bkgd=False):
 
 
 def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N_importance, lindisp=False, perturb=False,
-                    det=True, white_bkgd=False, t_rand=None, u=None, noise0=None, noise1=None, seed0=0, seed1=0, save=False, skip_dead_rgb=False):
+                    det=True, white_bkgd=False, t_rand=None, u=None, noise0=None, noise1=None, seed0=0, seed1=0, save=False, skip_dead_rgb=False, act_bufs=None):
     """One C-ABI call for the whole forward of render_rays (render.py:238-299).  Returns a dict of the tensors the
     step-by-step ops would have produced (same kernels, same results).  params_f / packed_f may be None when
     N_importance == 0."""
@@ -228,14 +228,23 @@ def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N
     if u is not None:
         u = _f32(u)
         assert u.shape == (n, N_importance)
+    # act_bufs = (buffer for the coarse pass, buffer for the fine pass): caller-owned scratch for the saved activations (11 GB at
+    # the bench size) instead of fresh allocations -- for callers whose backward follows before the next forward
+    def act_buf(k, count):
+        if not save:
+            return None
+        if act_bufs is not None and act_bufs[k] is not None:
+            assert act_bufs[k].numel() >= count and act_bufs[k].dtype == torch.float32 and act_bufs[k].device == dev
+            return act_bufs[k]
+        return torch.empty(count, **f32)
     o = {'z0': torch.empty(n, N_samples, **f32), 'raw0': torch.empty(n, N_samples, 4, **f32),
-         'act0': torch.empty(act_floats(n * N_samples), **f32) if save else None,
+         'act0': act_buf(0, act_floats(n * N_samples)),
          'rgb0': torch.empty(n, 3, **f32), 'disp0': torch.empty(n, **f32), 'acc0': torch.empty(n, **f32),
          'w0': torch.empty(n, N_samples, **f32), 'depth0': torch.empty(n, **f32)}
     S1 = N_samples + N_importance
     if N_importance > 0:
         o.update({'z1': torch.empty(n, S1, **f32), 'z_samples': torch.empty(n, N_importance, **f32), 'z_std': torch.empty(n, **f32),
-                  'raw1': torch.empty(n, S1, 4, **f32), 'act1': torch.empty(act_floats(n * S1), **f32) if save else None,
+                  'raw1': torch.empty(n, S1, 4, **f32), 'act1': act_buf(1, act_floats(n * S1)),
                   'rgb1': torch.empty(n, 3, **f32), 'disp1': torch.empty(n, **f32), 'acc1': torch.empty(n, **f32),
                   'w1': torch.empty(n, S1, **f32), 'depth1': torch.empty(n, **f32)})
     g = o.get

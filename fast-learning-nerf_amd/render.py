@@ -138,20 +138,27 @@ class LivePolicy:
 
 
 def _forward_core(rays11, net_c, net_f, N_samples, N_importance, lindisp, perturb, white_bkgd, t_rand, u, noise0,
-                  noise1, save, packed_c=None, packed_f=None, skip_dead_rgb=False):
+                  noise1, save, packed_c=None, packed_f=None, skip_dead_rgb=False, act_ws=False):
     """The fused forward.  Returns (outputs dict, saved-for-backward dict)."""
     pc = packed_c if packed_c is not None else net_c.packed()
     fine = pf = None
     if N_importance > 0:
         fine = net_f if net_f is not None else net_c
         pf = packed_f if packed_f is not None else (fine.packed() if fine is not net_c else pc)
+    # act_ws (the fused Trainer: its backward runs before its next forward): the saved activations live in this stream's
+    # persistent scratch instead of 11 GB of fresh allocations per step
+    act_bufs = None
+    if save and act_ws:
+        n_ = rays11.shape[0]
+        act_bufs = (_Workspace.get('act0', rays11.device, ops.act_floats(n_ * N_samples)),
+                    _Workspace.get('act1', rays11.device, ops.act_floats(n_ * (N_samples + N_importance))) if N_importance > 0 else None)
     # one C-ABI call enqueues sampler -> MLP -> compositing [-> sample_pdf + merge -> MLP -> compositing]
     o = ops.render_rays_fwd(rays11, net_c.flat, pc[0], None if fine is None else fine.flat, None if pf is None else pf[0],
                             N_samples, N_importance, lindisp=lindisp, perturb=perturb, det=(perturb == 0.),
                             white_bkgd=white_bkgd, t_rand=t_rand, u=u, noise0=noise0, noise1=noise1,
                             seed0=_next_seed() if (perturb and t_rand is None) else 0,
                             seed1=_next_seed() if (N_importance > 0 and perturb and u is None) else 0, save=save,
-                            skip_dead_rgb=bool(skip_dead_rgb and not save and net_c.use_viewdirs))
+                            skip_dead_rgb=bool(skip_dead_rgb and not save and net_c.use_viewdirs), act_bufs=act_bufs)
     out = {}
     saved = {'rays11': rays11, 'z0': o['z0'], 'raw0': o['raw0'], 'act0': o['act0'], 'noise0': noise0, 'white': white_bkgd,
              'net_c': net_c, 'net_f': None, 'pc': pc, 'live': not save}

@@ -194,7 +194,7 @@ class Trainer:
         live = self.live.use_live(self.net_c, self.net_f, self.N_importance)
         out, saved = _forward_core(rays11, self.net_c, self.net_f, self.N_samples, self.N_importance, self.lindisp,
                                    self.perturb, self.white_bkgd, t_rand, u, noise0, noise1, save=not live,
-                                   packed_c=self.pc, packed_f=self.pf, skip_dead_rgb=live and self.skip_dead_rgb)
+                                   packed_c=self.pc, packed_f=self.pf, skip_dead_rgb=live and self.skip_dead_rgb, act_ws=True)
         scale = 1.0 if n_global is None else float(n) / float(n_global)
         loss2, g, g0 = ops.mse_leafmax(out['rgb_map'], out.get('rgb0'), target, grad_scale=scale, leaf_tag=leaf_tag,
                                        max_leaves=max_leaves, table=table)
