@@ -24,3 +24,9 @@ for rep in range(3):
         for i in range(100): tr.step(*batches[i % 64])
         torch.cuda.synchronize()
         print(f'skip={skip}: {(time.perf_counter() - t0) * 10:.3f} ms/step live={tr.last_step_live}', flush=True)
+# host-side enqueue time of a step (the GPU must never wait for the host): 100 steps issued without synchronising
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(100): tr.step(*batches[i % 64])
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+print(f'host enqueue {t_host * 10:.3f} ms/step, GPU-bound wall {t_all * 10:.3f} ms/step', flush=True)
