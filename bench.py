@@ -419,8 +419,8 @@ def main():
                               'it) keeps 0.19 fine / 0.08 coarse live from step ~500 through 6000 (tools/live_trajectory.py); '
                               '`gaussian_tails_scene` and `steady_state_plain` are the adverse cases'},
             'device': {'name': torch.cuda.get_device_name(dev), 'compute_units': torch.cuda.get_device_properties(dev).multi_processor_count,
-                       'note': 'the chip is power-managed under these kernels (DESIGN section 9): the same tree measured 384 k .. 429 k rays/s on '
-                               'different boxes of the pool, every leg moving together'},
+                       'note': 'the chip is power-managed under these kernels (DESIGN section 9): the same tree measured 720 k .. 757 k rays/s on '
+                               'different boxes of the pool (one box of an earlier session ran every leg 8 % slower), every leg moving together'},
             'final_loss': [float(x) for x in loss2.tolist()],
             'backward': ('compacted: samples with an exactly-zero gradient skipped (FASTNERF_COMPACT=%s)' % fastnerf.render.get_compact())
             if backward_kind == 'compacted' else 'plain (every sample)',
