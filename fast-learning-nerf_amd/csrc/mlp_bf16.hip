@@ -56,6 +56,9 @@ typedef unsigned long long u64;
 #define BF_PRIO 1   // s_setprio level of a wave inside the k-loops (0: none); +1..2 % with two workgroups per CU
 #endif
 #ifndef BF_BUFLD
+#ifndef BF_WAUX
+#define BF_WAUX 0   // cache-policy bits of the weight-fragment loads (1 = sc0, 2 = sc1 / slc, 3 = both): measured, see DESIGN section 9
+#endif
 #define BF_BUFLD 1   // weight fragments via buffer_load_dwordx4 (scalar offsets) instead of 64-bit vector pointers
 #endif
 #ifndef BF_SKIP_DEAD
@@ -350,8 +353,8 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
     for (int nt = 0; nt < NT; ++nt) {
 #if BF_BUFLD
       typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
-      bh[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048, 0));
-      bl[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048 + 1024, 0));
+      bh[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048, BF_WAUX));
+      bl[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048 + 1024, BF_WAUX));
 #else
       bh[nt] = (bptr[nt] + ks * 128)[blane]; bl[nt] = (bptr[nt] + ks * 128 + 64)[blane];
 #endif
