@@ -56,6 +56,9 @@ typedef unsigned long long u64;
 #define BF_PRIO 1   // s_setprio level of a wave inside the k-loops (0: none); +1..2 % with two workgroups per CU
 #endif
 #ifndef BF_BUFLD
+#ifndef DW_SKIP_IDLE
+#define DW_SKIP_IDLE 1   // dW workgroups without tiles write no partials and breduce skips them (0: A/B)
+#endif
 #ifndef BF_WAUX
 #define BF_WAUX 0   // cache-policy bits of the weight-fragment loads (1 = sc0, 2 = sc1 / slc, 3 = both): measured, see DESIGN section 9
 #endif
@@ -1332,6 +1335,11 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
   const int64_t t0 = blockIdx.x * per;
   int64_t t1 = t0 + per;
   if (t1 > ntiles) t1 = ntiles;
+  // a workgroup without tiles (short live lists: 390 tiles leave 61 of 256 idle) writes nothing: breduce_kernel sums the
+  // partials of the first ceil(ntiles / per) workgroups only
+#if DW_SKIP_IDLE
+  if (t0 >= ntiles) return;
+#endif
 
   f32x16 acc[TO][TI];
 #pragma unroll
@@ -1533,6 +1541,7 @@ __global__ void __launch_bounds__(128) head_grads_bf16_kernel(int64_t P, int64_t
 struct BRedSeg {
   int64_t src, wg_stride, dst;
   int nwg, rows, cols, ld, valid_cols, perm;
+  int dw;   // partials of a dW job: only the workgroups that had tiles wrote theirs
 };
 #define BMAX_SEGS 32
 struct BRedTable {
@@ -1542,8 +1551,15 @@ struct BRedTable {
 __host__ __device__ inline int b_unperm(int q) { return (q & ~63) + 2 * (q & 31) + ((q >> 5) & 1); }
 
 __global__ void __launch_bounds__(256) breduce_kernel(BRedTable tab, const float* __restrict__ partial,
-                                                       float* __restrict__ grads) {
-  const BRedSeg sg = tab.s[blockIdx.y];
+                                                       float* __restrict__ grads, int64_t ntiles, const int* __restrict__ live_cnt) {
+  BRedSeg sg = tab.s[blockIdx.y];
+#if DW_SKIP_IDLE
+  if (sg.dw) {   // the dW workgroups that had tiles: the first ceil(ntiles / per), per = ceil(ntiles / nwg) (mlp_bwd_dw_lds_bf16_kernel)
+    if (live_cnt) ntiles = ((int64_t)*live_cnt + BTM - 1) / BTM;
+    const int64_t per = (ntiles + sg.nwg - 1) / sg.nwg;
+    sg.nwg = per > 0 ? (int)((ntiles + per - 1) / per) : 0;
+  }
+#endif
   const int64_t total = (int64_t)sg.rows * sg.cols;
   const float* src = partial + sg.src;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1557,7 +1573,11 @@ __global__ void __launch_bounds__(256) breduce_kernel(BRedTable tab, const float
 #pragma unroll
       for (int i = 0; i < 8; ++i) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
     }
-    for (; w < sg.nwg; ++w) a[0] += src[(int64_t)w * sg.wg_stride + e];
+    // tail: partial w still goes to running sum w % 8, so that leaving out workgroups that wrote nothing (exact zeros) does not
+    // change a single bit of the result
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (w + i < sg.nwg) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
     grads[sg.dst + (int64_t)r * sg.ld + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
 }
@@ -1608,10 +1628,10 @@ static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, cons
 }
 
 static void b_add_seg(BRedTable& T, int64_t src, int64_t wg_stride, int nwg, int rows, int cols, int64_t dst, int ld,
-                      int valid_cols, int perm) {
+                      int valid_cols, int perm, int dw = 0) {
   BRedSeg& s = T.s[T.n++];
   s.src = src; s.wg_stride = wg_stride; s.nwg = nwg; s.rows = rows; s.cols = cols; s.dst = dst; s.ld = ld;
-  s.valid_cols = valid_cols; s.perm = perm;
+  s.valid_cols = valid_cols; s.perm = perm; s.dw = dw;
 }
 
 static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const float* act_f, const float* params,
@@ -1658,10 +1678,10 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
   auto segs = [&](int j, int64_t dstW, int ld, int validc, int permW, int64_t dstB, int64_t dstR) {
     const BJob d = b_job(j, PEP);
     const int64_t b = b_job_base(j, ncu, PEP);
-    b_add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc, permW);
+    b_add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc, permW, 1);
     int64_t o = b + (int64_t)nwg * d.NO * d.KI;
-    if (d.bias) { b_add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO, (permW & 1) ? 2 : 0); o += (int64_t)nwg * d.NO; }
-    if (d.rank1) b_add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI, (permW & 2));
+    if (d.bias) { b_add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO, (permW & 1) ? 2 : 0, 1); o += (int64_t)nwg * d.NO; }
+    if (d.rank1) b_add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI, (permW & 2), 1);
   };
   const uint4* a_pe = act + ba_pe(nt);
   // L0
@@ -1697,7 +1717,7 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
     b_add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387, 0);   // dWr (384) + dbr (3), contiguous in every layout
     b_add_seg(T, hb + 387, 388, hg, 1, 1, L.AB, 1, 1, 0);   // dba
   }
-  hipLaunchKernelGGL(breduce_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
+  hipLaunchKernelGGL(breduce_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads, nt, live_cnt);
   FN_LAUNCH_CHECK();
   return 0;
 }

@@ -1,7 +1,7 @@
 """Run-to-run reproducibility: the same 150 optimisation steps (4096 rays, 64+128 samples, fixed seeds) twice in one
 process and report whether parameters and losses are bit-identical; also scans every step's loss for non-finite values."""
 import sys, hashlib, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import fastnerf as fn
 from fastnerf import ops
 H = W = 200
