@@ -17,6 +17,25 @@ F = C.c_float
 D = C.c_double
 U64 = C.c_uint64
 
+
+
+class StepArgs(C.Structure):
+    """fn_step_args of include/fastnerf.h, field for field."""
+    _fields_ = (
+        [('n', L)] + [(k, P) for k in ('rays_o', 'rays_d', 'target', 't_rand', 'u', 'noise0', 'noise1')]
+        + [('seed0', U64), ('seed1', U64), ('leaf_tag', P), ('table', P), ('net_floats', L)]
+        + [(k, P) for k in ('params', 'grads', 'adam_m', 'adam_v', 'packed_fwd_c', 'packed_bwd_c', 'packed_fwd_f', 'packed_bwd_f',
+                            'rays11', 'z0', 'raw0', 'act0', 'rgb0', 'disp0', 'acc0', 'w0', 'depth0',
+                            'z1', 'z_samples', 'z_std', 'raw1', 'act1', 'rgb1', 'disp1', 'acc1', 'w1', 'depth1',
+                            'g_rgb', 'g_rgb0', 'loss2', 'draw_ws', 'act_ws', 'dact_ws', 'partial_ws', 'live_ws', 'counts')]
+        + [(k, D) for k in ('focal', 'lr', 'beta1', 'beta2', 'eps')]
+        + [(k, F) for k in ('near_plane', 'far_plane', 'grad_scale')]
+        + [(k, I) for k in ('math_mode', 'N_samples', 'N_importance', 'lindisp', 'perturb', 'white_bkgd', 'ndc', 'H', 'W', 'live',
+                            'fwd_flags', 'max_leaves', 'adam_t')])
+
+
+STEP_FORWARD, STEP_BWD_FINE, STEP_BWD_COARSE, STEP_UPDATE = 1, 2, 4, 8
+
 # name -> (restype, argtypes); mirrors include/fastnerf.h one to one
 SIGNATURES = {
     'fastnerf_version': (I, []),
@@ -79,6 +98,8 @@ SIGNATURES = {
     'fastnerf_mlp_fwd_live_ex': (I, [I, L, I, P, P, P, P, P, P, P, P]),
     'fastnerf_mlp_bwd_live_ex': (I, [I, L, I, P, P, P, P, P, P, P, P, P, P]),
     'fastnerf_render_rays_bwd_live': (I, [I, L, I, I, P, I] + [P] * 22 + [P]),
+    'fastnerf_step_args_size': (L, []),
+    'fastnerf_train_step': (I, [C.POINTER(StepArgs), I, P]),
 }
 
 _lib = None
@@ -97,6 +118,8 @@ def lib():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if l.fastnerf_step_args_size() != C.sizeof(StepArgs):
+            raise RuntimeError('fn_step_args: the ctypes mirror does not match the library (stale libfastnerf.so?)')
         _lib = l
     return _lib
 

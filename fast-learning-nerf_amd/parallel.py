@@ -45,6 +45,21 @@ def all_reduce_sum(flat):
     return flat
 
 
+def all_reduce_sum_async(flat):
+    """Start all-reduce(SUM) of a contiguous slice of the gradient buffer and return its work handle: with the RCCL backend
+    the collective runs on the process group's own stream behind everything enqueued on the current stream so far, beside
+    whatever the caller enqueues next; `wait_all` orders the current stream behind it."""
+    if world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def wait_all(*works):
+    for w in works:
+        if w is not None:
+            w.wait()
+
+
 def all_reduce_max_int(table_i32):
     """MAX over ranks of the leaf-error table stored as the int32 bit patterns of non-negative
     floats (monotone in the float value) -> exact and order independent."""

@@ -8,6 +8,7 @@ run_nerf.py:479-508) that the benchmark and `train()` use; the autograd-compatib
 Dataset readers / CLI parsing are out of scope; `train()` takes
 in-memory images + poses.
 """
+import ctypes
 import math
 import os
 import time
@@ -15,9 +16,9 @@ import time
 import numpy as np
 import torch
 
-from . import ops, parallel
+from . import _lib, ops, parallel
 from .model import NeRF, noview_slices
-from .render import LivePolicy, _backward_core, _forward_core, render, render_path  # noqa: F401
+from .render import LivePolicy, _Workspace, _backward_core, _forward_core, _next_seed, render, render_path  # noqa: F401
 from .run_nerf_helpers import get_embedder, img2mse, mse2psnr
 from .tree import QuadTreeManager
 
@@ -138,6 +139,65 @@ def create_nerf(args, device='cuda'):
     return render_kwargs_train, render_kwargs_test, start_epoch, start_iter, grad_vars, optimizer
 
 
+class _StepOut:
+    """The tensors of one fused step as a read-only mapping with the keys of render_rays' output dict (plus the extras the
+    fused Trainer has always returned); views into the step's output block are built on first access."""
+
+    def __init__(self, block, regions, names):
+        self._block, self._regions, self._names, self._cache = block, regions, names, {}
+
+    def __getitem__(self, key):
+        t = self._cache.get(key)
+        if t is None:
+            off, shape = self._regions[self._names[key]]
+            n = 1
+            for d in shape:
+                n *= d
+            t = self._cache[key] = self._block[off:off + n].view(shape)
+        return t
+
+    def __contains__(self, key):
+        return key in self._names
+
+    def get(self, key, default=None):
+        return self[key] if key in self._names else default
+
+    def keys(self):
+        return self._names.keys()
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+
+def _step_regions(n, S0, Ni):
+    """name -> (offset, shape) of the per-step tensors inside one fp32 block (every region starts on a 256-byte boundary),
+    and the block's size."""
+    S1 = S0 + Ni
+    shapes = [('rays11', (n, 11)), ('z0', (n, S0)), ('raw0', (n, S0, 4)), ('rgb0', (n, 3)), ('disp0', (n,)), ('acc0', (n,)),
+              ('w0', (n, S0)), ('depth0', (n,)), ('g_rgb', (n, 3)), ('loss2', (2,))]
+    if Ni > 0:
+        shapes += [('z1', (n, S1)), ('z_samples', (n, Ni)), ('z_std', (n,)), ('raw1', (n, S1, 4)), ('rgb1', (n, 3)),
+                   ('disp1', (n,)), ('acc1', (n,)), ('w1', (n, S1)), ('depth1', (n,)), ('g_rgb0', (n, 3))]
+    regions, off = {}, 0
+    for name, shape in shapes:
+        cnt = 1
+        for d in shape:
+            cnt *= d
+        regions[name] = (off, shape)
+        off += (cnt + 63) // 64 * 64
+    return regions, off
+
+
+_OUT_NAMES_2 = {'rgb_map': 'rgb1', 'disp_map': 'disp1', 'acc_map': 'acc1', 'raw': 'raw1', 'rgb0': 'rgb0', 'disp0': 'disp0',
+                'acc0': 'acc0', 'z_std': 'z_std', 'weights': 'w1', 'z_vals': 'z1', 'depth_map': 'depth1',
+                'z_samples': 'z_samples', 'weights0': 'w0', 'z0': 'z0'}
+_OUT_NAMES_1 = {'rgb_map': 'rgb0', 'disp_map': 'disp0', 'acc_map': 'acc0', 'raw': 'raw0', 'weights': 'w0', 'z_vals': 'z0',
+                'depth_map': 'depth0'}
+
+
 class Trainer:
     """Fused optimisation step over rays sharded across ranks (one process per GPU).
 
@@ -173,6 +233,13 @@ class Trainer:
         self.skip_dead_rgb = True
         self.live_counts = torch.zeros(4, device=self.flat.device, dtype=torch.int32)
         self.last_step_live = False
+        # one C-ABI call per step (fastnerf_train_step) instead of ~10 calls and ~25 allocations: two distinct nets with view
+        # directions (or a single pass).  FASTNERF_FUSED_STEP=0 keeps the call-by-call sequencing (same kernels, same bits).
+        self.fused = (os.environ.get('FASTNERF_FUSED_STEP', '1') != '0' and self.use_viewdirs
+                      and (self.N_importance == 0 or (self.net_f is not None and self.net_f is not self.net_c)))
+        self.overlap_allreduce = os.environ.get('FASTNERF_OVERLAP_ALLREDUCE', '1') != '0'
+        self._sa = None          # fn_step_args of the fused path
+        self._sa_key = None
         self.repack()
 
     def repack(self):
@@ -208,19 +275,151 @@ class Trainer:
         self.last_step_live = live
         return loss2, out
 
+    # ---- fused route: one fastnerf_train_step call per phase group ------------------------------------------------
+    def _fused_prepare(self, rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global):
+        """Fill fn_step_args for this batch; returns (args, out mapping, loss2, live)."""
+        n = rays_o.shape[0]
+        dev = rays_o.device
+        S0, Ni = self.N_samples, self.N_importance
+        S1 = S0 + Ni
+        P0, P1 = n * S0, n * S1
+        ops.require_gpu(rays_o, rays_d, target, leaf_tag, table, t_rand, u)
+        tag = 'bf16x3' if ops.get_math() == 'bf16x3' else 'fp32'
+        if getattr(self.pc[0], '_fn_math', None) != tag:
+            self.repack()           # the math mode changed under this trainer
+            self._sa_key = None
+        live = self.live.use_live(self.net_c, self.net_f, Ni)
+        key = (n, str(dev), torch.cuda.current_stream(dev).cuda_stream, tag)
+        a = self._sa
+        if a is None or self._sa_key != key:
+            a = self._sa = _lib.StepArgs()
+            self._sa_key = key
+            self._regions, self._block_floats = _step_regions(n, S0, Ni)
+            a.n, a.net_floats = n, ops.NET_PARAMS
+            a.math_mode = 1 if tag == 'bf16x3' else 0
+            a.N_samples, a.N_importance, a.lindisp, a.perturb = S0, Ni, int(bool(self.lindisp)), int(bool(self.perturb))
+            a.white_bkgd, a.ndc, a.H, a.W = int(bool(self.white_bkgd)), int(bool(self.ndc)), int(self.H), int(self.W)
+            a.focal, a.near_plane, a.far_plane = float(self.K[0][0]), float(self.near), float(self.far)
+            a.beta1, a.beta2, a.eps = self.beta1, self.beta2, self.eps
+            a.params, a.grads, a.adam_m, a.adam_v = self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
+            a.packed_fwd_c, a.packed_bwd_c = self.pc[0].data_ptr(), self.pc[1].data_ptr()
+            if Ni > 0:
+                a.packed_fwd_f, a.packed_bwd_f = self.pf[0].data_ptr(), self.pf[1].data_ptr()
+            # scratch of this (device, stream), shared with the call-by-call route (render._Workspace)
+            ws = _Workspace.dact(dev, ops.dact_floats(P1) + P1 * 4)
+            a.dact_ws = ws.data_ptr()
+            a.draw_ws = ws.data_ptr() + 4 * ops.dact_floats(P1)
+            a.partial_ws = _Workspace.partial(dev).data_ptr()
+            a.counts = self.live_counts.data_ptr()
+            self._keep = [ws]
+        # the big buffers of the route this step takes (allocated on first use: a run that never falls back to the plain
+        # backward never pays for its 11 GB of saved activations)
+        if live:
+            if not a.act_ws:
+                t1 = _Workspace.get('act', dev, ops.act_floats(P1))
+                t2 = _Workspace.get('live', dev, ops.live_ws_ints(P1), torch.int32)
+                a.act_ws, a.live_ws = t1.data_ptr(), t2.data_ptr()
+                self._keep += [t1, t2]
+        elif not a.act0:
+            t1 = _Workspace.get('act0', dev, ops.act_floats(P0))
+            a.act0 = t1.data_ptr()
+            self._keep.append(t1)
+            if Ni > 0:
+                t2 = _Workspace.get('act1', dev, ops.act_floats(P1))
+                a.act1 = t2.data_ptr()
+                self._keep.append(t2)
+        block = torch.empty(self._block_floats, device=dev, dtype=torch.float32)
+        base = block.data_ptr()
+        for name, (off, _) in self._regions.items():
+            setattr(a, name, base + 4 * off)
+        ro, rd, tg = ops._f32(rays_o).reshape(-1, 3), ops._f32(rays_d).reshape(-1, 3), ops._f32(target)
+        a.rays_o, a.rays_d, a.target = ro.data_ptr(), rd.data_ptr(), tg.data_ptr()
+        hold = [ro, rd, tg]
+        if t_rand is not None:
+            t_rand = ops._f32(t_rand)
+            assert t_rand.shape == (n, S0)
+            hold.append(t_rand)
+        if u is not None:
+            u = ops._f32(u)
+            assert u.shape == (n, Ni)
+            hold.append(u)
+        a.t_rand = None if t_rand is None else t_rand.data_ptr()
+        a.u = None if u is None else u.data_ptr()
+        noise0 = noise1 = None
+        if self.raw_noise_std > 0.:
+            noise0 = torch.randn(n, S0, device=dev) * self.raw_noise_std
+            noise1 = torch.randn(n, S1, device=dev) * self.raw_noise_std
+            hold += [noise0, noise1]
+        a.noise0 = None if noise0 is None else noise0.data_ptr()
+        a.noise1 = None if noise1 is None else noise1.data_ptr()
+        # (the same draws, in the same order, as the call-by-call route: render._forward_core)
+        a.seed0 = _next_seed() if (self.perturb and t_rand is None) else 0
+        a.seed1 = _next_seed() if (Ni > 0 and self.perturb and u is None) else 0
+        if leaf_tag is not None:
+            leaf_tag = leaf_tag.contiguous()
+            hold.append(leaf_tag)
+        a.leaf_tag = None if leaf_tag is None else leaf_tag.data_ptr()
+        a.table = None if table is None else table.data_ptr()
+        a.max_leaves = int(max_leaves)
+        a.grad_scale = 1.0 if n_global is None else float(n) / float(n_global)
+        a.live = int(live)
+        a.fwd_flags = 1 if (live and self.skip_dead_rgb and noise0 is None) else 0
+        self._hold = hold       # inputs stay referenced until the next step is prepared (the launches are asynchronous)
+        out = _StepOut(block, self._regions, _OUT_NAMES_2 if Ni > 0 else _OUT_NAMES_1)
+        loss2 = block[self._regions['loss2'][0]:self._regions['loss2'][0] + 2]
+        return a, out, loss2, live
+
+    def _fused_call(self, a, phases):
+        _lib.check(_lib.lib().fastnerf_train_step(ctypes.byref(a), int(phases), _lib.stream()), 'fastnerf_train_step')
+
+    def _after_backward(self, live):
+        if live:
+            self.live.after_live_step(self.live_counts)
+        self.live.tick()
+        self.last_step_live = live
+
     def step(self, rays_o, rays_d, target, leaf_tag=None, table=None, max_leaves=0, t_rand=None, u=None,
              n_global=None, decay=None):
-        if rays_o.shape[0] == 0:
-            # a rank whose shard of a (tail) batch is empty still joins the collective with a zero gradient
-            self.grad.zero_()
-            loss2, out = torch.zeros(2, device=self.grad.device), {}
-        else:
-            loss2, out = self.forward_backward(rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global)
-        if self.world > 1:
-            parallel.all_reduce_sum(self.grad)
+        n = rays_o.shape[0]
+        Nn = ops.NET_PARAMS
+        two = self.N_importance > 0 and self.net_f is not None and self.net_f is not self.net_c
+        overlap = self.world > 1 and two and self.overlap_allreduce and self.grad.numel() == 2 * Nn
+        fused = self.fused and n > 0
         self.adam_t += 1
-        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.adam_t, self.beta1, self.beta2, self.eps)
-        self.repack()
+        if fused:
+            a, out, loss2, live = self._fused_prepare(rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global)
+            a.lr, a.adam_t = float(self.lr), int(self.adam_t)
+            if self.world == 1:
+                self._fused_call(a, _lib.STEP_FORWARD | _lib.STEP_BWD_FINE | _lib.STEP_BWD_COARSE | _lib.STEP_UPDATE)
+                self._after_backward(live)
+            else:
+                # data parallel: the fine net's gradient (the second half of the flat buffer) is final after the fine pass and is
+                # all-reduced while the coarse pass's backward runs (the collective has its own stream; `wait` orders ours behind it)
+                if overlap:
+                    self._fused_call(a, _lib.STEP_FORWARD | _lib.STEP_BWD_FINE)
+                    w1 = parallel.all_reduce_sum_async(self.grad[Nn:])
+                    self._fused_call(a, _lib.STEP_BWD_COARSE)
+                    w0 = parallel.all_reduce_sum_async(self.grad[:Nn])
+                    parallel.wait_all(w1, w0)
+                else:
+                    self._fused_call(a, _lib.STEP_FORWARD | _lib.STEP_BWD_FINE | _lib.STEP_BWD_COARSE)
+                    parallel.all_reduce_sum(self.grad)
+                self._after_backward(live)
+                self._fused_call(a, _lib.STEP_UPDATE)
+        else:
+            if n == 0:
+                # a rank whose shard of a (tail) batch is empty still joins the collective with a zero gradient
+                self.grad.zero_()
+                loss2, out = torch.zeros(2, device=self.grad.device), {}
+            else:
+                loss2, out = self.forward_backward(rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global)
+            if self.world > 1:
+                if overlap:   # same two collectives as the fused route, so that every rank issues the same sequence
+                    parallel.wait_all(parallel.all_reduce_sum_async(self.grad[Nn:]), parallel.all_reduce_sum_async(self.grad[:Nn]))
+                else:
+                    parallel.all_reduce_sum(self.grad)
+            ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.adam_t, self.beta1, self.beta2, self.eps)
+            self.repack()
         if (self.decay if decay is None else decay):
             self.lr = self.lrate * (0.1 ** (self.global_iter / (self.lrate_decay * 1000)))
             self.global_iter += 1

@@ -303,6 +303,49 @@ int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N
                                   float* draw_ws, float* act_ws, float* dact_ws, float* partial_ws, int32_t* live_ws,
                                   float* grads_c, float* grads_f, int32_t* counts_out, fn_stream_t stream);
 
+/* ---- one optimisation step per call (run_nerf.py:479-508: render -> img2mse fine + coarse -> loss.backward() ->
+ * optimizer.step(), the epoch loss map of :505-506 fed inside the loss launch) ----------------------------------------
+ * fastnerf_train_step enqueues the phases selected by `phases` on `stream`, using exactly the entry points above in the
+ * order the reference's loop implies, so its results are bit-identical to calling them one by one; what it removes is
+ * host work (one call instead of ~10 and no per-step allocations: the caller keeps every buffer alive in `args`).
+ * Data parallel: FN_STEP_FORWARD | FN_STEP_BWD_FINE, then the caller starts the all-reduce of the fine net's gradient
+ * (grads + net_floats) on a side stream, FN_STEP_BWD_COARSE runs beside it, all-reduce of the coarse half, FN_STEP_UPDATE.
+ * Two distinct NeRF nets with view directions (or one net when N_importance == 0); coarse net first in params / grads /
+ * adam_m / adam_v (the order of `grad_vars`, run_nerf.py:87-97).  Buffer shapes are those of the individual entry points;
+ * act0 / act1 are used by the plain backward (live == 0), act_ws / live_ws / counts by the compacted one (live != 0). */
+#define FN_STEP_FORWARD 1     /* pack rays, forward, loss + d(loss)/d(rgb maps) + leaf table */
+#define FN_STEP_BWD_FINE 2    /* backward of the fine pass -> grads + net_floats (no-op when N_importance == 0) */
+#define FN_STEP_BWD_COARSE 4  /* backward of the coarse pass -> grads */
+#define FN_STEP_UPDATE 8      /* Adam over both nets + re-pack of their weights */
+typedef struct fn_step_args {
+  /* the batch */
+  int64_t n;
+  const float *rays_o, *rays_d, *target;            /* [n,3] each */
+  const float *t_rand, *u, *noise0, *noise1;        /* injected randoms or NULL (fastnerf_render_rays_fwd) */
+  uint64_t seed0, seed1;
+  const int32_t* leaf_tag;                          /* [n,2] or NULL */
+  uint32_t* table;                                  /* leaf-error table or NULL */
+  /* networks, optimiser state */
+  int64_t net_floats;                               /* FASTNERF_NET_PARAMS */
+  float *params, *grads, *adam_m, *adam_v;          /* (1 or 2) x net_floats */
+  float *packed_fwd_c, *packed_bwd_c, *packed_fwd_f, *packed_bwd_f;
+  /* tensors of the step (outputs of the forward, kept for the backward) */
+  float *rays11, *z0, *raw0, *act0, *rgb0, *disp0, *acc0, *w0, *depth0;
+  float *z1, *z_samples, *z_std, *raw1, *act1, *rgb1, *disp1, *acc1, *w1, *depth1;
+  float *g_rgb, *g_rgb0, *loss2;                    /* [n,3], [n,3], [2] */
+  float *draw_ws, *act_ws, *dact_ws, *partial_ws;   /* scratch, sized as for fastnerf_render_rays_bwd(_live) */
+  int32_t *live_ws, *counts;                        /* compacted backward: scratch, optional int32[4] live / total counts */
+  double focal, lr, beta1, beta2, eps;
+  float near_plane, far_plane, grad_scale;
+  int32_t math_mode;                                /* 0 exact fp32, 1 split-bf16 */
+  int32_t N_samples, N_importance, lindisp, perturb, white_bkgd, ndc, H, W;
+  int32_t live;                                     /* != 0: forward without saving + compacted backward */
+  int32_t fwd_flags;                                /* FN_FWD_* of the first forward of a compacted step */
+  int32_t max_leaves, adam_t;
+} fn_step_args;
+int64_t fastnerf_step_args_size(void);              /* sizeof(fn_step_args): binding sanity check */
+int fastnerf_train_step(const fn_step_args* args, int phases, fn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
