@@ -1,39 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- training rays/s of the MI355X-native NeRF inner loop (BASELINE.json metric).
+"""bench.py -- training rays/s (+ PSNR at equal iterations) of the MI355X-native NeRF inner loop (BASELINE.json metric).
 
-A "step" = one full optimisation step (ray packing -> stratified + hierarchical sampling -> PE ->
-coarse/fine MLP -> compositing -> 2xMSE + per-(image, leaf) error table (atomicMax) -> backward ->
-[RCCL all-reduce] -> Adam + LR decay) on 4096 rays x (64 + 128) samples per GPU, i.e. BASELINE.json
-configs[1] ("nerf-ours Lego full 800x800, 4096 rays, 64+128 samples"): synthetic Lego-like cameras
-(100 x pose_spherical, 800x800, focal 1111.11, near 2 / far 6), quadtree leaf tags of a depth-5 tree
-(256 leaves per image), default-init weights (seed 0).  Inputs are resident in HBM before the timed region.
+A "step" = one full optimisation step of the reference's loop (run_nerf.py:479-508): ray packing -> stratified + hierarchical
+sampling -> PE -> coarse / fine MLP -> compositing -> 2 x MSE + per-(image, leaf) error table (atomicMax) -> backward ->
+[RCCL all-reduce] -> Adam + LR decay, on BASELINE.json configs[1] ("nerf-ours Lego full 800x800, 4096 rays, 64+128 samples").
 
-What the nets are trained on matters since round 2: the backward skips samples whose gradient is EXACTLY zero
-(sigma <= 0: empty space of a radiance field), so throughput depends on where the field puts its density.
-`value` is measured on the analytic Lego-like scene of fastnerf.synthetic: three SOLID coloured bodies (density exactly zero
-beyond 1.5 standard deviations of each blob's centre) on a white background, covering ~30 % of the pixels like the Lego
-bulldozer; targets by quadrature along each batch's rays.  The nets are first optimised from their random initialisation for
---scene-steps (600) untimed steps, then W warm-up and K timed steps follow on the same stream of batches.  On this scene the
-fraction of samples that stay live is STATIONARY from step ~500 on (0.19 fine / 0.08 coarse through 6000 steps,
-tools/live_trajectory.py), so `value` does not depend on when it is measured.  Reported next to it in the same line:
-  * `steady_state_plain`  the same state with the compaction off = the floor, what a field without dead samples costs;
-  * `gaussian_tails_scene`  the same three blobs WITHOUT the cut-off (round-2's first protocol): density that never vanishes.
-    After 300 steps 53 % / 37 % of the samples are live; the fraction then RISES with training (0.72 at 2000 steps, 0.8-0.9 from
-    3500 on: the nets learn the faint tails) and the policy falls back to the plain backward -- the long-run rate on that scene
-    is the floor.  Real scenes sit between the two: how many samples die is a property of the scene and of the training
-    trajectory (a field that explains empty space as thin white fog keeps them all);
-  * `init_state`  the round-1 protocol: random-init nets, U[0,1) noise targets, no scene (84 % live, plain backward).
-The GPU legs import nothing from oracle/; only `cpu_baseline` does.
+`value` follows SURVEY 8(d) to the letter: 100 pose_spherical(-180 + 3.6 k, -30, 4) cameras, 800 x 800, focal 1111.11, near 2 /
+far 6; every batch = 4096 rays drawn uniformly from all 64 M pixels, targets U[0,1)^3 (values do not affect timing), nets at
+their default initialisation (seed 0), perturb = 1, white background, leaf tags of a depth-5 quadtree; the EXACT-fp32 math
+mode (v_mfma_f32_32x32x2_f32: the reference's own arithmetic width) and the PLAIN backward (every sample goes through
+loss.backward(); FASTNERF_COMPACT is forced to 0 for this leg).  Inputs are resident in HBM before the timed region.
 
-  python bench.py --gpus N --steps K --warmup W
+Everything else rides in the same JSON line as named sibling blocks and never feeds `value`:
+  split_bf16_mode    the same protocol in the split-bf16 mode (3 bf16 MFMA products per fp32 product, 16-bit operands: faster and
+                     NARROWER than fp32, hence not the headline), plus that mode on a trained sparse scene with the exact
+                     zero-gradient compaction (what a converged Lego-like field looks like to the backward);
+  drop_in_route      INTEGRATION option A, the reference's loop verbatim (render(); loss.backward(); torch.optim.Adam.step());
+  psnr_vs_cpu        the metric's second half: PSNR after N iterations on the analytic scene, GPU (both modes) vs the CPU
+                     oracle on identical batches / injected randoms (SURVEY 8d "PSNR runs");
+  inference          render()-style rays/s;   cpu_baseline   the CPU oracle timed on this box's host cores.
+
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  The GPU legs import nothing from oracle/; only the CPU legs (cpu_baseline, psnr_vs_cpu.cpu) do.
 """
 import argparse
 import json
-import os
-import sys
 import math
+import os
+import subprocess
+import sys
+import tempfile
 import time
 
 import numpy as np
@@ -43,14 +40,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_RAYS, N_SAMPLES, N_IMPORTANCE = 4096, 64, 128
-SCENE_CUTOFF = 1.5      # solid bodies: density exactly zero beyond 1.5 standard deviations of a blob's centre
+SCENE_CUTOFF = 1.5      # sparse-scene sibling leg: density exactly zero beyond 1.5 standard deviations of a blob's centre
 S1 = N_SAMPLES + N_IMPORTANCE
-MAC_PER_POINT = 593408                     # SURVEY §8(d)
+MAC_PER_POINT = 593408                     # SURVEY 8(d)
 FWD_FLOP_PER_POINT = 2 * MAC_PER_POINT     # 1.186816 MFLOP
+BWD_FLOP_PER_POINT = 2 * (2 * MAC_PER_POINT - 35712)   # dX (without the input-side blocks) + dW
 TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + S1)  # 893.2 MFLOP
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 matrix peak
-PROFILE_ROUND = 'r02'
+PROFILE_ROUND = 'r03'
+H = W = 800
+FOCAL = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+PSNR_ITERS, PSNR_RAYS, PSNR_HELD_OUT = 200, 512, 2048
 
 
 def cpu_model():
@@ -63,16 +64,21 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(protocol='full'):
-    """The CPU oracle (a port of the reference's step, validated against it by tests/) timed on the host cores of this
-    box, SURVEY §8(d) protocol: the identical step (64+128 samples, fp32) at N = 1024 rays, 3 warm-up + 10 timed steps,
-    median, with 32 threads (where torch's CPU GEMMs peak on this box); one step at N = 4096 as a confirmation; a short
-    scan of larger thread counts on 256 rays.  About 65 s in total.  `--cpu-protocol short` = 1 + 3 steps of 256 rays."""
-    from oracle import nerf_oracle as O
+def cpu_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    return avail, max(1, min(avail, 32))   # torch's CPU GEMMs peak at 32 threads on the bench boxes (tools/cpu_threads_probe.py)
+
+
+def cpu_baseline(protocol='full'):
+    """The CPU oracle (a port of the reference's step, validated against it by tests/) timed on the host cores of this
+    box, SURVEY 8(d): the identical step (64+128 samples, fp32) at N = 1024 rays, 2 warm-up + 6 timed steps, median, with 32
+    threads (where torch's CPU GEMMs peak on this box: 64 / 128 / 256 threads measured 0.47x / 0.24x / 0.003x in round 2,
+    tools/cpu_threads_probe.py); one step at N = 4096 as a confirmation.  About 40 s.  `short` = 1 + 3 steps of 256 rays."""
+    from oracle import nerf_oracle as O
+    avail, t32 = cpu_threads()
     gen = torch.Generator().manual_seed(0)
     sdc, sdf = O.init_nerf_params(gen), O.init_nerf_params(gen)
     opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
@@ -93,34 +99,134 @@ def cpu_baseline(protocol='full'):
             times.append(time.time() - t0)
         return n / float(np.median(times[warm:]))
 
-    t32 = max(1, min(avail, 32))
+    base = {'unit': 'rays/s', 'cores': t32, 'kind': 'port', 'cpu': cpu_model(), 'cores_available': avail}
     if protocol == 'short':
-        v = run(256, t32, 1, 3)
-        return {'value': v, 'unit': 'rays/s', 'cores': t32, 'kind': 'port', 'cpu': cpu_model(), 'cores_available': avail,
-                'sample': f'1 warm-up + 3 timed steps of 256 rays x (64+128) samples, median, torch CPU fp32, {t32} threads '
-                          '(oracle/nerf_oracle.py train_step)'}
-    v32 = run(1024, t32, 3, 10)
+        base.update(value=run(256, t32, 1, 3),
+                    sample=f'1 warm-up + 3 timed steps of 256 rays x (64+128) samples, median, torch CPU fp32, {t32} threads '
+                           '(oracle/nerf_oracle.py train_step)')
+        return base
+    v1024 = run(1024, t32, 2, 6)
     v4096 = run(4096, t32, 0, 1)
-    # more threads only lose on this box (tools/cpu_threads_probe.py, round 2: N=1024 315 rays/s with 32 threads, 210 with 64,
-    # 89 with 128; with all 256 hardware threads ONE step takes 52-62 s whatever the ray count -- 16 rays or 64 -- so that
-    # setting is reported from the probe instead of spending three minutes on it in every bench run)
-    scan = {}
-    for th in (64, 128):
-        if avail >= th:
-            scan[f'rays_per_s_{th}_threads_n256'] = run(256, th, 1, 1)
-    best, cores = v32, t32
-    for k, v in scan.items():
-        if v > best:
-            best, cores = v, int(k.split('_')[3])
-    out = {'value': best, 'unit': 'rays/s', 'cores': cores, 'kind': 'port', 'cpu': cpu_model(), 'cores_available': avail,
-           'rays_per_s_32_threads_n1024': v32, 'rays_per_s_32_threads_n4096': v4096}
-    out.update(scan)
-    out['all_hardware_threads'] = ('256 threads: 52-62 s per step at 16 and at 64 rays (~1 ray/s), measured once with '
-                                   'tools/cpu_threads_probe.py on the round-2 bench box; not repeated per run')
-    out['sample'] = (f'SURVEY 8(d): N=1024 rays x (64+128) samples per step, 3 warm-up + 10 timed steps, median, torch CPU fp32 '
-                     f'with {t32} threads; one step at N=4096; 1 + 1 steps of 256 rays with 64 and 128 threads '
-                     '(oracle/nerf_oracle.py train_step); value = the best thread count')
-    return out
+    base.update(value=v1024, rays_per_s_n1024=v1024, rays_per_s_n4096=v4096,
+                more_threads='measured slower in round 2 on this CPU model: 64 threads 0.47x, 128 threads 0.24x, all 256 hardware '
+                             'threads ~1 ray/s (tools/cpu_threads_probe.py); not repeated per run',
+                sample=f'SURVEY 8(d): N=1024 rays x (64+128) samples per step, 2 warm-up + 6 timed steps, median, torch CPU fp32 '
+                       f'with {t32} threads; one step at N=4096 (oracle/nerf_oracle.py train_step)')
+    return base
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PSNR at equal iterations, CPU side (the only other place that touches oracle/): a worker process, so that it runs beside
+# the GPU legs
+# ---------------------------------------------------------------------------------------------------------------------
+def psnr_of(losses, last):
+    return float(-10.0 * np.log10(np.mean(np.asarray(losses[-last:], dtype=np.float64))))
+
+
+def psnr_cpu_worker(in_path, out_path):
+    """Free run of the CPU oracle on the PSNR protocol's inputs; records its state (weights, Adam moments) BEFORE every step
+    in <out_path>.states (float32 [iters + 1, 3, n_params]) for the GPU side's lockstep replay."""
+    from oracle import nerf_oracle as O
+    d = torch.load(in_path)
+    _, t32 = cpu_threads()
+    torch.set_num_threads(t32)
+    sdc, sdf = d['sdc'], d['sdf']
+    params = list(sdc.values()) + list(sdf.values())
+    opt = O.Adam(params, lr=5e-4)
+    n_par = sum(p.numel() for p in params)
+    states = np.lib.format.open_memmap(out_path + '.states', mode='w+', dtype=np.float32, shape=(d['iters'] + 1, 3, n_par))
+
+    def snapshot(i):
+        for j, ts in enumerate((params, opt.m, opt.v)):
+            states[i, j] = torch.cat([t.detach().reshape(-1) for t in ts]).numpy()
+    losses, times = [], []
+    for it in range(d['iters']):
+        snapshot(it)
+        opt.lr = O.lr_schedule(5e-4, 500, it - 1) if it > 0 else 5e-4   # pre-increment rule (run_nerf.py:498-508)
+        rb = O.make_ray_batch(d['ro'][it], d['rd'][it], 2.0, 6.0)
+        t0 = time.time()
+        l1, l0, _, _ = O.train_step(sdc, sdf, opt, rb, d['tgt'][it], N_SAMPLES, N_IMPORTANCE, True, t_rand=d['t_rand'][it], u=d['u'][it])
+        times.append(time.time() - t0)
+        losses.append(float(l1))
+    snapshot(d['iters'])
+    states.flush()
+    with torch.no_grad():   # held-out rays, perturb = 0 (render_kwargs_test)
+        rb = O.make_ray_batch(d['ho_ro'], d['ho_rd'], 2.0, 6.0)
+        mse = 0.0
+        for s in range(0, rb.shape[0], 512):
+            ret = O.render_rays(rb[s:s + 512], sdc, sdf, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)
+            mse += float(((ret['rgb_map'] - d['ho_tgt'][s:s + 512]) ** 2).sum())
+        mse /= rb.shape[0] * 3
+    json.dump({'losses': losses, 'held_out_mse': mse, 'median_step_s': float(np.median(times)), 'threads': t32,
+               'rays_per_s': d['ro'].shape[1] / float(np.median(times))}, open(out_path, 'w'))
+
+
+def psnr_inputs(fastnerf, dev, iters, args, poses, K, draw_pixels):
+    """SURVEY 8(d) "PSNR runs": per iteration PSNR_RAYS uniformly drawn rays of the 100 cameras with the analytic scene's
+    colours as targets, jitter streams t_rand / u from seed 2, default-init nets (seed 0) -- one set, handed to both sides."""
+    from fastnerf import ops, synthetic
+    g = torch.Generator().manual_seed(2)
+    ros, rds, tgts = [], [], []
+    for it in range(iters):
+        ro, rd = ops.gen_rays_pixels(draw_pixels(g, PSNR_RAYS).to(dev), poses, K)
+        ros.append(ro); rds.append(rd); tgts.append(synthetic.render_rays(ro, rd, cutoff=0.0))
+    ho_ro, ho_rd = ops.gen_rays_pixels(draw_pixels(torch.Generator().manual_seed(7), PSNR_HELD_OUT).to(dev), poses, K)
+    torch.manual_seed(0)
+    k0 = fastnerf.run_nerf.create_nerf(args, device=dev)[0]
+    return {'iters': iters, 'ro': torch.stack(ros).cpu(), 'rd': torch.stack(rds).cpu(), 'tgt': torch.stack(tgts).cpu(),
+            't_rand': torch.rand(iters, PSNR_RAYS, N_SAMPLES, generator=g), 'u': torch.rand(iters, PSNR_RAYS, N_IMPORTANCE, generator=g),
+            'ho_ro': ho_ro.cpu(), 'ho_rd': ho_rd.cpu(), 'ho_tgt': synthetic.render_rays(ho_ro, ho_rd, cutoff=0.0).cpu(),
+            'sdc': {k: v.detach().cpu().clone() for k, v in k0['network_fn'].state_dict().items()},
+            'sdf': {k: v.detach().cpu().clone() for k, v in k0['network_fine'].state_dict().items()}}
+
+
+def psnr_gpu_free(fastnerf, dd, new_trainer, K, mode, jitter_ulp_seed=None):
+    """One free GPU run of the protocol in `mode`.  jitter_ulp_seed: perturb every initial weight by a random -1 / 0 / +1 ulp
+    (the ensemble that measures how far apart two runs of the SAME arithmetic class end up: trajectories are chaotic)."""
+    from fastnerf import ops
+    ops.set_math(mode)
+    fastnerf.render.set_compact('0')
+    tr, _, kt, _ = new_trainer()
+    if jitter_ulp_seed is not None:
+        g = torch.Generator(device=tr.flat.device).manual_seed(jitter_ulp_seed)
+        with torch.no_grad():
+            bits = tr.flat.view(torch.int32)
+            bits += torch.randint(-1, 2, bits.shape, generator=g, device=bits.device, dtype=torch.int32)
+        tr.repack()
+    ls = []
+    for it in range(dd['iters']):
+        ls.append(tr.step(dd['ro'][it], dd['rd'][it], dd['tgt'][it], t_rand=dd['t_rand'][it], u=dd['u'][it])[0][0])
+    ls = torch.stack(ls).cpu().numpy().tolist()
+    with torch.no_grad():
+        rgb = fastnerf.render.render(H, W, K, chunk=PSNR_HELD_OUT, rays=(dd['ho_ro'], dd['ho_rd']), near=2.0, far=6.0, **kt)[0]
+        mse = float(torch.mean((rgb - dd['ho_tgt']) ** 2))
+    return {'train_psnr_db': psnr_of(ls, 20), 'held_out_psnr_db': -10.0 * math.log10(mse), 'first_loss': ls[0], 'last_loss': ls[-1]}, ls
+
+
+def psnr_gpu_lockstep(fastnerf, dd, new_trainer, states, cpu_losses, mode):
+    """The GPU step from the CPU oracle's state, iteration by iteration (weights and Adam moments taken over before every step):
+    the same PSNR number without the trajectory divergence -- what is left is the per-step arithmetic difference."""
+    from fastnerf import ops
+    ops.set_math(mode)
+    fastnerf.render.set_compact('0')
+    tr, _, _, _ = new_trainer()
+    dev = tr.flat.device
+    ls, upd = [], []
+    for it in range(dd['iters']):
+        st = torch.from_numpy(np.ascontiguousarray(states[it])).to(dev)
+        with torch.no_grad():
+            tr.flat.copy_(st[0]); tr.m.copy_(st[1]); tr.v.copy_(st[2])
+        tr.adam_t = it
+        tr.lr = 5e-4 * (0.1 ** ((it - 1) / (500 * 1000))) if it > 0 else 5e-4
+        tr.repack()
+        ls.append(tr.step(dd['ro'][it], dd['rd'][it], dd['tgt'][it], t_rand=dd['t_rand'][it], u=dd['u'][it], decay=False)[0][0])
+        if it % 10 == 5:   # the update itself against the CPU's (Adam's g / (|g| + 1e-8) amplifies noise on ~zero gradients: L2, not max)
+            nxt = torch.from_numpy(np.ascontiguousarray(states[it + 1][0])).to(dev)
+            upd.append(float((tr.flat - nxt).norm() / (nxt - st[0]).norm()))
+    ls = torch.stack(ls).cpu().numpy()
+    cl = np.asarray(cpu_losses)
+    return {'train_psnr_db': psnr_of(ls.tolist(), 20), 'max_rel_loss_diff': float(np.max(np.abs(ls - cl) / cl)),
+            'max_rel_update_diff_l2': max(upd) if upd else None}
 
 
 def time_launch(fn_, reps):
@@ -142,11 +248,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--sustained-steps', type=int, default=400)
-    ap.add_argument('--scene-steps', type=int, default=600, help='untimed optimisation steps on the analytic scene before W + K')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='weak: 4096 rays per GPU per step; strong: 4096 rays per step split over the GPUs')
+    ap.add_argument('--sustained-steps', type=int, default=150)
+    ap.add_argument('--scene-steps', type=int, default=600, help='untimed optimisation steps of the sparse-scene sibling leg')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip both CPU legs (cpu_baseline, psnr_vs_cpu.cpu)')
+    ap.add_argument('--no-siblings', action='store_true', help='headline + roofline only')
     ap.add_argument('--cpu-protocol', choices=['full', 'short'], default='full')
+    ap.add_argument('--psnr-iters', type=int, default=PSNR_ITERS)
+    ap.add_argument('--psnr-cpu-worker', nargs=2, metavar=('IN', 'OUT'), help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.psnr_cpu_worker:
+        return psnr_cpu_worker(*a.psnr_cpu_worker)
 
     import fastnerf
     from fastnerf import ops, parallel, synthetic
@@ -156,52 +269,66 @@ def main():
     local = local % max(1, torch.cuda.device_count())   # (only differs in single-GPU plumbing tests of the N>1 path)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    n_local = N_RAYS if a.scaling == 'weak' else N_RAYS // world      # rays per rank per step
+    n_step = n_local * world                                          # rays per step, whole job
+    siblings = rank == 0 and world == 1 and not a.no_siblings
 
     args = fastnerf.run_nerf.make_args(N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, perturb=1.0, white_bkgd=True,
-                                       no_reload=True, lrate=5e-4, lrate_decay=500)
-    H = W = 800
-    focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
-    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+                                       no_reload=True, lrate=5e-4, lrate_decay=500, N_rand=n_local)
+    K = np.array([[FOCAL, 0, 0.5 * W], [0, FOCAL, 0.5 * H], [0, 0, 1]])
     n_img, max_leaves = 100, 256
     poses = torch.stack([pose_spherical(-180.0 + 3.6 * k, -30.0, 4.0)[:3, :4] for k in range(n_img)], 0).to(dev)
+
+    def draw_pixels(gen, n):
+        return torch.stack([torch.randint(0, n_img, (n,), generator=gen), torch.randint(0, H, (n,), generator=gen),
+                            torch.randint(0, W, (n,), generator=gen)], 1).int()
+
+    # ---- PSNR protocol inputs first, so that the CPU side can start right away and run beside the GPU legs ----------------
+    psnr_proc = psnr_in = psnr_out = None
+    psnr_data = None
+    if siblings and a.psnr_iters > 0:
+        psnr_data = psnr_inputs(fastnerf, dev, a.psnr_iters, args, poses, K, draw_pixels)
+        if not a.no_cpu_baseline:
+            tmp = tempfile.mkdtemp(prefix='fastnerf_psnr_')
+            psnr_in, psnr_out = os.path.join(tmp, 'in.pt'), os.path.join(tmp, 'out.json')
+            torch.save(psnr_data, psnr_in)
+            psnr_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--psnr-cpu-worker', psnr_in, psnr_out],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, cwd=ROOT)
+
+    # ---- throughput batches: uniformly drawn rays, U[0,1) targets (+ the analytic scene's colours for the sibling legs) ----
     gen = torch.Generator().manual_seed(1000 + rank)
-    n_batches = 64          # 262 144 distinct rays per rank, cycled
-    batches = []            # (rays_o, rays_d, scene colour, noise colour, leaf tag)
+    n_batches = 64          # 262 144 distinct rays per rank at 4096 rays per step, cycled
+    batches = []            # (rays_o, rays_d, {targets}, leaf tag)
     for _ in range(n_batches):
-        pix = torch.stack([torch.randint(0, n_img, (N_RAYS,), generator=gen), torch.randint(0, H, (N_RAYS,), generator=gen),
-                           torch.randint(0, W, (N_RAYS,), generator=gen)], 1).int()
+        pix = draw_pixels(gen, n_local)
         ro, rd = ops.gen_rays_pixels(pix.to(dev), poses, K)
         # (image, leaf) tags of a depth-5 quadtree: 16 x 16 leaves of 50 x 50 pixels, DFS order irrelevant for timing
         tag = torch.stack([pix[:, 0], (pix[:, 1] // 50) * 16 + pix[:, 2] // 50], 1).int().to(dev).contiguous()
-        batches.append((ro, rd, {'solid': synthetic.render_rays(ro, rd, cutoff=SCENE_CUTOFF).contiguous(),
-                                 'soft': synthetic.render_rays(ro, rd, cutoff=0.0).contiguous(),
-                                 'noise': torch.rand(N_RAYS, 3, generator=gen).to(dev)}, tag))
-    # silhouette of the solid scene: share of this rank's rays that hit a body (colour differs from the white background)
-    coverage = float(torch.cat([(b[2]['solid'] < 0.999).any(-1) for b in batches]).float().mean())
+        tg = {'noise': torch.rand(n_local, 3, generator=gen).to(dev)}
+        if siblings:
+            tg['solid'] = synthetic.render_rays(ro, rd, cutoff=SCENE_CUTOFF).contiguous()
+        batches.append((ro, rd, tg, tag))
     table = torch.zeros(n_img * max_leaves, device=dev, dtype=torch.int32)
-    n_global = N_RAYS * world if world > 1 else None
+    n_global = n_step if world > 1 else None
 
     def new_trainer():
         torch.manual_seed(0)   # identical initial weights on every rank, and for every leg
-        k_train, k_test, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
-        return fastnerf.run_nerf.Trainer(k_train, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500), k_test
+        k_train, k_test, _, _, grad_vars, _ = fastnerf.run_nerf.create_nerf(args, device=dev)
+        return fastnerf.run_nerf.Trainer(k_train, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500), k_train, k_test, grad_vars
 
-    n_opt = {}              # optimisation steps applied per trainer (for the PSNR@iterations figure)
-
-    def step(trainer, i, scene='solid'):
-        n_opt[id(trainer)] = n_opt.get(id(trainer), 0) + 1
+    def step(trainer, i, scene='noise'):
         ro, rd, tgts, tag = batches[i % n_batches]
         return trainer.step(ro, rd, tgts[scene], leaf_tag=tag, table=table, max_leaves=max_leaves, n_global=n_global)
 
-    def timed(trainer, first, warm, steps, scene='solid'):
+    def timed(step_fn, first, warm, steps):
         """W warm-up + K timed steps, barrier + synchronize on both sides, MAX over ranks -> (seconds, last loss, local s)."""
         for i in range(warm):
-            step(trainer, first + i, scene)
+            step_fn(first + i)
         parallel.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            loss2, _ = step(trainer, first + warm + i, scene)
+            loss2 = step_fn(first + warm + i)
         torch.cuda.synchronize()
         t_local = time.perf_counter() - t0
         parallel.barrier()
@@ -211,112 +338,47 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t[0]), loss2, t_local
 
-    # ---- the solid-body scene: untimed optimisation from random init, then W + K (`value`) ----
-    tr, kte = new_trainer()
-    for i in range(a.scene_steps):
-        step(tr, i)
-    dt, loss2, t_local = timed(tr, a.scene_steps, a.warmup, a.steps)
-    per_rank_ms = [1e3 * t_local / a.steps]
-    allreduce_ms = None
-    if world > 1:
-        tl = torch.tensor([1e3 * t_local / a.steps], device=dev, dtype=torch.float64)
-        gathered = [torch.zeros_like(tl) for _ in range(world)]
-        torch.distributed.all_gather(gathered, tl)
-        per_rank_ms = [float(g[0]) for g in gathered]
-        # the step's only data-path collective, timed alone: all-reduce(SUM) of the flat gradient (4.77 MB)
-        allreduce_ms = time_launch(lambda: parallel.all_reduce_sum(tr.grad), 20)
-    live_frac = None
-    if tr.last_step_live:
-        c = tr.live_counts.cpu().tolist()
-        live_frac = {'fine': c[0] / max(1, c[1]), 'coarse': c[2] / max(1, c[3])}
-    backward_kind = 'compacted' if tr.last_step_live else 'plain'
+    def leg(seconds, steps, **kw):
+        d = {'ms_per_step': 1e3 * seconds / steps, 'value': n_step * steps / seconds, 'unit': 'rays/s', 'steps': steps}
+        d.update(kw)
+        return d
 
-    # ---- sustained leg: the same stream of steps for >= 400 more steps (power-managed clocks settle within seconds) ----
-    sustained = None
-    if a.sustained_steps > 0:
-        ts, _, _ = timed(tr, a.scene_steps + a.warmup + a.steps, 0, a.sustained_steps)
-        sustained = {'steps': a.sustained_steps, 'ms_per_step': 1e3 * ts / a.sustained_steps,
-                     'value': N_RAYS * world * a.sustained_steps / ts, 'unit': 'rays/s', 'seconds': ts}
-
-    # ---- the same state with the compaction switched off (every point goes through the backward) ----
-    old_mode = fastnerf.render.get_compact()
-    fastnerf.render.set_compact('0')
-    try:
-        tp, _, _ = timed(tr, 7, 6, 20)   # (the first plain steps allocate the 11 GB of saved activations: keep them out of the timed 20)
-    finally:
-        fastnerf.render.set_compact(old_mode)
-    steady_plain = {'ms_per_step': 1e3 * tp / 20, 'value': N_RAYS * world * 20 / tp, 'unit': 'rays/s', 'steps': 20, 'warmup': 6,
-                    'what': 'FASTNERF_COMPACT=0 on the trained nets: plain backward over every sample'}
-
-    # ---- round-1 protocol: random-init nets, U[0,1) noise targets, no scene (W = 3, K = 20) ----
-    tr_i, _ = new_trainer()
-    ti, loss_i, _ = timed(tr_i, 0, 3, 20, scene='noise')
-    tr_i.live.poll()
-    init_state = {'ms_per_step': 1e3 * ti / 20, 'value': N_RAYS * world * 20 / ti, 'unit': 'rays/s', 'steps': 20, 'warmup': 3,
-                  'backward': 'compacted' if tr_i.last_step_live else 'plain', 'live_fraction_measured': tr_i.live.frac,
-                  'final_loss': [float(x) for x in loss_i.tolist()],
-                  'what': 'random-init nets (seed 0), U[0,1) targets: the protocol of BENCH_r01'}
-    del tr_i
-
-    # ---- the same blobs with their Gaussian tails (no cut-off): 300 untimed steps, then W = 3, K = 20 ----
-    tr_s, _ = new_trainer()
-    soft_steps = min(300, a.scene_steps)
-    for i in range(soft_steps):
-        step(tr_s, i, 'soft')
-    tsoft, loss_s, _ = timed(tr_s, soft_steps, 3, 20, scene='soft')
-    soft_live = None
-    if tr_s.last_step_live:
-        c = tr_s.live_counts.cpu().tolist()
-        soft_live = {'fine': c[0] / max(1, c[1]), 'coarse': c[2] / max(1, c[3])}
-    soft_scene = {'ms_per_step': 1e3 * tsoft / 20, 'value': N_RAYS * world * 20 / tsoft, 'unit': 'rays/s', 'steps': 20, 'warmup': 3,
-                  'after_optimisation_steps': soft_steps, 'backward': 'compacted' if tr_s.last_step_live else 'plain', 'live_fraction': soft_live,
-                  'final_loss': [float(x) for x in loss_s.tolist()],
-                  'what': 'the three blobs WITHOUT the cut-off (density never vanishes), state after %d steps; the live fraction ' % soft_steps +
-                          'rises with training on this scene (0.72 at 2000 steps, 0.8-0.9 from 3500 on: tools/live_trajectory.py) '
-                          'and the policy then uses the plain backward, so its long-run rate is `steady_state_plain`'}
-    del tr_s
-
-    def mlp_roofline(trainer, split, compact_frac):
-        """HIP-event timing of the MLP launches of one step's FINE pass (786 432 points); the one the step spends the most
-        time in is `roofline`.  achieved = algorithmic FLOPs of the launch / its average duration."""
+    def mlp_roofline(trainer, split):
+        """HIP-event timing of the MLP launches of one step's FINE pass (4096 x 192 points per rank at weak scaling); the
+        launch the step spends the most time in is `roofline`.  achieved = algorithmic FLOPs of the launch / its duration."""
         ro, rd = batches[0][0], batches[0][1]
         rays11 = ops.pack_rays(ro, rd, 2.0, 6.0)
-        z = torch.sort(torch.rand(N_RAYS, S1, device=dev) * 4 + 2, -1).values
-        P = N_RAYS * S1
+        n = ro.shape[0]
+        z = torch.sort(torch.rand(n, S1, device=dev) * 4 + 2, -1).values
+        P = n * S1
         act = torch.empty(ops.act_floats(P), device=dev)
-        raw = torch.empty(N_RAYS, S1, 4, device=dev)
+        dact = torch.empty(ops.dact_floats(P), device=dev)
+        partial = torch.empty(ops.mlp_bwd_partial_floats(), device=dev)
+        gtmp = torch.empty(ops.NET_PARAMS, device=dev)
+        raw = torch.empty(n, S1, 4, device=dev)
+        draw = torch.randn(n, S1, 4, device=dev) * 1e-4
         reps = max(3, min(a.steps, 10))
         peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
         base = 'mlp_fwd_bf16_kernel' if split else 'mlp_fwd_kernel'
-        rows = []
         ms_save = time_launch(lambda: ops.mlp_fwd(rays11, z, trainer.net_f.flat, trainer.pf[0], act=act, raw=raw), reps)
         ms_inf = time_launch(lambda: ops.mlp_fwd(rays11, z, trainer.net_f.flat, trainer.pf[0], raw=raw), reps)
-        rows.append({'kernel': base + '<true, false>', 'what': 'training forward, saves activations, %d points' % P,
-                     'points': P, 'avg_launch_ms': ms_save})
-        rows.append({'kernel': base + '<false, false>', 'what': 'forward without saving (inference; first pass of a compacted step), %d points' % P,
-                     'points': P, 'avg_launch_ms': ms_inf})
-        if compact_frac is not None:
-            # the compacted step: inference forward on all points + saving forward on the live list
-            draw = torch.randn(P, 4, device=dev)
-            draw[torch.rand(P, device=dev) >= compact_frac] = 0
-            idx, cnt = ops.compact_live(draw)
-            k = int(cnt[0])
-            ms_live = time_launch(lambda: ops.mlp_fwd_live(rays11, z, trainer.net_f.flat, trainer.pf[0], act, idx, cnt), reps)
-            rows.append({'kernel': base + '<true, false>', 'what': 'training forward over the live list, %d of %d points' % (k, P),
-                         'points': k, 'avg_launch_ms': ms_live})
-            in_step = [rows[1], rows[2]]
-        else:
-            in_step = [rows[0]]
+        ms_bwd = time_launch(lambda: ops.mlp_bwd(draw, act, trainer.net_f.flat, trainer.pf[1], dact, partial, gtmp), reps)
+        rows = [{'kernel': base + '<true, false>', 'what': 'training forward, saves activations, %d points' % P,
+                 'points': P, 'avg_launch_ms': ms_save, 'flop_per_launch': P * FWD_FLOP_PER_POINT},
+                {'kernel': base + '<false, false>', 'what': 'forward without saving (inference), %d points' % P,
+                 'points': P, 'avg_launch_ms': ms_inf, 'flop_per_launch': P * FWD_FLOP_PER_POINT},
+                {'kernel': 'backward of the pass: dX chain + 12 dW launches + head gradients + partial reduction (15 launches)',
+                 'what': 'mlp_bwd, %d points' % P, 'points': P, 'avg_launch_ms': ms_bwd, 'flop_per_launch': P * BWD_FLOP_PER_POINT}]
         for r in rows:
-            r['flop_per_launch'] = r['points'] * FWD_FLOP_PER_POINT
             r['achieved'] = r['flop_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12
             r['frac'] = r['achieved'] / peak
-        dom = max(in_step, key=lambda r: r['avg_launch_ms'])
+        dom = rows[0]    # the single launch the plain step spends the most time in (the backward row is 15 launches)
         traffic = step_traffic = None
-        try:   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles.sh)
+        try:   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles_r03.sh)
             pmc = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_pmc_traffic.json')))
-            traffic = pmc['kernels']['void ' + dom['kernel']]['hbm_bytes']
-            step_traffic = pmc.get('step_traffic')
+            mode = 'bf16x3' if split else 'fp32'
+            traffic = pmc[mode]['kernels'][dom['kernel']]['hbm_bytes']
+            step_traffic = pmc[mode]['step_traffic']
         except Exception:
             pass
         roof = {'bound': 'mfma', 'kernel': dom['kernel'] + ' (fine pass; ' + dom['what'] + ')', 'achieved': dom['achieved'],
@@ -327,117 +389,205 @@ def main():
                 'step_traffic': step_traffic, 'avg_launch_ms': dom['avg_launch_ms'], 'flop_per_launch': dom['flop_per_launch'],
                 'mfma_tflops_issued': (3.0 if split else 1.0) * dom['achieved'], 'launches': rows}
         if split:
-            # tools/micro/mfma_power.hip on the bench box: a saturated v_mfma_f32_32x32x16_bf16 stream (32.0 clk per
-            # MFMA and SIMD) holds 2.24-2.38 GHz on constant operands but only 1.79 GHz = 1871 TFLOP/s on uniform(-1,1)
-            # bf16 data (power management)
+            # tools/micro/mfma_power.hip: a saturated v_mfma_f32_32x32x16_bf16 stream holds 2.24-2.38 GHz on constant operands
+            # but only 1.79 GHz = 1871 TFLOP/s on uniform(-1,1) bf16 data (power management)
             roof['peak_measured_real_data'] = 1871.0 / 3.0
             roof['frac_of_measured_peak'] = dom['achieved'] / (1871.0 / 3.0)
         return roof
 
-    roof = None
-    if rank == 0:
-        roof = mlp_roofline(tr, ops.get_math() == 'bf16x3', live_frac['fine'] if live_frac else None)
+    # =====================================================================================================================
+    # headline: exact fp32, SURVEY 8(d) protocol, plain backward
+    # =====================================================================================================================
+    main_mode, main_compact = ops.get_math(), fastnerf.render.get_compact()
+    ops.set_math('fp32')
+    fastnerf.render.set_compact('0')
+    tr, _, kte, _ = new_trainer()
+    dt, loss2, t_local = timed(lambda i: step(tr, i)[0], 0, a.warmup, a.steps)
+    per_rank_ms = [1e3 * t_local / a.steps]
+    allreduce_ms = None
+    if world > 1:
+        tl = torch.tensor([1e3 * t_local / a.steps], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(tl) for _ in range(world)]
+        torch.distributed.all_gather(gathered, tl)
+        per_rank_ms = [float(g[0]) for g in gathered]
+        # the step's data-path collectives, timed alone: all-reduce(SUM) of each net's half of the flat gradient (2.38 MB each;
+        # in the step the fine net's runs beside the coarse pass's backward)
+        Nn = ops.NET_PARAMS
+        allreduce_ms = {'fine_half': time_launch(lambda: parallel.all_reduce_sum(tr.grad[Nn:]), 20),
+                        'coarse_half': time_launch(lambda: parallel.all_reduce_sum(tr.grad[:Nn]), 20),
+                        'whole_buffer': time_launch(lambda: parallel.all_reduce_sum(tr.grad), 20),
+                        'overlapped_with_coarse_backward': bool(tr.overlap_allreduce)}
+    sustained = None
+    if a.sustained_steps > 0:   # power-managed clocks settle within seconds: the same stream of steps for a few seconds more
+        ts, _, _ = timed(lambda i: step(tr, i)[0], a.warmup + a.steps, 0, a.sustained_steps)
+        sustained = leg(ts, a.sustained_steps, wall_seconds=ts)
+    roof = mlp_roofline(tr, False) if rank == 0 else None
+    step_tflops = n_step * a.steps / dt * TRAIN_FLOP_PER_RAY / 1e12 / world
 
-    # ---- the same step in the exact-fp32 math mode (1 GPU only; not `value`): its own roofline block ---------------
-    alt = None
-    if rank == 0 and world == 1 and ops.get_math() != 'fp32':
-        main_mode = ops.get_math()
+    # =====================================================================================================================
+    # siblings (1 GPU, rank 0): never part of `value`
+    # =====================================================================================================================
+    split_block = drop_in = infer = psnr_block = None
+    trb = kte_b = None
+    if not a.no_siblings:
+        # ---- split-bf16: the same protocol (random init, noise targets, plain backward); every rank takes part ---------------
+        ops.set_math('bf16x3')
+        trb, _, kte_b, _ = new_trainer()
+        tb, lb, _ = timed(lambda i: step(trb, i)[0], 0, 3, 20)
+        if rank == 0:
+            split_block = {'math_mode': 'bf16x3', 'dtype': 'split-bf16 x3: every fp32 product as hi*hi + hi*lo + lo*hi on the bf16 '
+                           'matrix cores with fp32 accumulation; operands carry 16 significand bits -- NARROWER than fp32, hence a sibling',
+                           'init_state': leg(tb, 20, warmup=3, backward='plain', final_loss=[float(x) for x in lb.tolist()],
+                                             what='the headline protocol (random init, U[0,1) targets, plain backward) in this mode',
+                                             step_frac_of_bf16_mfma_peak_x3=3.0 * n_step * 20 / tb * TRAIN_FLOP_PER_RAY / 1e12 / world / BF16_MFMA_PEAK_TFLOPS),
+                           'roofline': mlp_roofline(trb, True)}
+    if siblings:
+        # ---- split-bf16 on a trained sparse scene, compacted backward (round 2's headline, now a named sibling) -------------
+        fastnerf.render.set_compact('auto')
+        trs, _, _, _ = new_trainer()
+        for i in range(a.scene_steps):
+            step(trs, i, 'solid')
+        tsol, lsol, _ = timed(lambda i: step(trs, i, 'solid')[0], a.scene_steps, 3, 20)
+        live_frac, was_live = None, trs.last_step_live
+        if was_live:
+            c = trs.live_counts.cpu().tolist()
+            live_frac = {'fine': c[0] / max(1, c[1]), 'coarse': c[2] / max(1, c[3])}
+        fastnerf.render.set_compact('0')
+        tpl, _, _ = timed(lambda i: step(trs, i, 'solid')[0], 7, 6, 20)
+        split_block['sparse_scene'] = leg(
+            tsol, 20, warmup=3, backward='compacted' if was_live else 'plain', live_fraction=live_frac,
+            after_optimisation_steps=a.scene_steps + 3, final_loss=[float(x) for x in lsol.tolist()],
+            what='three solid analytic bodies on white (density exactly zero beyond %.1f sigma, ~27 %% of the pixels covered): nets '
+                 'trained inside the run, backward over the samples with a non-zero gradient only (exact; DESIGN 4a).  Scene and '
+                 'trajectory dependent: a field without exactly-empty space runs at `same_state_plain_backward`' % SCENE_CUTOFF,
+            same_state_plain_backward=leg(tpl, 20, warmup=6))
+        del trs
+
+        # ---- INTEGRATION option A: the reference's own loop on the drop-in surface (run_nerf.py:479-508) ----------------------
+        def drop_in_leg(mode):
+            ops.set_math(mode)
+            fastnerf.render.set_compact('0')
+            torch.manual_seed(0)
+            k_train, _, _, _, grad_vars, optimizer = fastnerf.run_nerf.create_nerf(args, device=dev)
+            k_train.update(near=2.0, far=6.0)
+            state = {'it': 0}
+
+            def one(i):
+                ro, rd, tgts, _ = batches[i % n_batches]
+                rgb, disp, acc, extras = fastnerf.render.render(H, W, K, chunk=args.chunk, rays=(ro, rd), retraw=True, **k_train)
+                optimizer.zero_grad()
+                img_loss = fastnerf.run_nerf_helpers.img2mse(rgb, tgts['noise'])
+                loss = img_loss + fastnerf.run_nerf_helpers.img2mse(extras['rgb0'], tgts['noise'])
+                loss.backward()
+                optimizer.step()
+                new_lrate = 5e-4 * (0.1 ** (state['it'] / (500 * 1000)))
+                for pg in optimizer.param_groups:
+                    pg['lr'] = new_lrate
+                state['it'] += 1
+                return img_loss.detach()
+            td, ld, _ = timed(one, 0, 3, 20)
+            return leg(td, 20, warmup=3, final_img_loss=float(ld))
+        d32 = drop_in_leg('fp32')
+        d16 = drop_in_leg('bf16x3')
+        drop_in = {'what': 'the reference\'s loop verbatim on the drop-in surface: render(retraw=True) -> img2mse x 2 -> loss.backward() -> '
+                           'torch.optim.Adam(48 tensors).step() -> lr rule; same protocol and batches as `value`',
+                   'fp32': d32, 'bf16x3': d16,
+                   'fraction_of_fused_trainer': {'fp32': d32['value'] / (n_step * a.steps / dt),
+                                                 'bf16x3': d16['value'] / split_block['init_state']['value']}}
+
+        # ---- PSNR at equal iterations: GPU side (both modes, free runs + a 1-ulp ensemble) on the inputs the CPU worker got ---
+        if psnr_data is not None:
+            psnr_block = {'iters': psnr_data['iters'], 'rays_per_iter': PSNR_RAYS, 'samples': '64+128', 'cameras': '100 x 800x800',
+                          'scene': 'three analytic Gaussian density blobs on white (fastnerf.synthetic), identical batches, injected '
+                                   't_rand / u (seed 2) and initial weights (seed 0) on both sides',
+                          'train_psnr_window': 20, 'held_out_rays': PSNR_HELD_OUT, 'gpu': {}}
+            dd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in psnr_data.items()}
+            for mode in ('fp32', 'bf16x3'):
+                psnr_block['gpu'][mode] = psnr_gpu_free(fastnerf, dd, new_trainer, K, mode)[0]
+            ens = [psnr_gpu_free(fastnerf, dd, new_trainer, K, 'fp32', jitter_ulp_seed=100 + j)[0] for j in range(8)]
+            psnr_block['gpu_ensemble'] = {
+                'what': '8 more fp32 runs whose initial weights differ from the first by a random -1 / 0 / +1 ulp: the spread two runs of '
+                        'the same arithmetic reach at this iteration count (trajectories decorrelate within ~30 iterations: DESIGN 5)',
+                'train_psnr_db': [e['train_psnr_db'] for e in ens], 'held_out_psnr_db': [e['held_out_psnr_db'] for e in ens],
+                'train_psnr_std_db': float(np.std([e['train_psnr_db'] for e in ens], ddof=1)),
+                'held_out_psnr_std_db': float(np.std([e['held_out_psnr_db'] for e in ens], ddof=1))}
+
+        # ---- inference rays/s (render_path-style, perturb=0, no saved activations) -------------------------------
         ops.set_math('fp32')
-        try:
-            tr32, _ = new_trainer()
-            n32 = max(20, a.steps)
-            t32, l32, _ = timed(tr32, 0, 3, n32, scene='noise')   # round-1 protocol: random init, noise targets
-            dt32 = t32 / n32
-            # steady state: the trained state of the main leg (same weights, Adam moments, LR position), W = 3, K = n32
-            with torch.no_grad():
-                tr32.flat.copy_(tr.flat); tr32.m.copy_(tr.m); tr32.v.copy_(tr.v)
-            tr32.adam_t, tr32.global_iter, tr32.lr = tr.adam_t, tr.global_iter, tr.lr
-            tr32.repack()
-            tr32.live = fastnerf.render.LivePolicy()
-            ts32, ls32, _ = timed(tr32, a.scene_steps, 3, n32)
-            c32 = tr32.live_counts.cpu().tolist() if tr32.last_step_live else None
-            alt = {'math_mode': 'fp32', 'dtype': 'f32', 'value': N_RAYS * n32 / ts32, 'unit': 'rays/s', 'ms_per_step': 1e3 * ts32 / n32,
-                   'steps': n32, 'warmup': 3, 'final_loss': [float(x) for x in ls32.tolist()],
-                   'what': 'steady state of the trained scene (the main leg\'s weights), exact-fp32 MFMA kernels',
-                   'backward': 'compacted' if tr32.last_step_live else 'plain',
-                   'live_fraction': None if c32 is None else {'fine': c32[0] / max(1, c32[1]), 'coarse': c32[2] / max(1, c32[3])},
-                   'step_frac_of_fp32_mfma_peak': N_RAYS * n32 / ts32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                   'init_state': {'value': N_RAYS / dt32, 'ms_per_step': 1e3 * dt32, 'final_loss': [float(x) for x in l32.tolist()],
-                                  'step_frac_of_fp32_mfma_peak': N_RAYS / dt32 * TRAIN_FLOP_PER_RAY / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                  'what': 'random init, U[0,1) targets, plain backward: the protocol of BENCH_r01'},
-                   'roofline': mlp_roofline(tr32, False, c32[0] / max(1, c32[1]) if c32 else None)}
-            del tr32
-        finally:
-            ops.set_math(main_mode)
-
-    # ---- inference rays/s (render_path-style, perturb=0, no saved activations), rank 0 only -------------
-    infer = None
-    if rank == 0:
         n_inf = 32768
-        g2 = torch.Generator().manual_seed(7)
-        pix = torch.stack([torch.randint(0, n_img, (n_inf,), generator=g2), torch.randint(0, H, (n_inf,), generator=g2),
-                           torch.randint(0, W, (n_inf,), generator=g2)], 1).int().to(dev)
+        pix = draw_pixels(torch.Generator().manual_seed(7), n_inf).to(dev)
         ro_i, rd_i = ops.gen_rays_pixels(pix, poses, K)
-        with torch.no_grad():
-            for _ in range(2):
-                fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kte)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n_rep = 5
-            for _ in range(n_rep):
-                fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kte)
-            torch.cuda.synchronize()
-            dt_i = (time.perf_counter() - t1) / n_rep
-            rgb_i = fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kte)[0]
-            mse_i = float(torch.mean((rgb_i - synthetic.render_rays(ro_i, rd_i, cutoff=SCENE_CUTOFF)) ** 2))
-        infer = {'value': n_inf / dt_i, 'unit': 'rays/s', 'rays_per_call': n_inf, 'ms_per_call': 1e3 * dt_i,
-                 'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), 1 GPU',
-                 # the metric's second half: PSNR of the nets this run trained, on rays that were never in a batch
-                 'psnr_db': -10.0 * math.log10(max(mse_i, 1e-12)), 'psnr_after_optimisation_steps': n_opt.get(id(tr), 0),
-                 'psnr_what': 'held-out rays of the analytic scene (32768 random pixels of the 100 views, seed 7) against its '
-                              'quadrature colours; %d rays per step per GPU' % N_RAYS}
+        infer = {'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), random-init nets, 1 GPU'}
+        for mode, kt in (('fp32', kte), ('bf16x3', kte_b)):
+            ops.set_math(mode)
+            with torch.no_grad():
+                for _ in range(2):
+                    fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kt)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kt)
+                torch.cuda.synchronize()
+                dt_i = (time.perf_counter() - t1) / 5
+            infer[mode] = {'value': n_inf / dt_i, 'unit': 'rays/s', 'ms_per_call': 1e3 * dt_i}
+    ops.set_math(main_mode)
+    fastnerf.render.set_compact(main_compact)
 
     if rank == 0:
-        rays_per_s = N_RAYS * world * a.steps / dt
-        step_tflops = rays_per_s * TRAIN_FLOP_PER_RAY / 1e12 / world
+        # ---- CPU legs: wait for the PSNR worker (it ran beside the GPU legs), then time the step alone ----------------------
+        cpu = None
+        if siblings and not a.no_cpu_baseline:
+            if psnr_proc is not None:
+                _, err = psnr_proc.communicate()
+                if psnr_proc.returncode == 0:
+                    r = json.load(open(psnr_out))
+                    psnr_block['cpu'] = {'train_psnr_db': psnr_of(r['losses'], 20), 'held_out_psnr_db': -10.0 * math.log10(r['held_out_mse']),
+                                         'first_loss': r['losses'][0], 'last_loss': r['losses'][-1], 'threads': r['threads'],
+                                         'rays_per_s_while_gpu_legs_ran': r['rays_per_s'],
+                                         'what': 'oracle/nerf_oracle.py train_step / render_rays (torch CPU fp32), the same inputs'}
+                    psnr_block['delta_db'] = {m: {k: psnr_block['gpu'][m][k] - psnr_block['cpu'][k] for k in ('train_psnr_db', 'held_out_psnr_db')}
+                                              for m in psnr_block['gpu']}
+                    states = np.load(psnr_out + '.states', mmap_mode='r')
+                    psnr_block['lockstep'] = {
+                        'what': 'the GPU step taken from the CPU run\'s state before every iteration (weights + Adam moments): the same PSNR '
+                                'window without trajectory divergence; delta_db = GPU - CPU'}
+                    for mode in ('fp32', 'bf16x3'):
+                        r_ = psnr_gpu_lockstep(fastnerf, dd, new_trainer, states, r['losses'], mode)
+                        r_['delta_db'] = r_['train_psnr_db'] - psnr_block['cpu']['train_psnr_db']
+                        psnr_block['lockstep'][mode] = r_
+                    del states
+                    ops.set_math(main_mode)
+                    fastnerf.render.set_compact(main_compact)
+                else:
+                    psnr_block['cpu'] = {'error': err.decode()[-400:]}
+                for p in (psnr_in, psnr_out, psnr_out + '.states'):
+                    if p and os.path.exists(p):
+                        os.remove(p)
+            cpu = cpu_baseline(a.cpu_protocol)
+        rays_per_s = n_step * a.steps / dt
         out = {
-            'metric': 'training rays/sec (Lego-like 800x800, 64+128 samples)', 'value': rays_per_s, 'unit': 'rays/s',
+            'metric': 'training rays/sec (Lego-like 800x800, 64+128 samples) + PSNR@N-iters', 'value': rays_per_s, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (split-bf16 x3 on the bf16 matrix cores, fp32 accumulate)' if ops.get_math() == 'bf16x3' else 'f32',
-            'math_mode': ops.get_math(),
-            'data': 'synthetic (three solid analytic bodies on white, 100 pose_spherical cameras; nets trained from random init inside the run)',
-            'config': {'workload': 'nerf-ours Lego full 800x800, 4096 rays/GPU/step, 64+128 samples, use_viewdirs, '
-                                   'white_bkgd, perturb=1, leaf-error table on (BASELINE configs[1]); nets trained on the analytic '
-                                   'solid-body scene (%d untimed optimisation steps from random init, then W + K); the share of '
-                                   'live samples is stationary on this scene from step ~500 on' % a.scene_steps,
-                       'rays_per_gpu_per_step': N_RAYS, 'parallelism': f'dp{world}', 'scene_steps': a.scene_steps},
-            'scene': {'bodies': 'three blobs of fastnerf.synthetic, density exactly zero beyond %.1f standard deviations of each centre' % SCENE_CUTOFF,
-                      'silhouette_coverage': coverage,
-                      'note': 'throughput depends on the share of samples with an exactly-zero gradient (sigma <= 0), a property of the '
-                              'scene and of the training trajectory: this scene (coverage like the Lego bulldozer, empty space around '
-                              'it) keeps 0.19 fine / 0.08 coarse live from step ~500 through 6000 (tools/live_trajectory.py); '
-                              '`gaussian_tails_scene` and `steady_state_plain` are the adverse cases'},
-            'device': {'name': torch.cuda.get_device_name(dev), 'compute_units': torch.cuda.get_device_properties(dev).multi_processor_count,
-                       'note': 'the chip is power-managed under these kernels (DESIGN section 9): the same tree measured 720 k .. 757 k rays/s on '
-                               'different boxes of the pool (one box of an earlier session ran every leg 8 % slower), every leg moving together'},
-            'final_loss': [float(x) for x in loss2.tolist()],
-            'backward': ('compacted: samples with an exactly-zero gradient skipped (FASTNERF_COMPACT=%s)' % fastnerf.render.get_compact())
-            if backward_kind == 'compacted' else 'plain (every sample)',
-            'live_fraction': live_frac,
-            'steady_state_plain': steady_plain, 'speedup_vs_plain_backward': steady_plain['ms_per_step'] / (1e3 * dt / a.steps),
-            'gaussian_tails_scene': soft_scene,
-            'init_state': init_state,
+            'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
+            'dtype': 'f32', 'math_mode': 'fp32 (v_mfma_f32_32x32x2_f32, fp32 accumulate)',
+            'data': 'synthetic (SURVEY 8d: 100 pose_spherical cameras of 800x800, uniformly drawn rays, U[0,1) targets, default-init nets seed 0)',
+            'config': {'workload': 'nerf-ours Lego full 800x800 (BASELINE configs[1]), SURVEY 8(d) throughput protocol: %d uniformly drawn rays '
+                                   'per GPU per step, 64+128 samples, use_viewdirs, white_bkgd, perturb=1, U[0,1) targets, random-init nets, '
+                                   'leaf-error table on, exact-fp32 MFMA kernels, plain backward (FASTNERF_COMPACT=0)' % n_local,
+                       'rays_per_gpu_per_step': n_local, 'rays_per_step': n_step, 'parallelism': f'dp{world}'},
+            'device': {'name': torch.cuda.get_device_name(dev), 'compute_units': torch.cuda.get_device_properties(dev).multi_processor_count},
+            'final_loss': [float(x) for x in loss2.tolist()], 'backward': 'plain (every sample)',
             'per_rank_ms_per_step': per_rank_ms, 'allreduce_ms': allreduce_ms,
-            'step_tflops_note': 'rays/s x the algorithmic FLOPs of an UNCOMPACTED step (893.2 MFLOP/ray): with samples skipped this is '
-                                'an effective rate, not what the matrix cores executed -- see `roofline` for executed work per launch',
             'step_tflops_per_gpu': step_tflops, 'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
-            'step_frac_of_bf16_mfma_peak_x3': 3.0 * step_tflops / BF16_MFMA_PEAK_TFLOPS,
+            'step_tflops_note': 'rays/s x the algorithmic FLOPs of a step (893.2 MFLOP/ray, SURVEY 8d); the fp32-MFMA roofline of the step is '
+                                '%.1f k rays/s/GPU' % (FP32_MFMA_PEAK_TFLOPS * 1e12 / TRAIN_FLOP_PER_RAY / 1e3),
             'sustained': sustained,
             'roofline': roof,
+            'psnr_vs_cpu': psnr_block,
+            'split_bf16_mode': split_block,
+            'drop_in_route': drop_in,
             'inference': infer,
-            'exact_fp32_mode': alt,
-            'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.cpu_protocol),
+            'cpu_baseline': cpu,
         }
         print(json.dumps(out))
     if world > 1:

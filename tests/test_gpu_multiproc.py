@@ -14,28 +14,37 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(backend, port):
+def _run(backend, port, scaling='weak'):
     env = dict(os.environ)
     if backend:
         env['FASTNERF_DIST_BACKEND'] = backend
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--sustained-steps', '5', '--scene-steps', '12']
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--sustained-steps', '5',
+           '--scaling', scaling]
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
-def test_bench_two_ranks():
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_two_ranks(scaling):
     # two or more GPUs: the collective MUST be RCCL over xGMI -- a failure there is a failure (no gloo retry);
     # a 1-GPU box can only exercise the plumbing (both ranks on one device, gloo)
-    out = _run(None, 29533) if torch.cuda.device_count() >= 2 else _run('gloo', 29533)
+    port = 29533 if scaling == 'weak' else 29535
+    out = _run(None, port, scaling) if torch.cuda.device_count() >= 2 else _run('gloo', port, scaling)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]          # exactly one JSON line, from rank 0
     j = json.loads(lines[0])
-    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == 'weak' and j['value'] > 0
-    assert j['config']['parallelism'] == 'dp2' and j['cpu_baseline'] is None
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == scaling and j['value'] > 0 and j['dtype'] == 'f32'
+    per_gpu = 4096 if scaling == 'weak' else 2048        # weak: per-GPU work fixed; strong: 4096 rays per step split over the ranks
+    assert j['config']['parallelism'] == 'dp2' and j['config']['rays_per_gpu_per_step'] == per_gpu and j['cpu_baseline'] is None
+    assert abs(j['value'] - 2 * per_gpu * 3 / (j['ms_per_step'] * 3e-3)) < 1e-6 * j['value']
     assert all(abs(x) < 1.0 for x in j['final_loss'])
-    assert len(j['per_rank_ms_per_step']) == 2 and all(x > 0 for x in j['per_rank_ms_per_step']) and j['allreduce_ms'] > 0
+    assert len(j['per_rank_ms_per_step']) == 2 and all(x > 0 for x in j['per_rank_ms_per_step'])
+    ar = j['allreduce_ms']
+    assert ar['fine_half'] > 0 and ar['coarse_half'] > 0 and ar['whole_buffer'] > 0 and ar['overlapped_with_coarse_backward'] is True
     assert j['sustained']['steps'] == 5
+    assert j['split_bf16_mode']['init_state']['value'] > 0          # the sibling leg ran on both ranks too
+    assert j['psnr_vs_cpu'] is None and j['drop_in_route'] is None  # 1-GPU legs
 
 
 _SHARD_WORKER = r"""
@@ -47,6 +56,8 @@ from fastnerf import parallel
 rank, world, local = parallel.init_from_env('cuda')
 torch.cuda.set_device(0 if torch.cuda.device_count() < world else local)
 torch.manual_seed(0)
+if rank == 1 and os.environ.get('COMPACT_RANK1'):          # ranks that DISAGREE on compacted / plain backward
+    fastnerf.render.set_compact(os.environ['COMPACT_RANK1'])
 args = fastnerf.run_nerf.make_args(N_importance=32, N_samples=32, perturb=1.0, white_bkgd=True, no_reload=True, lrate=5e-4, lrate_decay=500)
 ktr, _, _, _, _, _ = fastnerf.run_nerf.create_nerf(args, device='cuda')
 imgs, poses, focal = fastnerf.synthetic.make_dataset(n_images=2, H=32, W=32)
@@ -58,7 +69,7 @@ ro = torch.cat([r[0].reshape(-1, 3) for r in rays], 0); rd = torch.cat([r[1].res
 tgt = imgs.reshape(-1, 3).cuda()
 ml = 16
 table = torch.zeros(2 * ml, device='cuda', dtype=torch.int32)
-losses = []
+losses, lives = [], []
 for it in range(4):
     N = (512, 512, 511, 1)[it]                  # a batch that does not divide evenly, then one whose shard is EMPTY on rank 1
     sel = torch.randint(0, ro.shape[0], (N,), generator=gen)
@@ -70,6 +81,7 @@ for it in range(4):
                        table=table, max_leaves=ml, t_rand=t_rand[sl].contiguous(), u=u[sl].contiguous(),
                        n_global=N if world > 1 else None)
     losses.append(loss2.cpu().tolist())
+    lives.append(bool(tr.last_step_live))
     if it == 0:
         grad0 = tr.grad.clone()                 # after the all-reduce: the global-batch mean gradient of step 1
         table0 = table.clone()
@@ -78,6 +90,9 @@ parallel.all_reduce_max_int(table)
 torch.cuda.synchronize()
 if rank == 0:
     torch.save({'flat': tr.flat.cpu(), 'grad0': grad0.cpu(), 'table0': table0.cpu(), 'table': table.cpu(), 'losses': losses, 'lr': tr.lr, 'adam_t': tr.adam_t}, %(out)r %% world)
+if world > 1:
+    torch.save({'flat': tr.flat.cpu(), 'm': tr.m.cpu(), 'v': tr.v.cpu(), 'grad0': grad0.cpu(), 'live': lives, 'overlap': tr.overlap_allreduce},
+               (%(out)r %% world) + '.rank%%d' %% rank)
 if world > 1:
     parallel.barrier(); torch.distributed.destroy_process_group()
 """
@@ -116,6 +131,50 @@ def test_sharded_trainer_equals_single_rank_on_the_union(tmp_path, compact):
     scale = a['flat'].abs().max().item()
     assert float((d > 1e-6 * scale).float().mean()) < 0.10, float((d > 1e-6 * scale).float().mean())   # measured 2-4 %
     assert d.max().item() <= 4 * 5e-4 * 2.001
+
+
+def _two_ranks(script, env, port):
+    env = dict(env)
+    if torch.cuda.device_count() < 2:
+        env['FASTNERF_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_overlapped_allreduce_is_bit_identical_and_replicas_agree(tmp_path):
+    """The fine net's gradient is all-reduced while the coarse pass's backward runs (Trainer.step, two collectives on the process
+    group's stream): same bits as one all-reduce of the whole buffer after the backward, and both ranks hold identical
+    parameters and Adam moments afterwards."""
+    script = str(tmp_path / 'worker.py')
+    res = {}
+    for overlap in ('1', '0'):
+        out = str(tmp_path / ('ov%s_%%d.pt' % overlap))
+        with open(script, 'w') as f:
+            f.write(_SHARD_WORKER % {'root': ROOT, 'out': out})
+        _two_ranks(script, dict(os.environ, FASTNERF_COMPACT='0', FASTNERF_OVERLAP_ALLREDUCE=overlap), 29551)
+        res[overlap] = [torch.load((out % 2) + '.rank%d' % r) for r in range(2)]
+        a, b = res[overlap]
+        assert a['overlap'] == (overlap == '1')
+        for k in ('flat', 'm', 'v', 'grad0'):
+            assert torch.equal(a[k], b[k]), k                       # replicas stay bit-identical
+    for k in ('flat', 'm', 'v', 'grad0'):
+        assert torch.equal(res['1'][0][k], res['0'][0][k]), k       # overlapping changes no bit
+
+
+def test_ranks_that_disagree_on_compaction_stay_identical(tmp_path):
+    """Rank 0 runs the plain backward, rank 1 the compacted one (in production each rank's LivePolicy follows its own shard's live
+    fraction): their gradient contributions differ in fp32 summation grouping, the all-reduced sum is the same tensor on
+    both, so parameters and Adam moments stay bit-identical across the replicas."""
+    script = str(tmp_path / 'worker.py')
+    out = str(tmp_path / 'mix_%d.pt')
+    with open(script, 'w') as f:
+        f.write(_SHARD_WORKER % {'root': ROOT, 'out': out})
+    _two_ranks(script, dict(os.environ, FASTNERF_COMPACT='0', COMPACT_RANK1='1'), 29553)
+    a, b = [torch.load((out % 2) + '.rank%d' % r) for r in range(2)]
+    assert a['live'] == [False] * 4 and b['live'][:3] == [True] * 3    # (the last batch leaves rank 1 without rays)
+    for k in ('flat', 'm', 'v', 'grad0'):
+        assert torch.equal(a[k], b[k]), k
 
 
 _TRAIN_WORKER = r"""

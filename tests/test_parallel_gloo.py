@@ -56,7 +56,14 @@ def _worker(rank, world, port, q):
     sl = parallel.shard(N)
     n_local = len(range(N)[sl])
     local, rgb_local = grads_of(sl, n_local / N)     # what mse_leafmax's grad_scale does on the device
+    halves = local.clone()
     parallel.all_reduce_sum(local)
+    # what Trainer.step does: the fine net's half while the coarse pass's backward still runs, then the coarse half
+    h = halves.numel() // 2
+    w1 = parallel.all_reduce_sum_async(halves[h:])
+    w0 = parallel.all_reduce_sum_async(halves[:h])
+    parallel.wait_all(w1, w0)
+    assert torch.equal(halves, local)
     err = (local - full).abs().max().item() / full.abs().max().item()
     # leaf table: per-rank segmented max -> all-reduce(MAX) on the int32 bit patterns
     tab = O.leaf_loss_max(tgt[sl], rgb_local, tag[sl], 2, 5).view(-1).view(torch.int32).clone()
