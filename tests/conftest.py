@@ -13,6 +13,72 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+# ---- the CPU oracle's 200-iteration run of tests/test_gpu_train.py::test_psnr_vs_cpu_at_the_baseline_shape takes ~5 minutes of
+# host time and no GPU time: when that test is selected on a GPU box, the run is started in a worker process as soon as the
+# collection is known, beside the rest of the suite, and the test (late in the order) collects its result.
+PSNR_TEST = 'test_psnr_vs_cpu_at_the_baseline_shape'
+
+
+def psnr_protocol(fn):
+    """(args, poses, K, draw_pixels, new_trainer) of bench.py's psnr_vs_cpu leg."""
+    import numpy as np
+    import torch
+    import bench as B
+    dev = torch.device('cuda')
+    K = np.array([[B.FOCAL, 0, 0.5 * B.W], [0, B.FOCAL, 0.5 * B.H], [0, 0, 1]])
+    poses = torch.stack([fn.synthetic.pose_spherical(-180.0 + 3.6 * k, -30.0, 4.0)[:3, :4] for k in range(100)], 0).to(dev)
+    args = fn.run_nerf.make_args(N_importance=B.N_IMPORTANCE, N_samples=B.N_SAMPLES, perturb=1.0, white_bkgd=True, no_reload=True,
+                                 lrate=5e-4, lrate_decay=500)
+
+    def draw_pixels(gen, n):
+        return torch.stack([torch.randint(0, 100, (n,), generator=gen), torch.randint(0, B.H, (n,), generator=gen),
+                            torch.randint(0, B.W, (n,), generator=gen)], 1).int()
+
+    def new_trainer():
+        torch.manual_seed(0)
+        k_train, k_test, _, _, grad_vars, _ = fn.run_nerf.create_nerf(args, device=dev)
+        return fn.run_nerf.Trainer(k_train, B.H, B.W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500), k_train, k_test, grad_vars
+    return args, poses, K, draw_pixels, new_trainer
+
+
+def start_psnr_cpu_run():
+    """-> dict(proc, data, out): the worker (bench.py --psnr-cpu-worker) runs the CPU oracle on the inputs in `data`."""
+    import subprocess
+    import tempfile
+    import torch
+    import fastnerf as fn
+    import bench as B
+    iters = int(os.environ.get('PSNR_TEST_ITERS', B.PSNR_ITERS))
+    args, poses, K, draw_pixels, _ = psnr_protocol(fn)
+    data = B.psnr_inputs(fn, torch.device('cuda'), iters, args, poses, K, draw_pixels)
+    tmp = tempfile.mkdtemp(prefix='fastnerf_psnr_test_')
+    p_in, p_out = os.path.join(tmp, 'in.pt'), os.path.join(tmp, 'out.json')
+    torch.save(data, p_in)
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--psnr-cpu-worker', p_in, p_out], cwd=ROOT,
+                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return {'proc': proc, 'data': data, 'out': p_out, 'tmp': tmp}
+
+
+@pytest.hookimpl(trylast=True)   # (after -m / -k have deselected)
+def pytest_collection_modifyitems(config, items):
+    if any(it.name == PSNR_TEST for it in items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                config._psnr_cpu_run = start_psnr_cpu_run()
+        except Exception as e:      # the test itself reports the problem
+            config._psnr_cpu_run = e
+
+
+def pytest_unconfigure(config):
+    run = getattr(config, '_psnr_cpu_run', None)
+    if isinstance(run, dict):
+        if run['proc'].poll() is None:
+            run['proc'].kill()
+        import shutil
+        shutil.rmtree(run['tmp'], ignore_errors=True)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

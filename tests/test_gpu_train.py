@@ -54,34 +54,35 @@ def test_psnr_at_equal_iterations(fn, math_mode):
 
 def test_psnr_300_iterations_both_modes(fn):
     """Long-horizon equivalence of the math modes: 300 optimisation steps on the synthetic scene, identical batches and
-    injected randoms, four seeds.  Seed-averaged training PSNR (last 50 iterations) of the default split-bf16 mode within
-    0.1 dB of the exact-fp32 mode; both within 0.1 dB of the CPU oracle over the prefix the oracle is run for.
+    injected randoms.  north_star: PSNR within 0.1 dB at equal iteration count.
 
-    Single trajectories are chaotic at this horizon (sample_pdf is ill-conditioned): the SAME
-    arithmetic with another grouping of the dW partial sums -- the compacted instead of the plain backward -- already moves
-    a seed's PSNR by up to 0.4 dB and the 4-seed mean by 0.12 dB, in either mode.  Each mode is therefore represented by
-    eight trajectories (4 seeds x {plain, compacted} backward); the mode means must agree to 0.1 dB, and the
-    plain-vs-compacted spread inside a mode -- the noise floor of the comparison -- is measured and bounded."""
+    Single trajectories are chaotic at this horizon (sample_pdf is ill-conditioned; at the BASELINE shape
+    two runs decorrelate within ~30 iterations, tools/psnr_lockstep.py): the SAME arithmetic with another grouping of the dW
+    partial sums -- the compacted instead of the plain backward -- already moves one seed's PSNR by up to 0.4 dB.  A mode is
+    therefore a DISTRIBUTION of trajectories, and the statement tested is about its mean: enough seeds that the standard error
+    of the mean per-seed difference is below 0.04 dB, then a hard 0.1 dB bound on that mean (2.5 standard errors)."""
     imgs, poses, focal = fn.synthetic.make_dataset(n_images=6, H=24, W=24)
     H = W = 24
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
     rays = [O.get_rays(H, W, K, poses[i]) for i in range(6)]
-    ro_all = torch.stack([r[0] for r in rays], 0).reshape(-1, 3)
-    rd_all = torch.stack([r[1] for r in rays], 0).reshape(-1, 3)
-    tgt_all = imgs.reshape(-1, 3)
-    n_iters, n_prefix, N, seeds = 300, 40, 192, (0, 1, 2, 3)   # (at 60 iterations single seeds are already 0.3 dB apart)
+    ro_all = torch.stack([r[0] for r in rays], 0).reshape(-1, 3).cuda()
+    rd_all = torch.stack([r[1] for r in rays], 0).reshape(-1, 3).cuda()
+    tgt_all = imgs.reshape(-1, 3).cuda()
+    n_iters, n_prefix, N = 300, 40, 192       # (at 60 iterations single seeds are already 0.3 dB apart)
+    n_seeds, n_full = 128, 4                  # seeds 0..3 additionally run the compacted backward and the CPU oracle's prefix
     old, old_c = fn.ops.get_math(), fn.render.get_compact()
     keys = ('fp32', 'bf16x3', 'fp32_compacted', 'bf16x3_compacted')
     psnr = {k: [] for k in keys + ('oracle_prefix',) + tuple(k + '_prefix' for k in keys)}
     try:
-        for seed in seeds:
+        for seed in range(n_seeds):
             gen = torch.Generator().manual_seed(100 + seed)
             sched = []
             for it in range(n_iters):
                 sched.append((torch.randint(0, ro_all.shape[0], (N,), generator=gen), torch.rand(N, 16, generator=gen),
                               torch.rand(N, 16, generator=gen)))
+            dsched = [(s.cuda(), t.cuda(), u.cuda()) for s, t, u in sched]
             init = None
-            for key in keys:
+            for key in (keys if seed < n_full else keys[:2]):
                 fn.ops.set_math('bf16x3' if key.startswith('bf16x3') else 'fp32')
                 fn.render.set_compact('1' if key.endswith('compacted') else '0')
                 torch.manual_seed(seed)
@@ -93,43 +94,104 @@ def test_psnr_300_iterations_both_modes(fn):
                             {k: v.detach().cpu().clone() for k, v in ktr['network_fine'].state_dict().items()})
                 tr = fn.run_nerf.Trainer(ktr, H, W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
                 losses = []
-                for sel, t_rand, u in sched:
-                    loss2, _ = tr.step(ro_all[sel].cuda(), rd_all[sel].cuda(), tgt_all[sel].cuda(), t_rand=t_rand.cuda(), u=u.cuda())
+                for sel, t_rand, u in dsched:
+                    loss2, _ = tr.step(ro_all[sel], rd_all[sel], tgt_all[sel], t_rand=t_rand, u=u)
                     losses.append(loss2[0])
                 assert tr.last_step_live == key.endswith('compacted')
                 losses = torch.stack(losses).cpu().numpy()
                 psnr[key].append(-10 * np.log10(np.mean(losses[-50:])))
                 psnr[key + '_prefix'].append(-10 * np.log10(np.mean(losses[n_prefix - 10:n_prefix])))
+            if seed >= n_full:
+                continue
             sdc, sdf = init
             opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
             lc = []
             for it, (sel, t_rand, u) in enumerate(sched[:n_prefix]):
                 opt.lr = O.lr_schedule(5e-4, 500, it - 1) if it > 0 else 5e-4
-                l1, _, _, _ = O.train_step(sdc, sdf, opt, O.make_ray_batch(ro_all[sel], rd_all[sel], 2.0, 6.0), tgt_all[sel], 16, 16,
-                                           True, t_rand=t_rand, u=u)
+                l1, _, _, _ = O.train_step(sdc, sdf, opt, O.make_ray_batch(ro_all[sel].cpu(), rd_all[sel].cpu(), 2.0, 6.0), tgt_all[sel].cpu(),
+                                           16, 16, True, t_rand=t_rand, u=u)
                 lc.append(float(l1))
             psnr['oracle_prefix'].append(-10 * np.log10(np.mean(lc[-10:])))
     finally:
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)
     m = {k: float(np.mean(v)) for k, v in psnr.items()}
-    print('PSNR300', {k: [round(float(x), 3) for x in v] for k, v in psnr.items()})
-    assert m['fp32'] > m['fp32_prefix'] + 1.0                                  # 240 more iterations did train
-    mode_fp32 = 0.5 * (m['fp32'] + m['fp32_compacted'])
-    mode_bf16 = 0.5 * (m['bf16x3'] + m['bf16x3_compacted'])
-    # the modes, at 300 iterations (8 runs each): within north_star's 0.1 dB -- or, when the four per-seed differences scatter
-    # more than that (any bit-level change of a summation order re-rolls these chaotic trajectories: the same suite measured
-    # 0.06 and 0.12 dB on two such re-rolls), within 2.5 standard errors of their mean, i.e. statistically indistinguishable
-    d = (0.5 * (np.array(psnr['bf16x3']) + np.array(psnr['bf16x3_compacted']))
-         - 0.5 * (np.array(psnr['fp32']) + np.array(psnr['fp32_compacted'])))
+    a32, a16 = np.array(psnr['fp32']), np.array(psnr['bf16x3'])
+    # About one seed in six never leaves the empty-scene solution within 300 iterations (the SAME seeds in both modes: a property
+    # of the initial weights; training PSNR 6.5 dB), and a few sit on the edge of it, where a rounding decides between 6 and 29 dB.
+    # The modes are compared on the seeds whose runs train in BOTH modes; how many collapse must agree too.
+    ok = (a32 > 20) & (a16 > 20)
+    assert ok.sum() >= 0.7 * n_seeds and abs(int((a32 > 20).sum()) - int((a16 > 20).sum())) <= 3, (int((a32 > 20).sum()), int((a16 > 20).sum()))
+    assert float(a32[ok].mean()) > float(np.mean(np.array(psnr['fp32_prefix'])[ok])) + 1.0   # 240 more iterations did train
+    d = a16[ok] - a32[ok]                                                    # per-seed difference of the modes, plain backward
     se = float(np.std(d, ddof=1) / np.sqrt(len(d)))
-    print('PSNR300 per-seed mode differences', [round(float(x), 3) for x in d], 'standard error', round(se, 3))
-    assert abs(mode_bf16 - mode_fp32) < max(0.1, 2.5 * se), (mode_bf16, mode_fp32, se, m)
-    assert abs(mode_bf16 - mode_fp32) < 0.3, (mode_bf16, mode_fp32, m)          # and never by more than the noise floor's bound
-    for k in keys:                                                             # vs the oracle, on its prefix
-        assert abs(m[k + '_prefix'] - m['oracle_prefix']) < 0.1, (k, m)
-    # the noise floor: same arithmetic, other summation grouping (measured 0.12-0.15 dB on the 4-seed mean)
-    assert abs(m['fp32_compacted'] - m['fp32']) < 0.3 and abs(m['bf16x3_compacted'] - m['bf16x3']) < 0.3, m
+    print('PSNR300 modes: %d of %d seeds train in both modes; mean fp32 %.3f, mean bf16x3 %.3f, mean per-seed difference %+.3f dB, '
+          'per-seed std %.3f, standard error %.3f' % (len(d), n_seeds, a32[ok].mean(), a16[ok].mean(), float(d.mean()), float(np.std(d, ddof=1)), se))
+    assert se < 0.045, se                                                    # the comparison has the power to see 0.1 dB (2.2 standard errors) ...
+    assert abs(float(d.mean())) < 0.1, (float(d.mean()), se)                 # ... and the modes agree within it (north_star)
+    for k in keys:                                                           # vs the oracle, on its prefix (before the divergence)
+        assert abs(float(np.mean(psnr[k + '_prefix'][:n_full])) - m['oracle_prefix']) < 0.1, (k, m)
+    # the noise floor: same arithmetic, other summation grouping (one seed moves by up to 0.4 dB, the 4-seed mean by 0.12-0.15 dB)
+    for base in ('fp32', 'bf16x3'):
+        assert abs(float(np.mean(psnr[base + '_compacted'])) - float(np.mean(psnr[base][:n_full]))) < 0.3, m
+
+
+def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
+    """The metric's second half at BASELINE configs[1]'s shape: 100 cameras of 800 x 800, 64 + 128 samples, 512 uniformly drawn
+    rays per iteration, 200 iterations, identical batches / injected t_rand, u / initial weights on the GPU and on the CPU oracle
+    (bench.py's `psnr_vs_cpu` leg: the same functions).  Three statements:
+      1. LOCKSTEP -- the GPU step taken from the CPU run's state before every iteration gives the CPU's loss to 1e-5 and hence its
+         PSNR window to < 0.01 dB (north_star's 0.1 dB with an order of magnitude to spare), in both math modes: there is no bias;
+      2. the first iterations of the FREE runs agree to 1e-4 (they decorrelate later: chaotic trajectories);
+      3. at 200 iterations the CPU's free-run PSNR is a member of the GPU's own distribution: within 4 standard deviations (+ 0.05 dB)
+         of a 9-member ensemble of fp32 runs whose initial weights differ by a random ulp.
+    The CPU run takes ~5 minutes of host time (PSNR_TEST_ITERS shortens it for local runs); tests/conftest.py starts it when the
+    collection is known, so it runs beside the rest of the suite."""
+    import json
+    import conftest
+    import bench as B
+    run = getattr(request.config, '_psnr_cpu_run', None)
+    if run is None:
+        run = conftest.start_psnr_cpu_run()
+    assert isinstance(run, dict), run
+    _, _, K, _, new_trainer = conftest.psnr_protocol(fn)
+    dev = torch.device('cuda')
+    data, iters = run['data'], run['data']['iters']
+    old, old_c = fn.ops.get_math(), fn.render.get_compact()
+    try:
+        dd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+        free = {m: B.psnr_gpu_free(fn, dd, new_trainer, K, m) for m in ('fp32', 'bf16x3')}
+        ens = [free['fp32'][0]] + [B.psnr_gpu_free(fn, dd, new_trainer, K, 'fp32', jitter_ulp_seed=100 + j)[0] for j in range(8)]
+        _, err = run['proc'].communicate()
+        assert run['proc'].returncode == 0, err.decode()[-2000:]
+        cpu = json.load(open(run['out']))
+        states = np.load(run['out'] + '.states', mmap_mode='r')
+        cpu_train = B.psnr_of(cpu['losses'], 20)
+        cpu_held = -10.0 * np.log10(cpu['held_out_mse'])
+        # 1. lockstep
+        for mode in ('fp32', 'bf16x3'):
+            r = B.psnr_gpu_lockstep(fn, dd, new_trainer, states, cpu['losses'], mode)
+            print('PSNR-vs-CPU lockstep', mode, r, 'cpu', cpu_train)
+            assert r['max_rel_loss_diff'] < 1e-5, (mode, r)
+            assert abs(r['train_psnr_db'] - cpu_train) < 0.01, (mode, r, cpu_train)
+            assert r['max_rel_update_diff_l2'] < 1e-2, (mode, r)
+        # 2. the free runs before they decorrelate
+        n0 = min(10, iters)
+        for mode in ('fp32', 'bf16x3'):
+            g = np.asarray(free[mode][1][:n0])
+            c = np.asarray(cpu['losses'][:n0])
+            assert np.max(np.abs(g - c) / c) < 1e-4, (mode, g, c)
+        # 3. the CPU's free run against the GPU's own run-to-run distribution
+        for key, cpu_v in (('train_psnr_db', cpu_train), ('held_out_psnr_db', cpu_held)):
+            v = np.array([e[key] for e in ens])
+            sd = float(np.std(v, ddof=1))
+            print('PSNR-vs-CPU free', key, 'cpu %.3f' % cpu_v, 'gpu fp32 ensemble mean %.3f std %.3f' % (v.mean(), sd),
+                  'bf16x3 %.3f' % free['bf16x3'][0][key])
+            assert abs(cpu_v - v.mean()) < 4 * sd + 0.05, (key, cpu_v, v.tolist())
+            assert abs(free['bf16x3'][0][key] - v.mean()) < 4 * sd + 0.05, (key, free['bf16x3'][0][key], v.tolist())
+    finally:
+        fn.ops.set_math(old)
+        fn.render.set_compact(old_c)
 
 
 def test_train_driver_with_quadtree(fn):
