@@ -226,6 +226,7 @@ def psnr_gpu_lockstep(fastnerf, dd, new_trainer, states, cpu_losses, mode):
     ls = torch.stack(ls).cpu().numpy()
     cl = np.asarray(cpu_losses)
     return {'train_psnr_db': psnr_of(ls.tolist(), 20), 'max_rel_loss_diff': float(np.max(np.abs(ls - cl) / cl)),
+            'median_rel_loss_diff': float(np.median(np.abs(ls - cl) / cl)),
             'max_rel_update_diff_l2': max(upd) if upd else None}
 
 

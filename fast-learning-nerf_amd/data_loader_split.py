@@ -54,6 +54,23 @@ def shrink_area(img, factor):
     return blocks.mean(axis=(1, 3), dtype=np.float32)
 
 
+def shrink_linear(img, factor):
+    """cv2.resize(..., INTER_LINEAR) to 1/factor of the size for an integer factor (nerf_sample_ray_split.py:82): destination
+    pixel x samples the source at factor * (x + 0.5) - 0.5 (half-pixel centres) -- for an even factor the midpoint of the two
+    central source pixels of its block in each direction (their 2 x 2 mean), for an odd one the block's central pixel.
+    OpenCV is not vendored or pinned by the reference: restated from its documented sampling rule, parity unpinned."""
+    if factor == 1:
+        return img
+    h, w = img.shape[0] // factor, img.shape[1] // factor
+    c = (factor - 1) // 2
+    if factor % 2:
+        return np.ascontiguousarray(img[c::factor, c::factor][:h, :w])
+    a = img[c::factor][:h].astype(np.float32)
+    b = img[c + 1::factor][:h].astype(np.float32)
+    rows = 0.5 * a + 0.5 * b
+    return (0.5 * rows[:, c::factor][:, :w] + 0.5 * rows[:, c + 1::factor][:, :w]).astype(np.float32)
+
+
 def shrink_nearest(img, factor):
     return img[::factor, ::factor][:img.shape[0] // factor, :img.shape[1] // factor]
 
@@ -84,10 +101,8 @@ class RaySamplerSingleImage:
         if self.mask_path is not None:
             self.mask = shrink_nearest(_read_image(self.mask_path), lvl).reshape(-1)
         if self.min_depth_path is not None:
-            if lvl != 1:
-                raise NotImplementedError('min_depth maps are only read at full resolution (the reference resamples them '
-                                          'with cv2 INTER_LINEAR, which is not restated here)')
-            self.min_depth = (_read_image(self.min_depth_path) * self.max_depth + 1e-4).reshape(-1)
+            md = _read_image(self.min_depth_path) * self.max_depth + 1e-4
+            self.min_depth = np.ascontiguousarray(shrink_linear(md, lvl)).reshape(-1)
         self._rays = None
 
     def _ray_tensors(self):

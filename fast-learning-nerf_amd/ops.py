@@ -37,6 +37,21 @@ def set_math(mode):
     _MATH = mode
 
 
+# math mode a packed-weight buffer was produced under: a Python attribute on the tensor object AND a registry by storage
+# address (a tensor that went through the PyTorch dispatcher -- torch.ops.fastnerf.mlp_fwd -- is a fresh object without the
+# attribute), so that weights packed under one mode and used under the other are an error, never garbage
+_PACK_TAGS = {}
+
+
+def _tag_packed(t, tag):
+    t._fn_math = tag
+    _PACK_TAGS[(t.device.index, t.data_ptr())] = tag
+
+
+def packed_tag(t):
+    return packed_tag(t) or _PACK_TAGS.get((t.device.index, t.data_ptr()))
+
+
 def _split(kind):
     return _MATH == 'bf16x3' and int(kind) in (0, 1, 2)
 
@@ -145,7 +160,8 @@ def mlp_pack(params, packed_fwd=None, packed_bwd=None, kind=0):
     assert packed_fwd.numel() == packed_floats(kind, 1) and packed_bwd.numel() == packed_floats(kind, 2), \
         'packed buffers were sized under a different math mode'
     # the two modes' buffers can have the same size: tag them so that a mix-up is an error, not garbage
-    packed_fwd._fn_math = packed_bwd._fn_math = 'bf16x3' if _split(kind) else 'fp32'
+    for t in (packed_fwd, packed_bwd):
+        _tag_packed(t, 'bf16x3' if _split(kind) else 'fp32')
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_pack(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),
               'fastnerf_mlp_bf16_pack')
@@ -164,7 +180,7 @@ def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None, kind=0):
         raw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
     if act is not None:
         assert act.numel() >= act_floats(n * S, kind)
-    assert packed_fwd.numel() == packed_floats(kind, 1) and getattr(packed_fwd, '_fn_math', None) == ('bf16x3' if _split(kind) else 'fp32'), \
+    assert packed_fwd.numel() == packed_floats(kind, 1) and packed_tag(packed_fwd) == ('bf16x3' if _split(kind) else 'fp32'), \
         'packed weights were not produced by mlp_pack under the current math mode'
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_fwd(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw),
@@ -183,7 +199,7 @@ def mlp_bwd(draw, act, params, packed_bwd, dact, partial, grads, kind=0):
     require_gpu(draw, act, params, packed_bwd, dact, partial, grads)
     n, S = draw.shape[0], draw.shape[1]
     assert dact.numel() >= dact_floats(n * S, kind) and grads.numel() == net_floats(kind, 0)
-    assert packed_bwd.numel() == packed_floats(kind, 2) and getattr(packed_bwd, '_fn_math', None) == ('bf16x3' if _split(kind) else 'fp32'), \
+    assert packed_bwd.numel() == packed_floats(kind, 2) and packed_tag(packed_bwd) == ('bf16x3' if _split(kind) else 'fp32'), \
         'packed weights were not produced by mlp_pack under the current math mode'
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_bwd(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
@@ -220,7 +236,7 @@ def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N
     f32 = dict(device=dev, dtype=torch.float32)
     split = _split(0)
     tag = 'bf16x3' if split else 'fp32'
-    assert getattr(packed_c, '_fn_math', None) == tag and (packed_f is None or getattr(packed_f, '_fn_math', None) == tag), \
+    assert packed_tag(packed_c) == tag and (packed_f is None or packed_tag(packed_f) == tag), \
         'packed weights were not produced by mlp_pack under the current math mode'
     if t_rand is not None:
         t_rand = _f32(t_rand)
@@ -268,7 +284,7 @@ def render_rays_bwd(rays11, white_bkgd, g_rgb, g_rgb0, noise0, noise1, z0, raw0,
     n = rays11.shape[0]
     S1 = N_samples + N_importance
     tag = 'bf16x3' if _split(0) else 'fp32'
-    assert getattr(packed_bwd_c, '_fn_math', None) == tag and (packed_bwd_f is None or getattr(packed_bwd_f, '_fn_math', None) == tag), \
+    assert packed_tag(packed_bwd_c) == tag and (packed_bwd_f is None or packed_tag(packed_bwd_f) == tag), \
         'packed weights were not produced by mlp_pack under the current math mode'
     assert draw_ws.numel() >= n * S1 * 4 and dact_ws.numel() >= dact_floats(n * S1)
     check(lib().fastnerf_render_rays_bwd(
@@ -296,7 +312,7 @@ def mlp_fwd_live(rays11, z, params, packed_fwd, act, live_idx, live_cnt, kind=0)
     n, S = z.shape
     tag = 'bf16x3' if _split(kind) else 'fp32'
     assert act.numel() >= act_floats(n * S, kind) and live_idx.dtype == torch.int32 and live_cnt.dtype == torch.int32
-    assert packed_fwd.numel() == packed_floats(kind, 1) and getattr(packed_fwd, '_fn_math', None) == tag
+    assert packed_fwd.numel() == packed_floats(kind, 1) and packed_tag(packed_fwd) == tag
     fn = lib().fastnerf_mlp_bf16_fwd_live if _split(kind) else lib().fastnerf_mlp_fwd_live_ex
     check(fn(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(act), ptr(live_idx), ptr(live_cnt), stream()),
           'fastnerf_mlp_fwd_live')
@@ -307,7 +323,7 @@ def mlp_bwd_live(draw, act, params, packed_bwd, dact, partial, grads, live_idx, 
     n, S = draw.shape[0], draw.shape[1]
     tag = 'bf16x3' if _split(kind) else 'fp32'
     assert dact.numel() >= dact_floats(n * S, kind) and grads.numel() == net_floats(kind, 0)
-    assert packed_bwd.numel() == packed_floats(kind, 2) and getattr(packed_bwd, '_fn_math', None) == tag
+    assert packed_bwd.numel() == packed_floats(kind, 2) and packed_tag(packed_bwd) == tag
     fn = lib().fastnerf_mlp_bf16_bwd_live if _split(kind) else lib().fastnerf_mlp_bwd_live_ex
     check(fn(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact), ptr(partial), ptr(grads), ptr(live_idx),
              ptr(live_cnt), stream()), 'fastnerf_mlp_bwd_live')
@@ -330,7 +346,7 @@ def render_rays_bwd_live(rays11, white_bkgd, g_rgb, g_rgb0, noise0, noise1, z0, 
     S1 = N_samples + N_importance
     tag = 'bf16x3' if _split(0) else 'fp32'
     for pk in (packed_c, packed_f):
-        assert pk is None or all(getattr(t, '_fn_math', None) == tag for t in pk)
+        assert pk is None or all(packed_tag(t) == tag for t in pk)
     assert draw_ws.numel() >= n * S1 * 4 and dact_ws.numel() >= dact_floats(n * S1) and act_ws.numel() >= act_floats(n * S1)
     assert live_ws.dtype == torch.int32 and live_ws.numel() >= live_ws_ints(n * S1)
     check(lib().fastnerf_render_rays_bwd_live(

@@ -285,7 +285,7 @@ class Trainer:
         P0, P1 = n * S0, n * S1
         ops.require_gpu(rays_o, rays_d, target, leaf_tag, table, t_rand, u)
         tag = 'bf16x3' if ops.get_math() == 'bf16x3' else 'fp32'
-        if getattr(self.pc[0], '_fn_math', None) != tag:
+        if ops.packed_tag(self.pc[0]) != tag:
             self.repack()           # the math mode changed under this trainer
             self._sa_key = None
         live = self.live.use_live(self.net_c, self.net_f, Ni)
@@ -460,13 +460,19 @@ class Trainer:
         if len(st) == 0:
             self.m.zero_(); self.v.zero_(); self.adam_t = 0
             return
+        # a parameter that never received a gradient has NO entry in torch.optim.Adam's state (e.g. the unused views_linears.0 of
+        # a reference checkpoint trained without view directions, model.py:60-61): zero moments, step count from the others
         off, steps = 0, set()
         for i, p in enumerate(self._param_list()):
             k = p.numel()
-            e = st[i]
-            self.m[off:off + k].copy_(torch.as_tensor(e['exp_avg']).reshape(-1))
-            self.v[off:off + k].copy_(torch.as_tensor(e['exp_avg_sq']).reshape(-1))
-            steps.add(int(float(e['step'])))
+            e = st.get(i)
+            if e is None:
+                self.m[off:off + k].zero_()
+                self.v[off:off + k].zero_()
+            else:
+                self.m[off:off + k].copy_(torch.as_tensor(e['exp_avg']).reshape(-1))
+                self.v[off:off + k].copy_(torch.as_tensor(e['exp_avg_sq']).reshape(-1))
+                steps.add(int(float(e['step'])))
             off += k
         assert off == self.flat.numel() and len(steps) == 1, 'optimizer state does not match the parameter list'
         self.adam_t = steps.pop()
@@ -495,7 +501,8 @@ def save_checkpoint(args, epoch_id, trainer, kw_train, mgr):
     path = os.path.join(d, '{:03d}.tar'.format(epoch_id))
     torch.save({'global_epoch': epoch_id, 'global_iter': trainer.global_iter,
                 'network_fn_state_dict': reference_state_dict(kw_train['network_fn']),
-                'network_fine_state_dict': reference_state_dict(kw_train['network_fine']),
+                'network_fine_state_dict': (None if kw_train['network_fine'] is None    # N_importance = 0: run_nerf.py:536 fails
+                                            else reference_state_dict(kw_train['network_fine'])),   # on None.state_dict(); None is kept
                 'optimizer_state_dict': trainer.torch_optimizer_state_dict()}, path)
     mgr.save_trees(tree_pkl_path(args, epoch_id))
     return path

@@ -72,7 +72,8 @@ def _(x, L):
 
 @_lib_def('fastnerf::mlp_fwd', mutates_args=())
 def mlp_fwd(rays11: Tensor, z: Tensor, params: Tensor, packed_fwd: Tensor) -> Tensor:
-    packed_fwd._fn_math = ops.get_math() if ops.get_math() == 'bf16x3' else 'fp32'   # (the tag does not survive the dispatcher)
+    # (the tensor objects the dispatcher hands over carry no Python attributes: ops.mlp_fwd finds the math mode packed_fwd
+    # was produced under in ops.mlp_pack's registry by storage address, and raises when it is not the current mode)
     return ops.mlp_fwd(rays11, z, params, packed_fwd)
 
 
@@ -111,6 +112,10 @@ def _r2o_setup(ctx, inputs, output):
 def _r2o_backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
     # the training loss reaches the network through the colour map only (run_nerf.py:482-490): that is the implemented formula
     raw, z, rays11, noise = ctx.saved_tensors
+    for name, g in (('disp', g_disp), ('acc', g_acc), ('weights', g_w), ('depth', g_depth)):
+        if g is not None and bool((g != 0).any()):
+            raise NotImplementedError('torch.ops.fastnerf.raw2outputs is differentiable through the colour map only; got a non-zero '
+                                      'gradient for ' + name)
     draw = torch.ops.fastnerf.raw2outputs_bwd(raw, z, rays11, g_rgb, noise if ctx.has_noise else None, ctx.white)
     return draw, None, None, None, None
 

@@ -61,3 +61,22 @@ def test_directory_reader(g, tmp_path):
         bad = os.path.join(base, 'bad.txt')
         open(bad, 'w').write('1 2 3')
         read_matrix_txt(bad)
+
+
+def test_min_depth_half_resolution_is_the_bilinear_sample_at_pixel_centres():
+    """load_data_split builds its samplers at resolution level 2, and a scene with a min_depth folder must load there.
+    cv2.resize(INTER_LINEAR) samples destination pixel x at 2x + 0.5 in the source: the mean of the 2 x 2 block (restated from
+    OpenCV's documented rule; parity unpinned -- OpenCV is neither vendored nor pinned by the reference)."""
+    import numpy as np
+    from fastnerf.data_loader_split import shrink_linear
+    rng = np.random.default_rng(0)
+    img = rng.random((10, 14)).astype(np.float32)
+    out = shrink_linear(img, 2)
+    assert out.shape == (5, 7) and out.dtype == np.float32
+    ref = 0.25 * (img[0::2, 0::2] + img[1::2, 0::2] + img[0::2, 1::2] + img[1::2, 1::2])
+    assert np.abs(out - ref).max() < 1e-6
+    assert np.array_equal(shrink_linear(img, 1), img)
+    o3 = shrink_linear(img[:9, :12], 3)                      # odd factor: the block's central pixel
+    assert np.array_equal(o3, img[1:9:3, 1:12:3])
+    o4 = shrink_linear(rng.random((8, 8)).astype(np.float32), 4)
+    assert o4.shape == (2, 2)

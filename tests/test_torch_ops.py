@@ -51,3 +51,35 @@ def test_custom_ops_on_the_gpu(golden_dir):
     fastnerf.ops.adam_step(p2, gr, m2, v2, 5e-4, 3, 0.9, 0.999, 1e-8)
     assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2) and not torch.equal(p, gr)
     torch.library.opcheck(torch.ops.fastnerf.sample_coarse.default, (r11, 16, False, False, None, 0), test_utils=('test_schema', 'test_faketensor'))
+
+
+@pytest.mark.gpu
+def test_mlp_fwd_op_checks_the_math_mode_and_r2o_backward_refuses_other_gradients():
+    """weights packed under one math mode and used under the other through the dispatcher are an error (the
+    dispatcher hands the op fresh tensor objects: the tag lives in ops.mlp_pack's registry); the registered autograd formula
+    of raw2outputs implements d/d(raw) through the colour map only and says so when asked for more."""
+    import fastnerf
+    from fastnerf import ops
+    old = ops.get_math()
+    try:
+        ops.set_math('fp32')
+        torch.manual_seed(0)
+        net = fastnerf.model.NeRF()
+        pf, _ = net.packed()
+        r11 = torch.zeros(8, 11).cuda()
+        r11[:, 3:6] = torch.randn(8, 3).cuda()
+        r11[:, 8:11] = torch.nn.functional.normalize(r11[:, 3:6], dim=-1)
+        z = torch.rand(8, 4).cuda() + 2
+        raw = torch.ops.fastnerf.mlp_fwd(r11, z, net.flat, pf)
+        assert torch.equal(raw, ops.mlp_fwd(r11, z, net.flat, pf))
+        ops.set_math('bf16x3')
+        with pytest.raises(AssertionError):
+            torch.ops.fastnerf.mlp_fwd(r11, z, net.flat, pf)      # fp32-packed weights under the split-bf16 mode
+        with pytest.raises(AssertionError):
+            torch.ops.fastnerf.mlp_fwd(r11, z, net.flat, torch.empty_like(pf))   # a buffer mlp_pack never produced
+    finally:
+        ops.set_math(old)
+    raw = torch.randn(8, 4, 4).cuda().requires_grad_(True)
+    rgb, disp, acc, w, depth = torch.ops.fastnerf.raw2outputs(raw, z, r11, None, False)
+    with pytest.raises(NotImplementedError):
+        (rgb.sum() + depth.sum()).backward()
