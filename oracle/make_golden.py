@@ -223,8 +223,21 @@ def main():
     ro8 = o_b.reshape(-1, 3)[sel].contiguous()
     rd8 = d_b.reshape(-1, 3)[sel].contiguous()
     tgt = torch.rand(256, 3, generator=g)
-    rgb, disp, acc, ex = R.render(800, 800, K, chunk=32768, rays=torch.stack([ro8, rd8], 0), retraw=True,
-                                  near=2.0, far=6.0, pytest=True, **kw_train)
+    # the sample depths of both passes are locals of the reference's render_rays (render.py:244-283): recorded through the
+    # z_vals argument of its two raw2outputs calls, so that the fine pass can be replayed at the reference's own positions
+    seen_z = []
+    orig_r2o = R.raw2outputs
+
+    def recording_r2o(raw, z_vals, *a, **k):
+        seen_z.append(z_vals.detach().numpy().copy())
+        return orig_r2o(raw, z_vals, *a, **k)
+    R.raw2outputs = recording_r2o
+    try:
+        rgb, disp, acc, ex = R.render(800, 800, K, chunk=32768, rays=torch.stack([ro8, rd8], 0), retraw=True,
+                                      near=2.0, far=6.0, pytest=True, **kw_train)
+    finally:
+        R.raw2outputs = orig_r2o
+    assert len(seen_z) == 2 and seen_z[0].shape == (256, 64) and seen_z[1].shape == (256, 192)
     optim.zero_grad()
     l1 = H.img2mse(rgb, tgt)
     l0 = H.img2mse(ex['rgb0'], tgt)
@@ -242,7 +255,8 @@ def main():
     new_lr = 5e-4 * (0.1 ** (0 / (500 * 1000)))
     np.savez(os.path.join(OUT, 'g8_train_step.npz'), ro=ro8.numpy(), rd=rd8.numpy(), target=tgt.numpy(), t_rand=t8, u=u8,
              loss=float(l1), loss0=float(l0), psnr=float(H.mse2psnr(l1.detach())[0]), rgb=rgb.detach().numpy(),
-             rgb0=ex['rgb0'].detach().numpy(), new_lr=new_lr, **grads, **post)
+             rgb0=ex['rgb0'].detach().numpy(), new_lr=new_lr, z0=seen_z[0], z_vals=seen_z[1],
+             raw=ex['raw'].detach().numpy(), **grads, **post)
 
     # ---- G9 quadtree -------------------------------------------------------
     tree_out = {}

@@ -156,3 +156,43 @@ class Manager:
 
     def leaf_array(self, ti):
         return np.array(self.trees[ti].leaves, dtype=np.float64).reshape(-1, 4)
+
+
+# --------------------------------------------------------------------------
+# nerf++-ours fork: variance-weighted picks (prob=True)
+# --------------------------------------------------------------------------
+def to_prob_v2(gray_img):
+    """ImageProcessor.to_prob_v2 (nerf++-ours/image_process.py:58-72): sampling probability of every pixel of a block of
+    the local-variance map -- values + 1e-6, clipped from below at 1 % of their mean, scaled by the maximum, normalised."""
+    raw_shape = np.shape(gray_img)
+    g = np.asarray(gray_img, dtype=np.float64).flatten() + 1e-6
+    g_min = 0.01 * np.mean(g)
+    g_max = np.max(g)
+    g = np.clip(g, g_min, g_max)
+    g = (g - 0) / (g_max - 0)
+    return np.reshape(g / np.sum(g), raw_shape)
+
+
+def leaf_pick_split(ray_num, rand_samp):
+    """nerf++-ours/tree.py:566-568: (weighted picks, uniform picks) of a leaf."""
+    n1 = int(ray_num * (1 - rand_samp))
+    return n1, ray_num - n1
+
+
+def expected_pixel_counts(trees, H, W, sharp_imgs, ray_num_per_pixel, prob, rand_samp):
+    """Expected number of picks per pixel of ONE epoch of gen_rays_v3_1_subThread (nerf++-ours/tree.py:548-607): per leaf
+    `leaf_ray_num` picks; with prob=True the first int(n (1 - rand)) of them are np.random.choice draws over the block
+    [int(x0):int(x1), int(y0):int(y1)] of the variance map with probability to_prob_v2 (image_process.py:74-93), the rest
+    (all of them with prob=False) torch.randint over rows [ceil(x0), ceil(x1)) x columns [ceil(y0), ceil(y1 - 0.01)).
+    -> float64 [n_images, H, W]."""
+    out = np.zeros((len(trees), H, W), dtype=np.float64)
+    for ti, tr in enumerate(trees):
+        for b in tr.leaves:
+            n = leaf_ray_num(tr, b, ray_num_per_pixel)
+            n1, n2 = leaf_pick_split(n, rand_samp) if prob else (0, n)
+            if n1 > 0:
+                x0, y0, x1, y1 = int(b[0]), int(b[1]), int(b[2]), int(b[3])
+                out[ti, x0:x1, y0:y1] += n1 * to_prob_v2(np.asarray(sharp_imgs[ti])[x0:x1, y0:y1])
+            r0, r1, c0, c1 = leaf_pixel_range(b)
+            out[ti, r0:r1, c0:c1] += n2 / float((r1 - r0) * (c1 - c0))
+    return out

@@ -128,6 +128,59 @@ def test_train_step_g8_fused(fn, golden_dir, math_mode):
     assert abs(tr.lr - float(g['new_lr'])) < 1e-12 and tr.global_iter == 1 and tr.adam_t == 1
 
 
+def test_train_step_g8_gradients_against_the_reference(fn, golden_dir, math_mode):
+    """G8's gradients against the REFERENCE's at the tight bound (relative L2 <= 2e-3, max <= 1e-2 of each tensor's max).  The
+    coarse pass's sample positions are well conditioned (the device's are the reference's to the last bit), so its gradient
+    comes straight from the fused step.  The fine pass is replayed at the depths the reference itself used -- its `z_vals`
+    (render.py:283), recorded in the golden -- through the per-stage entry points (fastnerf_mlp_fwd with explicit depths ->
+    raw2outputs -> mse -> raw2outputs_bwd -> mlp_bwd): same positions, so logits agree to 2e-5 and what is left between the
+    gradients are single ReLU-mask flips.  The 3e-2 bound of test_train_step_g8_fused is the price of the
+    device's OWN inverse-CDF positions (ill-conditioned in the reference itself), not of the kernels."""
+    g = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+    K = np.load(os.path.join(golden_dir, 'g1_get_rays.npz'))['K']
+    ktr, _, _, _ = build(fn, golden_dir)
+    tr = fn.run_nerf.Trainer(ktr, 800, 800, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+    ro, rd, tgt = (torch.from_numpy(g[k]).cuda() for k in ('ro', 'rd', 'target'))
+    loss2, out = tr.forward_backward(ro, rd, tgt, t_rand=torch.from_numpy(g['t_rand']).cuda(), u=torch.from_numpy(g['u']).cuda())
+    assert torch.equal(out['z0'].cpu(), torch.from_numpy(g['z0']))          # coarse depths: the reference's, bit for bit
+    zf = out['z_vals'].cpu().numpy()
+    moved = np.abs(zf - g['z_vals']) > 2e-5                                   # the fine depths are NOT (DESIGN 5 (i)): most agree,
+    assert moved.mean() < 0.02 and np.abs(zf - g['z_vals']).max() < 0.07      # a few sit one inverse-CDF bin away
+    shapes = O.nerf_param_shapes()
+
+    def check(flat, pre):
+        off = 0
+        for n, shp in shapes:
+            ref = torch.from_numpy(g['grad.' + pre + n])
+            k = ref.numel()
+            got = flat[off:off + k].view(shp).cpu()
+            assert (got - ref).norm() <= 2e-3 * ref.norm() + 1e-12, (pre + n, float((got - ref).norm() / ref.norm()))
+            assert (got - ref).abs().max() <= 1e-2 * max(float(ref.abs().max()), 1e-7), (pre + n)
+            off += k
+        assert off == fn.ops.NET_PARAMS
+    check(tr.grad[:fn.ops.NET_PARAMS], 'c.')
+    # the fine pass at the reference's depths
+    ops = fn.ops
+    net = ktr['network_fine']
+    pf, pb = net.packed()
+    rays11 = ops.pack_rays(ro, rd, 2.0, 6.0)
+    z = torch.from_numpy(g['z_vals']).cuda()
+    P = z.numel()
+    act = torch.empty(ops.act_floats(P), device='cuda')
+    raw = ops.mlp_fwd(rays11, z, net.flat, pf, act=act)
+    ref_raw = torch.from_numpy(g['raw'])
+    assert ((raw.cpu() - ref_raw).abs() <= 2e-5 * ref_raw.abs().clamp(min=1.0)).all()
+    rgb = ops.raw2outputs_fwd(raw, z, rays11, None, True)[0]
+    assert np.abs(rgb.cpu().numpy() - g['rgb']).max() < 1e-5
+    l2, grgb, _ = ops.mse_leafmax(rgb, None, tgt)
+    assert abs(float(l2[0]) - float(g['loss'])) < 1e-6
+    draw = ops.raw2outputs_bwd(raw, z, rays11, grgb, None, True)
+    gout = torch.empty(ops.NET_PARAMS, device='cuda')
+    ops.mlp_bwd(draw, act, net.flat, pb, torch.empty(ops.dact_floats(P), device='cuda'),
+                torch.empty(ops.mlp_bwd_partial_floats(), device='cuda'), gout)
+    check(gout, 'f.')
+
+
 def test_train_step_g8_autograd_route(fn, golden_dir):
     """The reference's own loop shape: render(...); loss.backward(); optimizer.step()."""
     g = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))

@@ -55,3 +55,27 @@ def test_seeded_gen_adjust_sequence(golden_dir, shape):
     assert np.array_equal(mgr.result_leaf_id.numpy(), g['last_leaf_id'])
     assert np.array_equal(images[pix[:, 0], pix[:, 1], pix[:, 2]].numpy(), g['last_rgb'])
     assert pix.shape[0] == n * H * W
+
+
+def test_weighted_pick_distribution_g20(golden_dir):
+    """G20 (recorded from nerf++-ours by oracle/make_golden_prob.py): the oracle's to_prob_v2 is the reference's bit for bit, and
+    its per-pixel expectation of one prob=True epoch (tree.py:548-607) explains the reference's own pixel histogram over 400 seeded
+    epochs: 5 sigma per pixel, and chi-square over all pixels.  This is what tests/test_gpu_epoch_rays.py takes the device
+    sampler's expectation from.  (The variance maps are an input fixture: get_sharp_img rests on OpenCV, parity unpinned.)"""
+    g = np.load(os.path.join(golden_dir, 'g20_pp_prob.npz'))
+    for i in range(3):
+        p = TO.to_prob_v2(g['block%d' % i])
+        assert p.dtype == np.float64 and np.array_equal(p, g['prob%d' % i])
+    H, W, rounds, rand = int(g['H']), int(g['W']), int(g['rounds']), float(g['rand'])
+    mgr = TO.Manager(H, W, 2, 2)
+    exp = rounds * TO.expected_pixel_counts(mgr.trees, H, W, [g['sharp0'], g['sharp1']], 1.0, True, rand)
+    hist = g['hist'].astype(np.float64)
+    assert abs(exp.sum() - hist.sum()) < 1e-6 * hist.sum() and hist.sum() == rounds * int(g['n_rays'])
+    sig = np.sqrt(np.maximum(exp, 1.0))
+    assert (np.abs(hist - exp) <= 5 * sig + 2).all()
+    chi2 = float((((hist - exp) ** 2) / np.maximum(exp, 1e-9)).sum())
+    dof = hist.size - 1
+    assert abs(chi2 - dof) < 6 * np.sqrt(2 * dof), (chi2, dof)
+    # the flat block of image 0 gets the clipped floor, not zero
+    assert exp[0, :8, :8].min() > 0.25 * exp[0].mean() and exp[0, :8, :8].max() < 0.3 * exp[0].mean()   # uniform share + floor
+    assert TO.leaf_pick_split(10, 0.25) == (7, 3) and TO.leaf_pick_split(256, 0.7) == (76, 180)
