@@ -26,6 +26,24 @@
 
 using namespace fnl;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Math modes of this file's kernels (template parameter MM):
+//   MM_F32  v_mfma_f32_32x32x2_f32: the products and sums of an fp32 FMA chain (157 TFLOP/s peak).
+//   MM_X6   "bf16x6": every fp32 operand x is decomposed EXACTLY into three bf16 pieces x = h + m + l (round-to-nearest at
+//           every level: 8 + 8 + 8 significand bits, |m| <= 2^-8 |x|, |l| <= 2^-17 |x|) and a product a*b is evaluated as
+//             a_h b_h + (a_h b_m + a_m b_h) + (a_m b_m + a_h b_l + a_l b_h)
+//           on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: six 32-cycle K=16 instructions instead of eight 64-cycle K=2
+//           ones (2.67x the matrix rate).  The three dropped terms are <= 2^-24 |a b| together, i.e. the product is as
+//           accurate as fp32's own rounding of it -- fp32 width, unlike the two-piece split of mlp_bf16.hip (16 bits).
+//           Weights are packed once per update as three bf16 planes in fragment order; activations / gradients stay fp32 in
+//           LDS and in HBM (same layouts, same bytes as MM_F32) and are split in registers when a fragment is read.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MM_F32 0
+#define MM_X6 1
 
 #ifndef TM
 #define TM 64          // points per tile (fwd / dx)
@@ -101,6 +119,57 @@ __global__ void __launch_bounds__(256) pack_kernel(PackTable tab, const float* _
   }
 }
 
+// MM_X6: three bf16 planes in fragment order of v_mfma_f32_32x32x16_bf16; uint4 units:
+//   dst[((tile*KS16 + ks)*3 + plane)*64 + l] = 8 bf16 = piece `plane` of W'[...][k = ks*16 + (l>>5)*8 + 0..7]
+//   fwd (n = tile*32 + (l&31)): W'[n][k] with the same k -> source column mapping as pack_kernel;  bwd: W[k][col0 + tile*32 + (l&31)]
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // bf16(a) | bf16(b) << 16 (round to nearest even)
+  const f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+// x0, x1 -> packed pieces (h, m, l); exact: x = h + m + l
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  l = cvt_pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+__global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* __restrict__ params,
+                                                     uint4* __restrict__ pf, uint4* __restrict__ pb) {
+  const PackDesc d = tab.d[blockIdx.y];
+  const int KS = (d.transposed ? d.n_rows : d.n_cols) / 16;
+  const int NTL = (d.transposed ? d.n_cols : d.n_rows) / 32;
+  const int64_t total = (int64_t)NTL * KS * 64;          // one thread = the three planes of one (tile, k-step, lane)
+  uint4* dst = (d.transposed ? pb : pf) + d.dst_off * 3 / 8;   // dst_off: floats of the fp32 packing = 8/3 of these uint4
+  const float* src = params + d.src_off;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(e & 63);
+    const int64_t blk = e >> 6;
+    const int tile = (int)(blk / KS), ks = (int)(blk % KS);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kp = ks * 16 + (l >> 5) * 8 + j;
+      v[j] = 0.f;
+      if (!d.transposed) {
+        const int n = tile * 32 + (l & 31);
+        int col = -1;
+        if (kp < d.segA_pad) { if (kp < d.segA_valid) col = kp; }
+        else { const int q = kp - d.segA_pad; if (q < d.segB_valid) col = d.segA_valid + q; }
+        if (col >= 0) v[j] = src[(int64_t)n * d.ld + col];
+      } else {
+        v[j] = src[(int64_t)kp * d.ld + d.col0 + tile * 32 + (l & 31)];
+      }
+    }
+    unsigned h[4], m[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], lo[q]);
+    uint4* o = dst + (blk * 3) * 64 + l;
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[64] = make_uint4(m[0], m[1], m[2], m[3]);
+    o[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 static PackTable make_pack_table(const NetLayout& L) {
   PackTable T;
   int n = 0;
@@ -153,6 +222,21 @@ extern "C" int fastnerf_mlp_pack_ex(int kind, const float* params, float* packed
   static const PackTable T[3] = {make_pack_table(layout_of(0)), make_pack_table(layout_of(1)),
                                  make_pack_table(layout_of(2))};
   hipLaunchKernelGGL(pack_kernel, dim3(64, 19), dim3(256), 0, fn::S(stream), T[kind], params, packed_fwd, packed_bwd);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+// MM_X6 packing: 1.5x the floats of the fp32 packing (three bf16 planes)
+extern "C" int64_t fastnerf_mlp_x6_packed_floats(int kind, int which) {
+  if (kind < 0 || kind > 2 || (which != 1 && which != 2)) return -1;
+  const NetLayout& L = layout_of(kind);
+  return (which == 1 ? L.pf_total : L.pb_total) * 3 / 2;
+}
+extern "C" int fastnerf_mlp_x6_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && params && packed_fwd && packed_bwd, "kind in 0..2, non-null pointers");
+  static const PackTable T[3] = {make_pack_table(layout_of(0)), make_pack_table(layout_of(1)),
+                                 make_pack_table(layout_of(2))};
+  hipLaunchKernelGGL(pack6_kernel, dim3(32, 19), dim3(256), 0, fn::S(stream), T[kind], params,
+                     reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -279,6 +363,110 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[2][NT], const float* __re
 #endif
 }
 
+// ---- MM_X6: the same tile product on v_mfma_f32_32x32x16_bf16 (file header) -------------------------------------------
+// k-steps of 16; a lane (row = lane & 31, kb = lane >> 5) takes k = ks*16 + kb*8 + 0..7: two 16-byte LDS reads of fp32
+// activations, split in registers into the three bf16 pieces; the weight pieces arrive pre-split (pack6_kernel), three
+// 1 KiB wave loads per column tile and k-step.  Small terms first; every product of a k-step shares the accumulator.
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split3_frag(const float4& lo4, const float4& hi4, uint4& h, uint4& m, uint4& l) {
+  split3_pair(lo4.x, lo4.y, h.x, m.x, l.x);
+  split3_pair(lo4.z, lo4.w, h.y, m.y, l.y);
+  split3_pair(hi4.x, hi4.y, h.z, m.z, l.z);
+  split3_pair(hi4.z, hi4.w, h.w, m.w, l.w);
+}
+template <int NT>
+__device__ __forceinline__ void mfma6(f32x16 (&acc)[2][NT], const float4 (&a)[2][2], const uint4 (&b)[NT][3]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    uint4 ah, am, al;
+    split3_frag(a[mt][0], a[mt][1], ah, am, al);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[mt][nt] = mfma_bf16(al, b[nt][0], acc[mt][nt]);
+      acc[mt][nt] = mfma_bf16(ah, b[nt][2], acc[mt][nt]);
+      acc[mt][nt] = mfma_bf16(am, b[nt][1], acc[mt][nt]);
+      acc[mt][nt] = mfma_bf16(am, b[nt][0], acc[mt][nt]);
+      acc[mt][nt] = mfma_bf16(ah, b[nt][1], acc[mt][nt]);
+      acc[mt][nt] = mfma_bf16(ah, b[nt][0], acc[mt][nt]);
+    }
+  }
+}
+// a_ks0 / nks / KS / b_ks0 in 16-wide k-steps; Bp = this layer's packed block (uint4 units)
+template <int NT, int AMODE>
+__device__ __forceinline__ void gemm_seg6(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks,
+                                          const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int wm, int lane,
+                                          float* __restrict__ save_dst, int save_valid, int wave) {
+  asm volatile("" : "+v"(lane));
+  const int lrow = lane & 31, kb = lane >> 5;
+  const float* arow[2];
+  int axor[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = wm * 64 + mt * 32 + lrow;
+    arow[mt] = As + m * (AMODE == 0 ? 256 : (AMODE == 1 ? 64 : 32));
+    axor[mt] = (AMODE == 2) ? ((m >> 1) & 7) : (m & 15);
+  }
+  const uint4* bptr[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 192 + lane;
+  auto load_a = [&](float4 (&a)[2][2], int ks) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        a[mt][j] = *reinterpret_cast<const float4*>(arow[mt] + ((((a_ks0 + ks) * 4 + kb * 2 + j) ^ axor[mt]) << 2));
+  };
+  auto load_b = [&](uint4 (&b)[NT][3], int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[nt][pl] = bptr[nt][ks * 192 + pl * 64];
+  };
+  auto side_copy = [&]() {   // (see gemm_seg)
+    if (AMODE == 0 && save_dst != nullptr) {
+#pragma unroll 4
+      for (int i = 0; i < TM / NWAVES; ++i) {
+        const int m = i * NWAVES + wave;
+        if (m < save_valid) {
+          const float4 v = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
+          store_nt(save_dst + (unsigned)(m * 256 + ((lane ^ (m & 15)) << 2)), v);
+        }
+      }
+    }
+  };
+  float4 a0[2][2], a1[2][2];
+  uint4 b0[NT][3], b1[NT][3];
+  load_b(b0, 0); load_a(a0, 0);
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks += 2) {   // nks is even for every segment
+    load_b(b1, ks + 1); load_a(a1, ks + 1);
+    mfma6<NT>(acc, a0, b0);
+    if (ks + 2 < nks) { load_b(b0, ks + 2); load_a(a0, ks + 2); } else side_copy();
+    mfma6<NT>(acc, a1, b1);
+  }
+}
+
+// one call site for both math modes: k-steps in the 8-wide units of gemm_seg, Bw = the layer's block in this mode's packing
+template <int MM, int NT, int AMODE>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
+                                     int KS, int b_ks0, int nt0, int wm, int lane, int dbg = 0,
+                                     float* __restrict__ save_dst = nullptr, int save_valid = 0, int wave = 0) {
+  if constexpr (MM == MM_X6)
+    gemm_seg6<NT, AMODE>(acc, As, a_ks0 / 2, nks / 2, reinterpret_cast<const uint4*>(Bw), KS / 2, b_ks0 / 2, nt0, wm, lane,
+                         save_dst, save_valid, wave);
+  else
+    gemm_seg<NT, AMODE>(acc, As, a_ks0, nks, reinterpret_cast<const float4*>(Bw), KS, b_ks0, nt0, wm, lane, dbg, save_dst,
+                        save_valid, wave);
+}
+// the block of a layer whose fp32 packing starts `off` floats into the packed buffer
+template <int MM>
+__device__ __forceinline__ const void* wblock(const float* packed, int64_t off) {
+  if constexpr (MM == MM_X6) return reinterpret_cast<const uint4*>(packed) + off * 3 / 8;
+  else return reinterpret_cast<const float4*>(packed) + off / 4;
+}
+
 template <int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
 #pragma unroll
@@ -394,7 +582,7 @@ __device__ __forceinline__ int x2idx(int m, int k) { return m * 32 + ((((k >> 2)
 // BG == true : nerf++ background net: inverted-sphere points (4-D), samples in flipped order
 //              (ddp_model.py:118-124), 84 channels = 64 in E + 20 (padded to 32) in the X2 block that
 //              borrows the first 8 KiB of H while H is free (L0) or after it has been consumed (L5).
-template <bool SAVE, bool BG>
+template <bool SAVE, bool BG, int MM = MM_F32>
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
                const float* __restrict__ params, const float* __restrict__ packed, float* __restrict__ raw,
@@ -415,7 +603,6 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const float4* pk = reinterpret_cast<const float4*>(packed);
   const int64_t ntiles = (P + TM - 1) / TM;
   const int PEP = BG ? 96 : 64;
   const int dbg = 0;
@@ -495,9 +682,9 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     zero_acc<2>(acc);
     float bv2[2];
     load_bias<2>(bv2, params + lay.LB[0], wn, lane);
-    gemm_seg<2, 1>(acc, Es, 0, 8, pk + lay.PF[0] / 4, PEP / 8, 0, wn * 2, wm, lane, dbg);
+    gemm<MM, 2, 1>(acc, Es, 0, 8, wblock<MM>(packed, lay.PF[0]), PEP / 8, 0, wn * 2, wm, lane, dbg);
     if (BG) {
-      gemm_seg<2, 2>(acc, X2, 0, 4, pk + lay.PF[0] / 4, PEP / 8, 8, wn * 2, wm, lane, dbg);
+      gemm<MM, 2, 2>(acc, X2, 0, 4, wblock<MM>(packed, lay.PF[0]), PEP / 8, 8, wn * 2, wm, lane, dbg);
       __syncthreads();   // X2 lives in H: everyone must be done with it before H is written
     }
     epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
@@ -507,24 +694,24 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
       zero_acc<2>(acc);
-      const float4* B = pk + lay.PF[l] / 4;
+      const void* B = wblock<MM>(packed, lay.PF[l]);
       load_bias<2>(bv2, params + lay.LB[l], wn, lane);
       float* sv = SAVE ? act + act_h(PL, PEP, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
       if (l == 5) {
         const int KS5 = (PEP + 256) / 8;
         if (!BG) {
-          gemm_seg<2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
-          gemm_seg<2, 0>(acc, Hs, 0, 32, B, KS5, 8, wn * 2, wm, lane, dbg, sv, valid, wave);
+          gemm<MM, 2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
+          gemm<MM, 2, 0>(acc, Hs, 0, 32, B, KS5, 8, wn * 2, wm, lane, dbg, sv, valid, wave);
         } else {
-          gemm_seg<2, 0>(acc, Hs, 0, 32, B, KS5, 12, wn * 2, wm, lane, dbg, sv, valid, wave);
+          gemm<MM, 2, 0>(acc, Hs, 0, 32, B, KS5, 12, wn * 2, wm, lane, dbg, sv, valid, wave);
           __syncthreads();   // h4 consumed: its first 8 KiB become X2 again
           write_x2();
           __syncthreads();
-          gemm_seg<2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
-          gemm_seg<2, 2>(acc, X2, 0, 4, B, KS5, 8, wn * 2, wm, lane, dbg);
+          gemm<MM, 2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
+          gemm<MM, 2, 2>(acc, X2, 0, 4, B, KS5, 8, wn * 2, wm, lane, dbg);
         }
       } else {
-        gemm_seg<2, 0>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
+        gemm<MM, 2, 0>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
       }
       __syncthreads();  // every wave has finished reading H
       epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
@@ -578,7 +765,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     // ---- feature layer (no ReLU) ------------------------------------------------------
     zero_acc<2>(acc);
     load_bias<2>(bv2, params + lay.FB, wn, lane);
-    gemm_seg<2, 0>(acc, Hs, 0, 32, pk + lay.PF[8] / 4, 32, 0, wn * 2, wm, lane, dbg,
+    gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed, lay.PF[8]), 32, 0, wn * 2, wm, lane, dbg,
                    SAVE ? act + act_h(PL, PEP, 7) + p0 * 256 : nullptr, valid, wave);
     __syncthreads();
     epilogue_fwd<2, false>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
@@ -597,9 +784,9 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       zero_acc<1>(av);
       float bv1[1];
       load_bias<1>(bv1, params + lay.VB, wn, lane);
-      gemm_seg<1, 0>(av, Hs, 0, 32, pk + lay.PF[9] / 4, 36, 0, wn, wm, lane, dbg,
+      gemm<MM, 1, 0>(av, Hs, 0, 32, wblock<MM>(packed, lay.PF[9]), 36, 0, wn, wm, lane, dbg,
                      SAVE ? act + act_feat(PL, PEP) + p0 * 256 : nullptr, valid, wave);
-      gemm_seg<1, 1>(av, Es, 0, 4, pk + lay.PF[9] / 4, 36, 32, wn, wm, lane, dbg);
+      gemm<MM, 1, 1>(av, Es, 0, 4, wblock<MM>(packed, lay.PF[9]), 36, 32, wn, wm, lane, dbg);
       __syncthreads();
       epilogue_fwd<1, true>(av, bv1, Hs, wm, wn, lane, nullptr, 128, valid);
       __syncthreads();
@@ -642,39 +829,43 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
   b_sched_exit(sched, tid);
 }
 
+template <bool SAVE, bool BG, int MM>
+static int fwd_launch_t(int grid, hipStream_t st, int64_t P, int S, const float* rays11, const float* z, const float* params,
+                        const float* packed_fwd, float* raw, float* act, const NetLayout& lay, unsigned* sched, const int* live_idx,
+                        const int* live_cnt, int flags) {
+  auto kern = mlp_fwd_kernel<SAVE, BG, MM>;
+  static bool attr = false;
+  if (!attr) {
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx,
+                     live_cnt, flags);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
 static int fwd_launch(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
                       const float* packed_fwd, float* raw, float* act, const int* live_idx, const int* live_cnt,
-                      fn_stream_t stream, int flags = 0) {
+                      fn_stream_t stream, int flags = 0, int mm = MM_F32) {
   const NetLayout& lay = layout_of(kind);
   const int64_t P = n * S;
   const int64_t ntiles = (P + TM - 1) / TM;
   int grid = num_cus() * WG_PER_CU;
   if (ntiles < grid) grid = (int)ntiles;
-  static bool attr_done = false;
-  if (!attr_done) {
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<true, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<false, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<true, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<false, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_done = true;
-  }
   hipStream_t st = fn::S(stream);
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
-  if (kind == 2) {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt, 0);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt, 0);
-  } else {
-    if (act) hipLaunchKernelGGL((mlp_fwd_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt, 0);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt,
-                            (kind == 0 && !live_idx) ? flags : 0);
+  const int fl = (kind == 0 && !live_idx && !act) ? flags : 0;
+#define FN_FWD(SAVE_, BG_, MM_) \
+  fwd_launch_t<SAVE_, BG_, MM_>(grid, st, P, S, rays11, z, params, packed_fwd, raw, act, lay, sched, live_idx, live_cnt, fl)
+  if (mm == MM_X6) {
+    if (kind == 2) return act ? FN_FWD(true, true, MM_X6) : FN_FWD(false, true, MM_X6);
+    return act ? FN_FWD(true, false, MM_X6) : FN_FWD(false, false, MM_X6);
   }
-  FN_LAUNCH_CHECK();
-  return 0;
+  if (kind == 2) return act ? FN_FWD(true, true, MM_F32) : FN_FWD(false, true, MM_F32);
+  return act ? FN_FWD(true, false, MM_F32) : FN_FWD(false, false, MM_F32);
+#undef FN_FWD
 }
 extern "C" int fastnerf_mlp_fwd_ex(int kind, int64_t n, int S, const float* rays11, const float* z,
                                    const float* params, const float* packed_fwd, float* raw, float* act,
@@ -765,6 +956,7 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
   }
 }
 
+template <int MM = MM_F32>
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __restrict__ act,
                   const float* __restrict__ params, const float* __restrict__ packed_t, float* __restrict__ dact,
@@ -780,7 +972,6 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const float4* pk = reinterpret_cast<const float4*>(packed_t);
   const int64_t ntiles = (P + TM - 1) / TM;
   stagger_start();
 
@@ -820,7 +1011,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     f32x16 acc[2][2];
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ------------------------------------------
     zero_acc<2>(acc);
-    gemm_seg<2, 0>(acc, Hs, 0, 16, pk + lay.PB[0] / 4, 16, 0, wn * 2, wm, lane);
+    gemm<MM, 2, 0>(acc, Hs, 0, 16, wblock<MM>(packed_t, lay.PB[0]), 16, 0, wn * 2, wm, lane);
     __syncthreads();
     epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
                               valid);
@@ -829,7 +1020,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     zero_acc<2>(acc);
     {
       const DxPre pre = dx_preload<true, true>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
-      gemm_seg<2, 0>(acc, Hs, 0, 32, pk + lay.PB[1] / 4, 32, 0, wn * 2, wm, lane, 0,
+      gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
                          dact + dact_feat(PL) + p0 * 256, valid, wave);    // streams dfeat (what it reads) out
       __syncthreads();
       epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
@@ -841,7 +1032,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       const int64_t off = lay.PB[9 - l];   // PB[2] = L7t ... PB[8] = L1t
       zero_acc<2>(acc);
       const DxPre pre = dx_preload<true, false>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
-      gemm_seg<2, 0>(acc, Hs, 0, 32, pk + off / 4, 32, 0, wn * 2, wm, lane, 0,
+      gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
                          dact + dact_y(PL, l) + p0 * 256, valid, wave);    // streams dY_l (what it reads) out
       __syncthreads();
       epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
@@ -868,7 +1059,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
 // WO x WI waves (4 or 8), each wave TO x TI MFMA tiles:  NO = WO*TO*32, KI = WI*TI*32.
 // The 256x256 jobs run 8 waves x 128 accumulator registers (two waves per SIMD) so that one wave's
 // staging / bias work overlaps the other's MFMAs.
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32>
 __global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                   const float* __restrict__ draw /*RANK1: dalpha = draw[p*4+3]*/, float* __restrict__ partial_w,
@@ -951,6 +1142,39 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
 #endif
     const float* Ys = cur;
     const float* Xs = cur + DW_MT * NO;
+    if constexpr (MM == MM_X6) {
+      // MM_X6: two k-steps of 16 points; a lane (channel = lane & 31, kb = lane >> 5) gathers its 8 consecutive points of a
+      // channel from the stage ([point][channel] fp32, conflict-free: consecutive lanes = consecutive channels), splits them into
+      // the three bf16 pieces and feeds the six-product MFMA group.  The dY fragments of a k-step are split once and reused
+      // for every X tile.
+      auto frag = [&](const float* base, int ld, int col, int mb, uint4& h, uint4& m, uint4& l) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = base[(mb + q) * ld + col];
+        split3_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
+      };
+#pragma unroll
+      for (int k16 = 0; k16 < DW_MT / 16; ++k16) {
+        const int mb = k16 * 16 + (lane >> 5) * 8;
+        uint4 ah[TO], am[TO], al[TO];
+#pragma unroll
+        for (int i = 0; i < TO; ++i) frag(Ys, NO, (wo * TO + i) * 32 + (lane & 31), mb, ah[i], am[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+          uint4 bh, bm, bl;
+          frag(Xs, KI, (wi * TI + j) * 32 + (lane & 31), mb, bh, bm, bl);
+#pragma unroll
+          for (int i = 0; i < TO; ++i) {
+            acc[i][j] = mfma_bf16(al[i], bh, acc[i][j]);
+            acc[i][j] = mfma_bf16(ah[i], bl, acc[i][j]);
+            acc[i][j] = mfma_bf16(am[i], bm, acc[i][j]);
+            acc[i][j] = mfma_bf16(am[i], bh, acc[i][j]);
+            acc[i][j] = mfma_bf16(ah[i], bm, acc[i][j]);
+            acc[i][j] = mfma_bf16(ah[i], bh, acc[i][j]);
+          }
+        }
+      }
+    } else
     // MFMA over the stage's 32 points, 2 per step; fragments of the next step are fetched from LDS
     // before the current step's MFMAs are issued (ping-pong registers): with one wave per SIMD
     // nothing else hides the ds_read latency.
@@ -1116,13 +1340,13 @@ extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
   return dw_job_base(12, num_cus(), 96) + (int64_t)HEAD_MAX_WG * 388;   // sized for the widest layout
 }
 
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32>
 static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* base,
                      int nwg, hipStream_t st, const int* live_idx = nullptr, const int* live_cnt = nullptr) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
   const size_t lds = 2 * STAGE * sizeof(float);
-  auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1>;
+  auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1, MM>;
   static bool attr = false;
   if (!attr) {
     FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1143,7 +1367,8 @@ static void add_seg(RedTable& T, int64_t src, int64_t wg_stride, int nwg, int ro
   s.valid_cols = valid_cols;
 }
 
-static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+template <int MM>
+static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                       const float* packed_bwd, float* dact, float* partial, float* grads, const int* live_idx,
                       const int* live_cnt, fn_stream_t stream) {
   const NetLayout& L = layout_of(kind);
@@ -1156,13 +1381,13 @@ static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_dx_kernel),
+    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_dx_kernel<MM>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done = true;
   }
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
-  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L, sched, live_idx, live_cnt);
+  hipLaunchKernelGGL(mlp_bwd_dx_kernel<MM>, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L, sched, live_idx, live_cnt);
   FN_LAUNCH_CHECK();
 
   // ---- dW jobs: every job writes per-workgroup partials into its own region ------------------
@@ -1183,27 +1408,27 @@ static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float
     if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
   };
   // L0
-  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
-  else rc = launch_dw<4, 1, 2, 3, true, false>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
+  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
+  else rc = launch_dw<4, 1, 2, 3, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
   if (rc) return rc;
   segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
-    if ((rc = launch_dw<4, 2, 2, 4, true, false>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
+    if ((rc = launch_dw<4, 2, 2, 4, true, false, MM>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
   }
   // L5 pe part
-  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
-  else rc = launch_dw<4, 1, 2, 3, false, false>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
+  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
+  else rc = launch_dw<4, 1, 2, 3, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
   if (rc) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
-  if ((rc = launch_dw<4, 2, 2, 4, true, true>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
+  if ((rc = launch_dw<4, 2, 2, 4, true, true, MM>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
   segs(9, L.FW, 256, 256, L.FB, L.AW);
   // view layer
-  if ((rc = launch_dw<2, 4, 2, 2, true, false>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st, live_idx, live_cnt))) return rc;
+  if ((rc = launch_dw<2, 4, 2, 2, true, false, MM>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st, live_idx, live_cnt))) return rc;
   segs(10, L.VW, 283, 256, L.VB, 0);
-  if ((rc = launch_dw<4, 1, 1, 1, false, false>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
+  if ((rc = launch_dw<4, 1, 1, 1, false, false, MM>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
   segs(11, L.VW + 256, 283, 27, 0, 0);
   // rgb head + alpha bias
   {
@@ -1217,6 +1442,12 @@ static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float
   hipLaunchKernelGGL(reduce_all_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
   FN_LAUNCH_CHECK();
   return 0;
+}
+static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                      const float* packed_bwd, float* dact, float* partial, float* grads, const int* live_idx,
+                      const int* live_cnt, fn_stream_t stream, int mm = MM_F32) {
+  return mm == MM_X6 ? bwd_launch_t<MM_X6>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream)
+                     : bwd_launch_t<MM_F32>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream);
 }
 extern "C" int fastnerf_mlp_bwd_ex(int kind, int64_t n, int S, const float* draw, const float* act,
                                    const float* params, const float* packed_bwd, float* dact, float* partial,
@@ -1238,4 +1469,35 @@ extern "C" int fastnerf_mlp_bwd(int64_t n, int S, const float* draw, const float
                                 const float* packed_bwd, float* dact, float* partial, float* grads,
                                 fn_stream_t stream) {
   return fastnerf_mlp_bwd_ex(0, n, S, draw, act, params, packed_bwd, dact, partial, grads, stream);
+}
+
+// ---- MM_X6 ("bf16x6") entry points: the call protocol of fastnerf_mlp_{fwd,bwd}_ex / _live_ex / _flags_ex, weights from
+// fastnerf_mlp_x6_pack; saved activations and gradient workspaces have the exact-fp32 kernels' layouts and sizes.
+extern "C" int fastnerf_mlp_x6_fwd(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                                   const float* packed_fwd, float* raw, float* act, int flags, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
+  FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
+  if (n == 0) return 0;
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream, flags, MM_X6);
+}
+extern "C" int fastnerf_mlp_x6_bwd(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                                   const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads, "null pointer");
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, nullptr, nullptr, stream, MM_X6);
+}
+extern "C" int fastnerf_mlp_x6_fwd_live(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                                        const float* packed_fwd, float* act, const int32_t* live_idx, const int32_t* live_cnt,
+                                        fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(rays11 && z && params && packed_fwd && act && live_idx && live_cnt, "null pointer");
+  FN_CHECK_ARG(n * (int64_t)S < ((int64_t)1 << 31), "live lists index points with int32");
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, nullptr, act, live_idx, live_cnt, stream, 0, MM_X6);
+}
+extern "C" int fastnerf_mlp_x6_bwd_live(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                                        const float* packed_bwd, float* dact, float* partial, float* grads,
+                                        const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream) {
+  FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
+  FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads && live_idx && live_cnt, "null pointer");
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream, MM_X6);
 }

@@ -14,8 +14,8 @@ extern "C" int fastnerf_render_rays_fwd_ex(int math_mode, int64_t n, int N_sampl
                                         float* disp0, float* acc0, float* w0, float* depth0, float* z1,
                                         float* z_samples, float* z_std, float* raw1, float* act1, float* rgb1,
                                         float* disp1, float* acc1, float* w1, float* depth1, int flags, fn_stream_t stream) {
-  if ((math_mode != 0 && math_mode != 1) || n < 0 || N_samples < 2 || N_importance < 0) {
-    fn::set_error("fastnerf_render_rays_fwd: bad argument: math_mode in {0,1}, n>=0, N_samples>=2, N_importance>=0");
+  if (math_mode < 0 || math_mode > 2 || n < 0 || N_samples < 2 || N_importance < 0) {
+    fn::set_error("fastnerf_render_rays_fwd: bad argument: math_mode in {0,1,2}, n>=0, N_samples>=2, N_importance>=0");
     return -1;
   }
   if (N_importance > 0 && N_samples < 3) {
@@ -32,6 +32,7 @@ extern "C" int fastnerf_render_rays_fwd_ex(int math_mode, int64_t n, int N_sampl
   // (options only where their precondition holds: an inference launch, no sigma noise in that pass)
   auto mlp = [&](int64_t nn, int S, const float* z, const float* params, const float* packed, float* raw, float* act,
                  const float* noise) {
+    if (math_mode == 2) return fastnerf_mlp_x6_fwd(0, nn, S, rays11, z, params, packed, raw, act, (!act && !noise) ? flags : 0, stream);
     if (!act && !noise && flags)
       return math_mode ? fastnerf_mlp_bf16_fwd_flags(0, nn, S, rays11, z, params, packed, raw, flags, stream)
                        : fastnerf_mlp_fwd_flags_ex(0, nn, S, rays11, z, params, packed, raw, flags, stream);
@@ -79,8 +80,8 @@ static int rr_bwd(int math_mode, int64_t n, int N_samples, int N_importance, con
                   const float* packed_bwd_c, const float* params_f, const float* packed_bwd_f,
                   float* draw_ws, float* dact_ws, float* partial_ws, float* grads_c, float* grads_f,
                   int passes, fn_stream_t stream) {
-  if ((math_mode != 0 && math_mode != 1) || n <= 0 || N_samples < 2 || N_importance < 0) {
-    fn::set_error("fastnerf_render_rays_bwd: bad argument: math_mode in {0,1}, n>0, N_samples>=2, N_importance>=0");
+  if (math_mode < 0 || math_mode > 2 || n <= 0 || N_samples < 2 || N_importance < 0) {
+    fn::set_error("fastnerf_render_rays_bwd: bad argument: math_mode in {0,1,2}, n>0, N_samples>=2, N_importance>=0");
     return -1;
   }
   if (!rays11 || !z0 || !raw0 || !act0 || !params_c || !packed_bwd_c || !draw_ws || !dact_ws || !partial_ws || !grads_c) {
@@ -89,6 +90,7 @@ static int rr_bwd(int math_mode, int64_t n, int N_samples, int N_importance, con
   }
   int rc;
   auto mlp = [&](int S, const float* act, const float* params, const float* packed, float* grads) {
+    if (math_mode == 2) return fastnerf_mlp_x6_bwd(0, n, S, draw_ws, act, params, packed, dact_ws, partial_ws, grads, stream);
     return math_mode ? fastnerf_mlp_bf16_bwd(0, n, S, draw_ws, act, params, packed, dact_ws, partial_ws, grads, stream)
                      : fastnerf_mlp_bwd_ex(0, n, S, draw_ws, act, params, packed, dact_ws, partial_ws, grads, stream);
   };
@@ -139,8 +141,8 @@ static int rr_bwd_live(int math_mode, int64_t n, int N_samples, int N_importance
                        const float* params_f, const float* packed_fwd_f, const float* packed_bwd_f,
                        float* draw_ws, float* act_ws, float* dact_ws, float* partial_ws, int32_t* live_ws,
                        float* grads_c, float* grads_f, int32_t* counts_out, int passes, fn_stream_t stream) {
-  if ((math_mode != 0 && math_mode != 1) || n <= 0 || N_samples < 2 || N_importance < 0) {
-    fn::set_error("fastnerf_render_rays_bwd_live: bad argument: math_mode in {0,1}, n>0, N_samples>=2, N_importance>=0");
+  if (math_mode < 0 || math_mode > 2 || n <= 0 || N_samples < 2 || N_importance < 0) {
+    fn::set_error("fastnerf_render_rays_bwd_live: bad argument: math_mode in {0,1,2}, n>0, N_samples>=2, N_importance>=0");
     return -1;
   }
   if (!rays11 || !z0 || !raw0 || !params_c || !packed_fwd_c || !packed_bwd_c || !draw_ws || !act_ws || !dact_ws ||
@@ -157,6 +159,10 @@ static int rr_bwd_live(int math_mode, int64_t n, int N_samples, int N_importance
                   const float* pf, const float* pb, float* grads, int32_t* cnt_out) -> int {
     if ((rc = fastnerf_raw2outputs_bwd(n, S, raw, z, rays11, noise, white_bkgd, g, draw_ws, stream))) return rc;
     if ((rc = fastnerf_compact_live(n * (int64_t)S, draw_ws, idx, cnt_out, cws, stream))) return rc;
+    if (math_mode == 2) {
+      if ((rc = fastnerf_mlp_x6_fwd_live(0, n, S, rays11, z, params, pf, act_ws, idx, cnt_out, stream))) return rc;
+      return fastnerf_mlp_x6_bwd_live(0, n, S, draw_ws, act_ws, params, pb, dact_ws, partial_ws, grads, idx, cnt_out, stream);
+    }
     if (math_mode) {
       if ((rc = fastnerf_mlp_bf16_fwd_live(0, n, S, rays11, z, params, pf, act_ws, idx, cnt_out, stream))) return rc;
       return fastnerf_mlp_bf16_bwd_live(0, n, S, draw_ws, act_ws, params, pb, dact_ws, partial_ws, grads, idx, cnt_out, stream);
@@ -206,8 +212,8 @@ extern "C" int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_sam
 extern "C" int64_t fastnerf_step_args_size(void) { return (int64_t)sizeof(fn_step_args); }
 
 extern "C" int fastnerf_train_step(const fn_step_args* a, int phases, fn_stream_t stream) {
-  if (!a || (a->math_mode != 0 && a->math_mode != 1) || a->n <= 0 || a->N_samples < 2 || a->N_importance < 0) {
-    fn::set_error("fastnerf_train_step: bad argument: args != NULL, math_mode in {0,1}, n>0, N_samples>=2, N_importance>=0");
+  if (!a || a->math_mode < 0 || a->math_mode > 2 || a->n <= 0 || a->N_samples < 2 || a->N_importance < 0) {
+    fn::set_error("fastnerf_train_step: bad argument: args != NULL, math_mode in {0,1,2}, n>0, N_samples>=2, N_importance>=0");
     return -1;
   }
   const bool two = a->N_importance > 0;
@@ -265,6 +271,7 @@ extern "C" int fastnerf_train_step(const fn_step_args* a, int phases, fn_stream_
     if ((rc = fastnerf_adam_step(total, a->params, a->grads, a->adam_m, a->adam_v, a->lr, a->beta1, a->beta2, a->eps, a->adam_t,
                                  stream))) return rc;
     auto pack = [&](const float* p, float* pf, float* pb) {
+      if (a->math_mode == 2) return fastnerf_mlp_x6_pack(0, p, pf, pb, stream);
       return a->math_mode ? fastnerf_mlp_bf16_pack(0, p, pf, pb, stream) : fastnerf_mlp_pack_ex(0, p, pf, pb, stream);
     };
     if ((rc = pack(params_c, a->packed_fwd_c, a->packed_bwd_c))) return rc;

@@ -17,12 +17,17 @@ DACT_FLOATS = 2432
 
 
 # ---- matrix-core math mode of the 8x256 MLP kernels ---------------------------------------------
-# 'fp32'   : v_mfma_f32_32x32x2_f32 (csrc/mlp.hip), every kind
-# 'bf16x3' : 3-term split-bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/mlp_bf16.hip),
-#            fp32-class accuracy at ~2.5x the rate; all three net kinds
+# 'fp32'   : v_mfma_f32_32x32x2_f32 (csrc/mlp.hip), every kind: the products and sums of an fp32 FMA chain
+# 'bf16x6' : csrc/mlp.hip MM_X6 -- every fp32 operand decomposed EXACTLY into three bf16 pieces, a product = its six piece
+#            products of weight >= 2^-16, fp32 accumulation on v_mfma_f32_32x32x16_bf16: fp32-WIDTH products (the dropped terms
+#            are <= 2^-24 of the product) at 2.67x the matrix rate of the fp32 instruction; same buffers as 'fp32' except the
+#            packed weights (three bf16 planes)
+# 'bf16x3' : 3-term split-bf16 (two pieces, 16 significand bits) on the same instruction (csrc/mlp_bf16.hip): NARROWER than
+#            fp32 (products ~2^-17 relative), ~2.5x the rate of 'fp32'; rendered RGB still within 1e-6 of the fp32 kernels
 import os
+MATH_MODES = ('fp32', 'bf16x3', 'bf16x6')
 _MATH = os.environ.get('FASTNERF_MATH', 'bf16x3')
-assert _MATH in ('fp32', 'bf16x3'), 'FASTNERF_MATH must be fp32 or bf16x3'
+assert _MATH in MATH_MODES, 'FASTNERF_MATH must be one of ' + ', '.join(MATH_MODES)
 
 
 def get_math():
@@ -33,8 +38,17 @@ def set_math(mode):
     """Switch the math mode.  Packed weights / saved activations are mode-specific: models re-pack on their
     next packed() call; do not mix buffers produced under different modes."""
     global _MATH
-    assert mode in ('fp32', 'bf16x3')
+    assert mode in MATH_MODES
     _MATH = mode
+
+
+def mode_id():
+    """math_mode argument of the fused C-ABI entry points (fastnerf_render_rays_*, fastnerf_train_step)."""
+    return MATH_MODES.index(_MATH)
+
+
+def _x6():
+    return _MATH == 'bf16x6'
 
 
 # math mode a packed-weight buffer was produced under: a Python attribute on the tensor object AND a registry by storage
@@ -49,7 +63,7 @@ def _tag_packed(t, tag):
 
 
 def packed_tag(t):
-    return packed_tag(t) or _PACK_TAGS.get((t.device.index, t.data_ptr()))
+    return getattr(t, '_fn_math', None) or _PACK_TAGS.get((t.device.index, t.data_ptr()))
 
 
 def _split(kind):
@@ -74,6 +88,8 @@ def packed_floats(kind, which):
     """which: 1 forward, 2 backward packed-weight buffer (floats) under the current math mode."""
     if _split(kind):
         return int(lib().fastnerf_mlp_bf16_floats(int(kind), int(which), 0))
+    if _x6():
+        return int(lib().fastnerf_mlp_x6_packed_floats(int(kind), int(which)))
     return net_floats(kind, which)
 
 
@@ -161,10 +177,13 @@ def mlp_pack(params, packed_fwd=None, packed_bwd=None, kind=0):
         'packed buffers were sized under a different math mode'
     # the two modes' buffers can have the same size: tag them so that a mix-up is an error, not garbage
     for t in (packed_fwd, packed_bwd):
-        _tag_packed(t, 'bf16x3' if _split(kind) else 'fp32')
+        _tag_packed(t, _MATH)
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_pack(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),
               'fastnerf_mlp_bf16_pack')
+        return packed_fwd, packed_bwd
+    if _x6():
+        check(lib().fastnerf_mlp_x6_pack(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()), 'fastnerf_mlp_x6_pack')
         return packed_fwd, packed_bwd
     check(lib().fastnerf_mlp_pack_ex(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),
           'fastnerf_mlp_pack_ex')
@@ -180,11 +199,15 @@ def mlp_fwd(rays11, z, params, packed_fwd, act=None, raw=None, kind=0):
         raw = torch.empty(n, S, 4, device=z.device, dtype=torch.float32)
     if act is not None:
         assert act.numel() >= act_floats(n * S, kind)
-    assert packed_fwd.numel() == packed_floats(kind, 1) and packed_tag(packed_fwd) == ('bf16x3' if _split(kind) else 'fp32'), \
+    assert packed_fwd.numel() == packed_floats(kind, 1) and packed_tag(packed_fwd) == _MATH, \
         'packed weights were not produced by mlp_pack under the current math mode'
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_fwd(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw),
                                           ptr(act), stream()), 'fastnerf_mlp_bf16_fwd')
+        return raw
+    if _x6():
+        check(lib().fastnerf_mlp_x6_fwd(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw), ptr(act), 0,
+                                        stream()), 'fastnerf_mlp_x6_fwd')
         return raw
     check(lib().fastnerf_mlp_fwd_ex(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(raw),
                                     ptr(act), stream()), 'fastnerf_mlp_fwd_ex')
@@ -199,11 +222,15 @@ def mlp_bwd(draw, act, params, packed_bwd, dact, partial, grads, kind=0):
     require_gpu(draw, act, params, packed_bwd, dact, partial, grads)
     n, S = draw.shape[0], draw.shape[1]
     assert dact.numel() >= dact_floats(n * S, kind) and grads.numel() == net_floats(kind, 0)
-    assert packed_bwd.numel() == packed_floats(kind, 2) and packed_tag(packed_bwd) == ('bf16x3' if _split(kind) else 'fp32'), \
+    assert packed_bwd.numel() == packed_floats(kind, 2) and packed_tag(packed_bwd) == _MATH, \
         'packed weights were not produced by mlp_pack under the current math mode'
     if _split(kind):
         check(lib().fastnerf_mlp_bf16_bwd(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
                                           ptr(partial), ptr(grads), stream()), 'fastnerf_mlp_bf16_bwd')
+        return grads
+    if _x6():
+        check(lib().fastnerf_mlp_x6_bwd(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact), ptr(partial),
+                                        ptr(grads), stream()), 'fastnerf_mlp_x6_bwd')
         return grads
     check(lib().fastnerf_mlp_bwd_ex(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact),
                                     ptr(partial), ptr(grads), stream()), 'fastnerf_mlp_bwd_ex')
@@ -235,7 +262,7 @@ def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N
     dev = rays11.device
     f32 = dict(device=dev, dtype=torch.float32)
     split = _split(0)
-    tag = 'bf16x3' if split else 'fp32'
+    tag = _MATH
     assert packed_tag(packed_c) == tag and (packed_f is None or packed_tag(packed_f) == tag), \
         'packed weights were not produced by mlp_pack under the current math mode'
     if t_rand is not None:
@@ -267,7 +294,7 @@ def render_rays_fwd(rays11, params_c, packed_c, params_f, packed_f, N_samples, N
     # skip_dead_rgb (FN_FWD_SKIP_DEAD_RGB): the inference launches may leave the colour logits of tiles without a live sample at
     # zero -- every other output is bit-identical; only callers that never expose `raw0` / `raw1` ask for it
     check(lib().fastnerf_render_rays_fwd_ex(
-        1 if split else 0, n, int(N_samples), int(N_importance), ptr(rays11), int(bool(lindisp)),
+        mode_id(), n, int(N_samples), int(N_importance), ptr(rays11), int(bool(lindisp)),
         int(bool(perturb) or t_rand is not None), int(bool(det)), int(bool(white_bkgd)), ptr(t_rand), ptr(u), ptr(noise0), ptr(noise1),
         int(seed0), int(seed1), ptr(params_c), ptr(packed_c), ptr(params_f), ptr(packed_f),
         ptr(o['z0']), ptr(o['raw0']), ptr(o['act0']), ptr(o['rgb0']), ptr(o['disp0']), ptr(o['acc0']), ptr(o['w0']), ptr(o['depth0']),
@@ -283,12 +310,12 @@ def render_rays_bwd(rays11, white_bkgd, g_rgb, g_rgb0, noise0, noise1, z0, raw0,
                 dact_ws, partial, grads_c, grads_f)
     n = rays11.shape[0]
     S1 = N_samples + N_importance
-    tag = 'bf16x3' if _split(0) else 'fp32'
+    tag = _MATH
     assert packed_tag(packed_bwd_c) == tag and (packed_bwd_f is None or packed_tag(packed_bwd_f) == tag), \
         'packed weights were not produced by mlp_pack under the current math mode'
     assert draw_ws.numel() >= n * S1 * 4 and dact_ws.numel() >= dact_floats(n * S1)
     check(lib().fastnerf_render_rays_bwd(
-        1 if _split(0) else 0, n, int(N_samples), int(N_importance), ptr(rays11), int(bool(white_bkgd)), ptr(g_rgb), ptr(g_rgb0),
+        mode_id(), n, int(N_samples), int(N_importance), ptr(rays11), int(bool(white_bkgd)), ptr(g_rgb), ptr(g_rgb0),
         ptr(noise0), ptr(noise1), ptr(z0), ptr(raw0), ptr(act0), ptr(z1), ptr(raw1), ptr(act1), ptr(params_c), ptr(packed_bwd_c),
         ptr(params_f), ptr(packed_bwd_f), ptr(draw_ws), ptr(dact_ws), ptr(partial), ptr(grads_c), ptr(grads_f), stream()),
         'fastnerf_render_rays_bwd')
@@ -310,10 +337,10 @@ def mlp_fwd_live(rays11, z, params, packed_fwd, act, live_idx, live_cnt, kind=0)
     """Training forward over a live list: saves the activations of points live_idx[0:live_cnt[0]] (current math mode)."""
     require_gpu(rays11, z, params, packed_fwd, act, live_idx, live_cnt)
     n, S = z.shape
-    tag = 'bf16x3' if _split(kind) else 'fp32'
+    tag = _MATH
     assert act.numel() >= act_floats(n * S, kind) and live_idx.dtype == torch.int32 and live_cnt.dtype == torch.int32
     assert packed_fwd.numel() == packed_floats(kind, 1) and packed_tag(packed_fwd) == tag
-    fn = lib().fastnerf_mlp_bf16_fwd_live if _split(kind) else lib().fastnerf_mlp_fwd_live_ex
+    fn = lib().fastnerf_mlp_bf16_fwd_live if _split(kind) else (lib().fastnerf_mlp_x6_fwd_live if _x6() else lib().fastnerf_mlp_fwd_live_ex)
     check(fn(int(kind), n, S, ptr(rays11), ptr(z), ptr(params), ptr(packed_fwd), ptr(act), ptr(live_idx), ptr(live_cnt), stream()),
           'fastnerf_mlp_fwd_live')
 
@@ -321,10 +348,10 @@ def mlp_fwd_live(rays11, z, params, packed_fwd, act, live_idx, live_cnt, kind=0)
 def mlp_bwd_live(draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, kind=0):
     require_gpu(draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt)
     n, S = draw.shape[0], draw.shape[1]
-    tag = 'bf16x3' if _split(kind) else 'fp32'
+    tag = _MATH
     assert dact.numel() >= dact_floats(n * S, kind) and grads.numel() == net_floats(kind, 0)
     assert packed_bwd.numel() == packed_floats(kind, 2) and packed_tag(packed_bwd) == tag
-    fn = lib().fastnerf_mlp_bf16_bwd_live if _split(kind) else lib().fastnerf_mlp_bwd_live_ex
+    fn = lib().fastnerf_mlp_bf16_bwd_live if _split(kind) else (lib().fastnerf_mlp_x6_bwd_live if _x6() else lib().fastnerf_mlp_bwd_live_ex)
     check(fn(int(kind), n, S, ptr(draw), ptr(act), ptr(params), ptr(packed_bwd), ptr(dact), ptr(partial), ptr(grads), ptr(live_idx),
              ptr(live_cnt), stream()), 'fastnerf_mlp_bwd_live')
     return grads
@@ -344,13 +371,13 @@ def render_rays_bwd_live(rays11, white_bkgd, g_rgb, g_rgb0, noise0, noise1, z0, 
                 grads_c, grads_f, counts)
     n = rays11.shape[0]
     S1 = N_samples + N_importance
-    tag = 'bf16x3' if _split(0) else 'fp32'
+    tag = _MATH
     for pk in (packed_c, packed_f):
         assert pk is None or all(packed_tag(t) == tag for t in pk)
     assert draw_ws.numel() >= n * S1 * 4 and dact_ws.numel() >= dact_floats(n * S1) and act_ws.numel() >= act_floats(n * S1)
     assert live_ws.dtype == torch.int32 and live_ws.numel() >= live_ws_ints(n * S1)
     check(lib().fastnerf_render_rays_bwd_live(
-        1 if _split(0) else 0, n, int(N_samples), int(N_importance), ptr(rays11), int(bool(white_bkgd)), ptr(g_rgb), ptr(g_rgb0), ptr(noise0), ptr(noise1),
+        mode_id(), n, int(N_samples), int(N_importance), ptr(rays11), int(bool(white_bkgd)), ptr(g_rgb), ptr(g_rgb0), ptr(noise0), ptr(noise1),
         ptr(z0), ptr(raw0), ptr(z1), ptr(raw1), ptr(params_c), ptr(packed_c[0]), ptr(packed_c[1]),
         ptr(params_f), ptr(None if packed_f is None else packed_f[0]), ptr(None if packed_f is None else packed_f[1]),
         ptr(draw_ws), ptr(act_ws), ptr(dact_ws), ptr(partial), ptr(live_ws), ptr(grads_c), ptr(grads_f), ptr(counts), stream()),

@@ -284,7 +284,7 @@ class Trainer:
         S1 = S0 + Ni
         P0, P1 = n * S0, n * S1
         ops.require_gpu(rays_o, rays_d, target, leaf_tag, table, t_rand, u)
-        tag = 'bf16x3' if ops.get_math() == 'bf16x3' else 'fp32'
+        tag = ops.get_math()
         if ops.packed_tag(self.pc[0]) != tag:
             self.repack()           # the math mode changed under this trainer
             self._sa_key = None
@@ -296,7 +296,7 @@ class Trainer:
             self._sa_key = key
             self._regions, self._block_floats = _step_regions(n, S0, Ni)
             a.n, a.net_floats = n, ops.NET_PARAMS
-            a.math_mode = 1 if tag == 'bf16x3' else 0
+            a.math_mode = ops.mode_id()
             a.N_samples, a.N_importance, a.lindisp, a.perturb = S0, Ni, int(bool(self.lindisp)), int(bool(self.perturb))
             a.white_bkgd, a.ndc, a.H, a.W = int(bool(self.white_bkgd)), int(bool(self.ndc)), int(self.H), int(self.W)
             a.focal, a.near_plane, a.far_plane = float(self.K[0][0]), float(self.near), float(self.far)

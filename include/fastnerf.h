@@ -160,7 +160,7 @@ int fastnerf_mlp_fwd_flags_ex(int kind, int64_t n, int S, const float* rays11, c
 
 /* ---- fused forward of render_rays (render.py:238-299): coarse sampler -> coarse MLP -> compositing ->
  * [sample_pdf + merge -> fine MLP -> compositing], enqueued by one call on `stream`.  math_mode 0 = exact fp32,
- * 1 = split-bf16; packed_* must come from the matching pack entry point; act0 / act1 == NULL: inference.  perturb /
+ * 1 = split-bf16 (x3), 2 = bf16x6; packed_* must come from the matching pack entry point; act0 / act1 == NULL: inference.  perturb /
  * t_rand / seed0 as fastnerf_sample_coarse, det / u / seed1 as fastnerf_sample_pdf_merge, noise* as
  * fastnerf_raw2outputs_fwd.  N_importance == 0: coarse pass only (the *_f / *1 arguments are ignored).  All buffers
  * are caller-owned device memory with the shapes of the individual entry points. */
@@ -303,6 +303,28 @@ int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N
                                   float* draw_ws, float* act_ws, float* dact_ws, float* partial_ws, int32_t* live_ws,
                                   float* grads_c, float* grads_f, int32_t* counts_out, fn_stream_t stream);
 
+/* ---- "bf16x6" math mode: fp32-WIDTH products on the bf16 matrix cores (csrc/mlp.hip, MM_X6) -------------------------------
+ * Same network functions and call protocol as fastnerf_mlp_pack_ex / fwd_ex / fwd_flags_ex / bwd_ex / fwd_live_ex / bwd_live_ex
+ * (run_nerf.py:50-64 run_network -> model.py:37-63, autograd backward of the same).  Every fp32 operand is decomposed EXACTLY
+ * into three bf16 pieces (8 + 8 + 8 significand bits) and a product is the sum of the six piece products whose weight is
+ * >= 2^-16 of it, accumulated in fp32 on v_mfma_f32_32x32x16_bf16: the dropped terms are <= 2^-24 of the product, the rounding
+ * fp32 itself applies to it.  Weights are packed as three bf16 planes (fastnerf_mlp_x6_packed_floats(kind, 1 | 2) floats);
+ * saved activations / gradient workspaces are those of the exact-fp32 kernels (fastnerf_mlp_act_floats,
+ * n*S*FASTNERF_DACT_FLOATS, fastnerf_mlp_bwd_partial_floats).  fwd: act == NULL -> inference, flags as
+ * fastnerf_mlp_fwd_flags_ex (ignored when act != NULL). */
+int64_t fastnerf_mlp_x6_packed_floats(int kind, int which);
+int fastnerf_mlp_x6_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream);
+int fastnerf_mlp_x6_fwd(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                        const float* packed_fwd, float* raw, float* act, int flags, fn_stream_t stream);
+int fastnerf_mlp_x6_bwd(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                        const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream);
+int fastnerf_mlp_x6_fwd_live(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
+                             const float* packed_fwd, float* act, const int32_t* live_idx, const int32_t* live_cnt,
+                             fn_stream_t stream);
+int fastnerf_mlp_x6_bwd_live(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
+                             const float* packed_bwd, float* dact, float* partial, float* grads, const int32_t* live_idx,
+                             const int32_t* live_cnt, fn_stream_t stream);
+
 /* ---- one optimisation step per call (run_nerf.py:479-508: render -> img2mse fine + coarse -> loss.backward() ->
  * optimizer.step(), the epoch loss map of :505-506 fed inside the loss launch) ----------------------------------------
  * fastnerf_train_step enqueues the phases selected by `phases` on `stream`, using exactly the entry points above in the
@@ -337,7 +359,7 @@ typedef struct fn_step_args {
   int32_t *live_ws, *counts;                        /* compacted backward: scratch, optional int32[4] live / total counts */
   double focal, lr, beta1, beta2, eps;
   float near_plane, far_plane, grad_scale;
-  int32_t math_mode;                                /* 0 exact fp32, 1 split-bf16 */
+  int32_t math_mode;                                /* 0 exact fp32 MFMA, 1 split-bf16 (x3), 2 bf16x6 (fp32 width) */
   int32_t N_samples, N_importance, lindisp, perturb, white_bkgd, ndc, H, W;
   int32_t live;                                     /* != 0: forward without saving + compacted backward */
   int32_t fwd_flags;                                /* FN_FWD_* of the first forward of a compacted step */

@@ -84,7 +84,7 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=['fp32', 'bf16x3'])
+@pytest.fixture(params=['fp32', 'bf16x3', 'bf16x6'])
 def math_mode(request):
     """Run a GPU test under both matrix-core math modes of the MLP kernels (ops.set_math)."""
     import fastnerf

@@ -124,7 +124,7 @@ def test_mlp_forward_points(fn, weights, P, math_mode):
     act = torch.empty(fn.ops.act_floats(P)).cuda()
     raw2 = fn.ops.mlp_fwd(rays, torch.zeros(P, 1).cuda(), flat, pf, act=act)[:, 0]
     assert torch.equal(raw, raw2)
-    if math_mode == 'fp32':
+    if math_mode in ('fp32', 'bf16x6'):   # (bf16x6 keeps the exact-fp32 kernels' buffers)
         pe = act[:P * 64].view(P, 64).cpu()
     else:   # K-fragment tensors: pe (natural channel order), h0 (wave-permuted order)
         nt = (P + 63) // 64
@@ -137,7 +137,7 @@ def test_mlp_forward_points(fn, weights, P, math_mode):
         assert (h0 - h0_ref).abs().max() < 2e-5
     assert (pe[:, 63] == 0).all()
     # fp32 mode stores fp32; split mode stores (hi, lo) bf16 pairs = 16 significand bits (|x| <= 4 here)
-    assert (pe[:, :63] - O.posenc(pts, 10)).abs().max() < (2e-6 if math_mode == 'fp32' else 4 * 2.0 ** -16)
+    assert (pe[:, :63] - O.posenc(pts, 10)).abs().max() < (2e-6 if math_mode in ('fp32', 'bf16x6') else 4 * 2.0 ** -16)
 
 
 def test_mlp_backward_vs_autograd(fn, weights, math_mode):
@@ -205,9 +205,12 @@ def test_mlp_edge_cases(fn, weights, math_mode):
     assert raw.shape == (0, 5, 4)
     # a bad net kind is an error code + message, not a crash
     lib = fn._lib.lib()
-    rc = (lib.fastnerf_mlp_bf16_fwd if math_mode == 'bf16x3' else lib.fastnerf_mlp_fwd_ex)(
-        7, 1, 1, fn._lib.ptr(torch.zeros(1, 11).cuda()), fn._lib.ptr(torch.zeros(1, 1).cuda()), fn._lib.ptr(flat), fn._lib.ptr(pf),
-        fn._lib.ptr(torch.zeros(1, 1, 4).cuda()), None, None)
+    a = (7, 1, 1, fn._lib.ptr(torch.zeros(1, 11).cuda()), fn._lib.ptr(torch.zeros(1, 1).cuda()), fn._lib.ptr(flat), fn._lib.ptr(pf),
+         fn._lib.ptr(torch.zeros(1, 1, 4).cuda()), None)
+    if math_mode == 'bf16x6':
+        rc = lib.fastnerf_mlp_x6_fwd(*a, 0, None)
+    else:
+        rc = (lib.fastnerf_mlp_bf16_fwd if math_mode == 'bf16x3' else lib.fastnerf_mlp_fwd_ex)(*a, None)
     assert rc != 0 and b'kind' in lib.fastnerf_last_error()
     # packed weights of the other math mode are rejected by the wrappers
     other = 'fp32' if math_mode == 'bf16x3' else 'bf16x3'
