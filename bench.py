@@ -7,11 +7,16 @@ sampling -> PE -> coarse / fine MLP -> compositing -> 2 x MSE + per-(image, leaf
 
 `value` follows SURVEY 8(d) to the letter: 100 pose_spherical(-180 + 3.6 k, -30, 4) cameras, 800 x 800, focal 1111.11, near 2 /
 far 6; every batch = 4096 rays drawn uniformly from all 64 M pixels, targets U[0,1)^3 (values do not affect timing), nets at
-their default initialisation (seed 0), perturb = 1, white background, leaf tags of a depth-5 quadtree; the EXACT-fp32 math
-mode (v_mfma_f32_32x32x2_f32: the reference's own arithmetic width) and the PLAIN backward (every sample goes through
-loss.backward(); FASTNERF_COMPACT is forced to 0 for this leg).  Inputs are resident in HBM before the timed region.
+their default initialisation (seed 0), perturb = 1, white background, leaf tags of a depth-5 quadtree; fp32-WIDTH arithmetic
+and the PLAIN backward (every sample goes through loss.backward(); FASTNERF_COMPACT is forced to 0 for this leg).  Inputs are
+resident in HBM before the timed region.  The arithmetic is the `bf16x6` mode of csrc/mlp.hip: every fp32 operand decomposed
+EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits), every product the sum of its six piece products of weight >= 2^-16
+with fp32 accumulation on v_mfma_f32_32x32x16_bf16 -- the dropped terms are <= 2^-24 of the product, fp32's own rounding; measured
+against fp64 its logits / head-layer gradients are as close as the fp32-MFMA kernels' (tests/test_gpu_mlp.py::
+test_bf16x6_decomposition_is_exact_and_products_have_fp32_width, profiles/r03_precision_vs_fp64.md).
 
 Everything else rides in the same JSON line as named sibling blocks and never feeds `value`:
+  fp32_mfma_mode     the same protocol on v_mfma_f32_32x32x2_f32 (an fp32 FMA chain bit for bit; 157 TFLOP/s ceiling);
   split_bf16_mode    the same protocol in the split-bf16 mode (3 bf16 MFMA products per fp32 product, 16-bit operands: faster and
                      NARROWER than fp32, hence not the headline), plus that mode on a trained sparse scene with the exact
                      zero-gradient compaction (what a converged Lego-like field looks like to the backward);
@@ -49,6 +54,10 @@ TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + S1)  # 893.2
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 matrix peak
 PROFILE_ROUND = 'r03'
+MAIN_MODE = 'bf16x6'                        # the headline's arithmetic: fp32-width products on the bf16 matrix cores (docstring)
+MODE_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 1.0, 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'mlp_fwd_kernel', ''),
+             'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6.0, 6.0, 'dense bf16 MFMA 2500 TFLOP/s / 6 piece products per fp32 product', 'mlp_fwd_kernel', ', 1'),
+             'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 3.0, 'dense bf16 MFMA 2500 TFLOP/s / 3 split terms per product', 'mlp_fwd_bf16_kernel', '')}
 H = W = 800
 FOCAL = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
 PSNR_ITERS, PSNR_RAYS, PSNR_HELD_OUT = 200, 512, 2048
@@ -344,7 +353,7 @@ def main():
         d.update(kw)
         return d
 
-    def mlp_roofline(trainer, split):
+    def mlp_roofline(trainer, mode):
         """HIP-event timing of the MLP launches of one step's FINE pass (4096 x 192 points per rank at weak scaling); the
         launch the step spends the most time in is `roofline`.  achieved = algorithmic FLOPs of the launch / its duration."""
         ro, rd = batches[0][0], batches[0][1]
@@ -359,14 +368,14 @@ def main():
         raw = torch.empty(n, S1, 4, device=dev)
         draw = torch.randn(n, S1, 4, device=dev) * 1e-4
         reps = max(3, min(a.steps, 10))
-        peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
-        base = 'mlp_fwd_bf16_kernel' if split else 'mlp_fwd_kernel'
+        peak, n_prod, peak_note, base, targ = MODE_PEAK[mode]
+        split = mode == 'bf16x3'
         ms_save = time_launch(lambda: ops.mlp_fwd(rays11, z, trainer.net_f.flat, trainer.pf[0], act=act, raw=raw), reps)
         ms_inf = time_launch(lambda: ops.mlp_fwd(rays11, z, trainer.net_f.flat, trainer.pf[0], raw=raw), reps)
         ms_bwd = time_launch(lambda: ops.mlp_bwd(draw, act, trainer.net_f.flat, trainer.pf[1], dact, partial, gtmp), reps)
-        rows = [{'kernel': base + '<true, false>', 'what': 'training forward, saves activations, %d points' % P,
+        rows = [{'kernel': base + '<true, false%s>' % targ, 'what': 'training forward, saves activations, %d points' % P,
                  'points': P, 'avg_launch_ms': ms_save, 'flop_per_launch': P * FWD_FLOP_PER_POINT},
-                {'kernel': base + '<false, false>', 'what': 'forward without saving (inference), %d points' % P,
+                {'kernel': base + '<false, false%s>' % targ, 'what': 'forward without saving (inference), %d points' % P,
                  'points': P, 'avg_launch_ms': ms_inf, 'flop_per_launch': P * FWD_FLOP_PER_POINT},
                 {'kernel': 'backward of the pass: dX chain + 12 dW launches + head gradients + partial reduction (15 launches)',
                  'what': 'mlp_bwd, %d points' % P, 'points': P, 'avg_launch_ms': ms_bwd, 'flop_per_launch': P * BWD_FLOP_PER_POINT}]
@@ -377,30 +386,28 @@ def main():
         traffic = step_traffic = None
         try:   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles_r03.sh)
             pmc = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_pmc_traffic.json')))
-            mode = 'bf16x3' if split else 'fp32'
             traffic = pmc[mode]['kernels'][dom['kernel']]['hbm_bytes']
             step_traffic = pmc[mode]['step_traffic']
         except Exception:
             pass
         roof = {'bound': 'mfma', 'kernel': dom['kernel'] + ' (fine pass; ' + dom['what'] + ')', 'achieved': dom['achieved'],
                 'peak': peak, 'unit': 'TFLOP/s', 'frac': dom['frac'],
-                'peak_note': ('dense bf16 MFMA 2500 TFLOP/s / 3 split terms per product' if split
-                              else 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)'),
+                'peak_note': peak_note,
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/%s_pmc_traffic.json)' % PROFILE_ROUND,
                 'step_traffic': step_traffic, 'avg_launch_ms': dom['avg_launch_ms'], 'flop_per_launch': dom['flop_per_launch'],
-                'mfma_tflops_issued': (3.0 if split else 1.0) * dom['achieved'], 'launches': rows}
-        if split:
+                'mfma_tflops_issued': n_prod * dom['achieved'], 'launches': rows}
+        if mode != 'fp32':
             # tools/micro/mfma_power.hip: a saturated v_mfma_f32_32x32x16_bf16 stream holds 2.24-2.38 GHz on constant operands
             # but only 1.79 GHz = 1871 TFLOP/s on uniform(-1,1) bf16 data (power management)
-            roof['peak_measured_real_data'] = 1871.0 / 3.0
-            roof['frac_of_measured_peak'] = dom['achieved'] / (1871.0 / 3.0)
+            roof['peak_measured_real_data'] = 1871.0 / n_prod
+            roof['frac_of_measured_peak'] = dom['achieved'] / (1871.0 / n_prod)
         return roof
 
     # =====================================================================================================================
-    # headline: exact fp32, SURVEY 8(d) protocol, plain backward
+    # headline: fp32-width arithmetic (MAIN_MODE), SURVEY 8(d) protocol, plain backward
     # =====================================================================================================================
     main_mode, main_compact = ops.get_math(), fastnerf.render.get_compact()
-    ops.set_math('fp32')
+    ops.set_math(MAIN_MODE)
     fastnerf.render.set_compact('0')
     tr, _, kte, _ = new_trainer()
     dt, loss2, t_local = timed(lambda i: step(tr, i)[0], 0, a.warmup, a.steps)
@@ -422,16 +429,26 @@ def main():
     if a.sustained_steps > 0:   # power-managed clocks settle within seconds: the same stream of steps for a few seconds more
         ts, _, _ = timed(lambda i: step(tr, i)[0], a.warmup + a.steps, 0, a.sustained_steps)
         sustained = leg(ts, a.sustained_steps, wall_seconds=ts)
-    roof = mlp_roofline(tr, False) if rank == 0 else None
+    roof = mlp_roofline(tr, MAIN_MODE) if rank == 0 else None
     step_tflops = n_step * a.steps / dt * TRAIN_FLOP_PER_RAY / 1e12 / world
 
     # =====================================================================================================================
     # siblings (1 GPU, rank 0): never part of `value`
     # =====================================================================================================================
-    split_block = drop_in = infer = psnr_block = None
-    trb = kte_b = None
+    split_block = fp32_block = drop_in = infer = psnr_block = None
+    trb = kte_b = kte_32 = None
     if not a.no_siblings:
-        # ---- split-bf16: the same protocol (random init, noise targets, plain backward); every rank takes part ---------------
+        # ---- the same protocol (random init, noise targets, plain backward) in the other two modes; every rank takes part -----
+        ops.set_math('fp32')
+        tr32, _, kte_32, _ = new_trainer()
+        t32_, l32_, _ = timed(lambda i: step(tr32, i)[0], 0, 3, 20)
+        if rank == 0:
+            fp32_block = {'math_mode': 'fp32', 'dtype': 'f32: v_mfma_f32_32x32x2_f32, an fp32 FMA chain (157.3 TFLOP/s ceiling)',
+                          'init_state': leg(t32_, 20, warmup=3, backward='plain', final_loss=[float(x) for x in l32_.tolist()],
+                                            what='the headline protocol on the fp32 matrix instruction',
+                                            step_frac_of_fp32_mfma_peak=n_step * 20 / t32_ * TRAIN_FLOP_PER_RAY / 1e12 / world / FP32_MFMA_PEAK_TFLOPS),
+                          'roofline': mlp_roofline(tr32, 'fp32')}
+        del tr32
         ops.set_math('bf16x3')
         trb, _, kte_b, _ = new_trainer()
         tb, lb, _ = timed(lambda i: step(trb, i)[0], 0, 3, 20)
@@ -441,7 +458,7 @@ def main():
                            'init_state': leg(tb, 20, warmup=3, backward='plain', final_loss=[float(x) for x in lb.tolist()],
                                              what='the headline protocol (random init, U[0,1) targets, plain backward) in this mode',
                                              step_frac_of_bf16_mfma_peak_x3=3.0 * n_step * 20 / tb * TRAIN_FLOP_PER_RAY / 1e12 / world / BF16_MFMA_PEAK_TFLOPS),
-                           'roofline': mlp_roofline(trb, True)}
+                           'roofline': mlp_roofline(trb, 'bf16x3')}
     if siblings:
         # ---- split-bf16 on a trained sparse scene, compacted backward (round 2's headline, now a named sibling) -------------
         fastnerf.render.set_compact('auto')
@@ -488,12 +505,14 @@ def main():
                 return img_loss.detach()
             td, ld, _ = timed(one, 0, 3, 20)
             return leg(td, 20, warmup=3, final_img_loss=float(ld))
+        dmain = drop_in_leg(MAIN_MODE)
         d32 = drop_in_leg('fp32')
         d16 = drop_in_leg('bf16x3')
         drop_in = {'what': 'the reference\'s loop verbatim on the drop-in surface: render(retraw=True) -> img2mse x 2 -> loss.backward() -> '
                            'torch.optim.Adam(48 tensors).step() -> lr rule; same protocol and batches as `value`',
-                   'fp32': d32, 'bf16x3': d16,
-                   'fraction_of_fused_trainer': {'fp32': d32['value'] / (n_step * a.steps / dt),
+                   MAIN_MODE: dmain, 'fp32': d32, 'bf16x3': d16,
+                   'fraction_of_fused_trainer': {MAIN_MODE: dmain['value'] / (n_step * a.steps / dt),
+                                                 'fp32': d32['value'] / fp32_block['init_state']['value'],
                                                  'bf16x3': d16['value'] / split_block['init_state']['value']}}
 
         # ---- PSNR at equal iterations: GPU side (both modes, free runs + a 1-ulp ensemble) on the inputs the CPU worker got ---
@@ -503,23 +522,23 @@ def main():
                                    't_rand / u (seed 2) and initial weights (seed 0) on both sides',
                           'train_psnr_window': 20, 'held_out_rays': PSNR_HELD_OUT, 'gpu': {}}
             dd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in psnr_data.items()}
-            for mode in ('fp32', 'bf16x3'):
+            for mode in (MAIN_MODE, 'fp32', 'bf16x3'):
                 psnr_block['gpu'][mode] = psnr_gpu_free(fastnerf, dd, new_trainer, K, mode)[0]
-            ens = [psnr_gpu_free(fastnerf, dd, new_trainer, K, 'fp32', jitter_ulp_seed=100 + j)[0] for j in range(8)]
+            ens = [psnr_gpu_free(fastnerf, dd, new_trainer, K, MAIN_MODE, jitter_ulp_seed=100 + j)[0] for j in range(8)]
             psnr_block['gpu_ensemble'] = {
-                'what': '8 more fp32 runs whose initial weights differ from the first by a random -1 / 0 / +1 ulp: the spread two runs of '
+                'what': '8 more ' + MAIN_MODE + ' runs whose initial weights differ from the first by a random -1 / 0 / +1 ulp: the spread two runs of '
                         'the same arithmetic reach at this iteration count (trajectories decorrelate within ~30 iterations: DESIGN 5)',
                 'train_psnr_db': [e['train_psnr_db'] for e in ens], 'held_out_psnr_db': [e['held_out_psnr_db'] for e in ens],
                 'train_psnr_std_db': float(np.std([e['train_psnr_db'] for e in ens], ddof=1)),
                 'held_out_psnr_std_db': float(np.std([e['held_out_psnr_db'] for e in ens], ddof=1))}
 
         # ---- inference rays/s (render_path-style, perturb=0, no saved activations) -------------------------------
-        ops.set_math('fp32')
+        ops.set_math(MAIN_MODE)
         n_inf = 32768
         pix = draw_pixels(torch.Generator().manual_seed(7), n_inf).to(dev)
         ro_i, rd_i = ops.gen_rays_pixels(pix, poses, K)
         infer = {'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), random-init nets, 1 GPU'}
-        for mode, kt in (('fp32', kte), ('bf16x3', kte_b)):
+        for mode, kt in ((MAIN_MODE, kte), ('fp32', kte_32), ('bf16x3', kte_b)):
             ops.set_math(mode)
             with torch.no_grad():
                 for _ in range(2):
@@ -552,7 +571,7 @@ def main():
                     psnr_block['lockstep'] = {
                         'what': 'the GPU step taken from the CPU run\'s state before every iteration (weights + Adam moments): the same PSNR '
                                 'window without trajectory divergence; delta_db = GPU - CPU'}
-                    for mode in ('fp32', 'bf16x3'):
+                    for mode in (MAIN_MODE, 'fp32', 'bf16x3'):
                         r_ = psnr_gpu_lockstep(fastnerf, dd, new_trainer, states, r['losses'], mode)
                         r_['delta_db'] = r_['train_psnr_db'] - psnr_block['cpu']['train_psnr_db']
                         psnr_block['lockstep'][mode] = r_
@@ -570,21 +589,25 @@ def main():
             'metric': 'training rays/sec (Lego-like 800x800, 64+128 samples) + PSNR@N-iters', 'value': rays_per_s, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
             'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'math_mode': 'fp32 (v_mfma_f32_32x32x2_f32, fp32 accumulate)',
+            'dtype': 'f32', 'math_mode': MAIN_MODE + ': fp32-width products on the bf16 matrix cores -- operands decomposed exactly into three bf16 '
+                                         'pieces, six piece products per fp32 product (weight >= 2^-16; dropped <= 2^-24), fp32 accumulation; '
+                                         'activations, gradients, parameters and optimiser state stay fp32',
             'data': 'synthetic (SURVEY 8d: 100 pose_spherical cameras of 800x800, uniformly drawn rays, U[0,1) targets, default-init nets seed 0)',
             'config': {'workload': 'nerf-ours Lego full 800x800 (BASELINE configs[1]), SURVEY 8(d) throughput protocol: %d uniformly drawn rays '
                                    'per GPU per step, 64+128 samples, use_viewdirs, white_bkgd, perturb=1, U[0,1) targets, random-init nets, '
-                                   'leaf-error table on, exact-fp32 MFMA kernels, plain backward (FASTNERF_COMPACT=0)' % n_local,
+                                   'leaf-error table on, fp32-width bf16x6 kernels, plain backward (FASTNERF_COMPACT=0)' % n_local,
                        'rays_per_gpu_per_step': n_local, 'rays_per_step': n_step, 'parallelism': f'dp{world}'},
             'device': {'name': torch.cuda.get_device_name(dev), 'compute_units': torch.cuda.get_device_properties(dev).multi_processor_count},
             'final_loss': [float(x) for x in loss2.tolist()], 'backward': 'plain (every sample)',
             'per_rank_ms_per_step': per_rank_ms, 'allreduce_ms': allreduce_ms,
-            'step_tflops_per_gpu': step_tflops, 'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
+            'step_tflops_per_gpu': step_tflops, 'step_frac_of_peak': step_tflops / MODE_PEAK[MAIN_MODE][0],
+            'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
             'step_tflops_note': 'rays/s x the algorithmic FLOPs of a step (893.2 MFLOP/ray, SURVEY 8d); the fp32-MFMA roofline of the step is '
                                 '%.1f k rays/s/GPU' % (FP32_MFMA_PEAK_TFLOPS * 1e12 / TRAIN_FLOP_PER_RAY / 1e3),
             'sustained': sustained,
             'roofline': roof,
             'psnr_vs_cpu': psnr_block,
+            'fp32_mfma_mode': fp32_block,
             'split_bf16_mode': split_block,
             'drop_in_route': drop_in,
             'inference': infer,

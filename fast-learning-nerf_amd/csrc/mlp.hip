@@ -126,12 +126,38 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // bf16(a)
   const f32x2v v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
 }
-// x0, x1 -> packed pieces (h, m, l); exact: x = h + m + l
+// x0, x1 -> packed pieces (h, m, l); exact: x = h + m + l.  The residual x - bf16(x) is one v_dot2c_f32_bf16 per value (the
+// packed piece times (-1, 0) or (0, -1), accumulated onto x: every intermediate is exactly representable), instead of an
+// unpack (shift / mask) and a subtraction: 7 VALU instructions per pair of values.
+#ifndef X6_DOT2
+#define X6_DOT2 1
+#endif
+#ifndef X6_PRIO
+#define X6_PRIO 1   // s_setprio level of a wave inside the six-product k-loops (0: none)
+#endif
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#if X6_DOT2
+  // (-1, 0) and (0, -1) as bf16 pairs, through opaque scalar moves: handed the constant vectors, hipcc (ROCm 7.2) encodes the
+  // first one as the inline operand -1.0, which this instruction does not read as a bf16 pair (wrong results on gfx950)
+  unsigned c10, c01;
+  asm("s_mov_b32 %0, 0xbf80" : "=s"(c10));
+  asm("s_mov_b32 %0, 0xbf800000" : "=s"(c01));
+  const bf16x2v m10 = __builtin_bit_cast(bf16x2v, c10), m01 = __builtin_bit_cast(bf16x2v, c01);
+  const f32x2v v = {x0, x1};
+  const bf16x2v hv = __builtin_convertvector(v, bf16x2v);
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(hv, m10, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(hv, m01, x1, false);
+  const f32x2v rv = {r0, r1};
+  const bf16x2v mv = __builtin_convertvector(rv, bf16x2v);
+  const f32x2v sv = {__builtin_amdgcn_fdot2_f32_bf16(mv, m10, r0, false), __builtin_amdgcn_fdot2_f32_bf16(mv, m01, r1, false)};
+  h = __builtin_bit_cast(unsigned, hv);
+  m = __builtin_bit_cast(unsigned, mv);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(sv, bf16x2v));
+#else
   h = cvt_pk_bf16(x0, x1);
   const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
   m = cvt_pk_bf16(r0, r1);
   l = cvt_pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+#endif
 }
 __global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* __restrict__ params,
                                                      uint4* __restrict__ pf, uint4* __restrict__ pb) {
@@ -378,20 +404,17 @@ __device__ __forceinline__ void split3_frag(const float4& lo4, const float4& hi4
 }
 template <int NT>
 __device__ __forceinline__ void mfma6(f32x16 (&acc)[2][NT], const float4 (&a)[2][2], const uint4 (&b)[NT][3]) {
+  uint4 ap[3][2];   // [piece][row tile]
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    uint4 ah, am, al;
-    split3_frag(a[mt][0], a[mt][1], ah, am, al);
+  for (int mt = 0; mt < 2; ++mt) split3_frag(a[mt][0], a[mt][1], ap[0][mt], ap[1][mt], ap[2][mt]);
+  // product-major: consecutive MFMAs go to different accumulators (no back-to-back dependency); small terms first
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      acc[mt][nt] = mfma_bf16(al, b[nt][0], acc[mt][nt]);
-      acc[mt][nt] = mfma_bf16(ah, b[nt][2], acc[mt][nt]);
-      acc[mt][nt] = mfma_bf16(am, b[nt][1], acc[mt][nt]);
-      acc[mt][nt] = mfma_bf16(am, b[nt][0], acc[mt][nt]);
-      acc[mt][nt] = mfma_bf16(ah, b[nt][1], acc[mt][nt]);
-      acc[mt][nt] = mfma_bf16(ah, b[nt][0], acc[mt][nt]);
-    }
-  }
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ap[PA[t]][mt], b[nt][PB[t]], acc[mt][nt]);
 }
 // a_ks0 / nks / KS / b_ks0 in 16-wide k-steps; Bp = this layer's packed block (uint4 units)
 template <int NT, int AMODE>
@@ -439,6 +462,9 @@ __device__ __forceinline__ void gemm_seg6(f32x16 (&acc)[2][NT], const float* __r
   float4 a0[2][2], a1[2][2];
   uint4 b0[NT][3], b1[NT][3];
   load_b(b0, 0); load_a(a0, 0);
+#if X6_PRIO
+  __builtin_amdgcn_s_setprio(X6_PRIO);
+#endif
 #pragma unroll 1
   for (int ks = 0; ks < nks; ks += 2) {   // nks is even for every segment
     load_b(b1, ks + 1); load_a(a1, ks + 1);
@@ -446,6 +472,9 @@ __device__ __forceinline__ void gemm_seg6(f32x16 (&acc)[2][NT], const float* __r
     if (ks + 2 < nks) { load_b(b0, ks + 2); load_a(a0, ks + 2); } else side_copy();
     mfma6<NT>(acc, a1, b1);
   }
+#if X6_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // one call site for both math modes: k-steps in the 8-wide units of gemm_seg, Bw = the layer's block in this mode's packing

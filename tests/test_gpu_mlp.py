@@ -346,3 +346,64 @@ def test_tile_scheduler_back_to_back_and_streams(fn, weights):
             assert torch.equal(grads, cases[ci][4]), ci
     finally:
         fn.ops.set_math(old)
+
+
+def test_bf16x6_decomposition_is_exact_and_products_have_fp32_width(fn, weights):
+    """The bf16x6 mode's claim (csrc/mlp.hip, MM_X6): every fp32 operand is decomposed EXACTLY into three bf16 pieces, so a product
+    evaluated from the six leading piece products is as accurate as fp32's own rounding of it.
+    (a) the packed weight planes of every layer sum back to the fp32 weights bit for bit (h + m + l in fp64, rounded to fp32);
+    (b) against an fp64 evaluation of the network on the same fp32 inputs, the logits of the bf16x6 kernels are as close as the
+        exact-fp32 MFMA kernels' (both are dominated by fp32 accumulation and sin / cos rounding), while the two-piece split-bf16
+        mode -- 16-bit operands -- sits measurably further away: that mode is narrower than fp32, this one is not."""
+    old = fn.ops.get_math()
+    try:
+        flat = flat_of(weights).cuda()
+        fn.ops.set_math('bf16x6')
+        pf, pb = fn.ops.mlp_pack(flat)
+        u16 = pf.cpu().numpy().view(np.uint16)             # uint4 units of 8 bf16: [tile][ks][plane][lane][8]
+
+        def bf(x):
+            return (x.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        off = 0
+        for l in range(10):
+            name = ('pts_linears.%d.weight' % l) if l < 8 else ('feature_linear.weight' if l == 8 else 'views_linears.0.weight')
+            w = weights[name].numpy()
+            N = w.shape[0]
+            kp = 64 if l == 0 else (320 if l == 5 else (288 if l == 9 else 256))
+            n_u4 = (N // 32) * (kp // 16) * 3 * 64
+            blk = u16[off * 8:(off + n_u4) * 8].reshape(N // 32, kp // 16, 3, 64, 8)
+            tot = bf(blk[:, :, 0]) + bf(blk[:, :, 1]) + bf(blk[:, :, 2])          # [tile][ks][lane][8]
+            # lane l of (tile, ks): n = tile*32 + (l & 31), k' = ks*16 + (l >> 5)*8 + 0..7
+            got = tot.reshape(N // 32, kp // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(N, kp)
+            if l == 0:
+                ref = np.concatenate([w, np.zeros((N, 1), np.float32)], 1)
+            elif l == 5:
+                ref = np.concatenate([w[:, :63], np.zeros((N, 1), np.float32), w[:, 63:]], 1)
+            elif l == 9:
+                ref = np.concatenate([w, np.zeros((N, 5), np.float32)], 1)
+            else:
+                ref = w
+            assert np.array_equal(got.astype(np.float32), ref) and np.array_equal(got, ref.astype(np.float64)), name
+            off += n_u4
+        assert off * 4 == pf.numel()
+        # (b) logits against fp64
+        gen = torch.Generator().manual_seed(4)
+        P = 4096
+        pts = (torch.rand(P, 3, generator=gen) * 2 - 1) * 1.5
+        vd = torch.randn(P, 3, generator=gen)
+        vd = vd / vd.norm(dim=-1, keepdim=True)
+        rays = rays_for_points(pts, vd).cuda()
+        sd64 = {k: v.double() for k, v in weights.items()}
+        x = torch.cat([O.posenc(pts.double(), 10), O.posenc(rays[:, 8:11].cpu().double(), 4)], -1)
+        ref = O.nerf_forward(sd64, x)
+        err = {}
+        for mode in fn.ops.MATH_MODES:
+            fn.ops.set_math(mode)
+            p1, _ = fn.ops.mlp_pack(flat)
+            raw = fn.ops.mlp_fwd(rays, torch.zeros(P, 1).cuda(), flat, p1)[:, 0].cpu().double()
+            err[mode] = float((raw - ref).pow(2).mean().sqrt())
+        print('rms logit error vs fp64:', err)
+        assert err['bf16x6'] <= 1.25 * err['fp32'] + 1e-9, err
+        assert err['bf16x3'] >= 1.5 * err['fp32'], err
+    finally:
+        fn.ops.set_math(old)

@@ -1,7 +1,8 @@
-"""MLP-only gradient check with TRAINED weights against an fp64 autograd reference: same points, same cotangent, both math
-modes.  Reports per parameter tensor the relative L2 error of each mode vs fp64 and the ratio of sums (bias check)."""
+"""MLP-only logit / gradient check with TRAINED weights against an fp64 autograd reference: same points, same cotangent, every math
+mode.  Reports per parameter tensor the relative L2 error of each mode vs fp64 and the ratio of sums (bias check)."""
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import fastnerf as fn
 from fastnerf import ops
 from oracle import nerf_oracle as O
@@ -30,7 +31,8 @@ z = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, -1).values.to(dev)
 cot = (torch.randn(n, S, 4, generator=gen) * 1e-3).to(dev)
 P = n * S
 res = {}
-for mode in ('fp32', 'bf16x3'):
+MODES = ('fp32', 'bf16x6', 'bf16x3')
+for mode in MODES:
     ops.set_math(mode)
     pf, pb = net.packed(refresh=True)
     act = torch.empty(ops.act_floats(P), device=dev)
@@ -51,16 +53,17 @@ raw64 = O.nerf_forward(sd, x).reshape(n, S, 4)
 (raw64 * cot.cpu().double()).sum().backward()
 names = [nm for nm, _ in O.nerf_param_shapes()]
 g64 = torch.cat([sd[nm].grad.reshape(-1) for nm in names])
-for mode in ('fp32', 'bf16x3'):
+for mode in MODES:
     raw, g = res[mode]
-    print('%-7s raw: max abs err %.3e (max |raw| %.2f)   grad: ||g - g64|| / ||g64|| = %.3e' % (
-        mode, (raw - raw64.detach()).abs().max().item(), raw64.abs().max().item(), ((g - g64).norm() / g64.norm()).item()))
+    e = (raw - raw64.detach()).abs()
+    print('%-7s raw: max abs err %.3e  mean abs err %.3e  rms %.3e (max |raw| %.2f)   grad: ||g - g64|| / ||g64|| = %.3e' % (
+        mode, e.max().item(), e.mean().item(), e.pow(2).mean().sqrt().item(), raw64.abs().max().item(), ((g - g64).norm() / g64.norm()).item()))
 off = 0
 for nm, s in O.nerf_param_shapes():
     k = int(np.prod(s))
     r = g64[off:off + k]
     line = '%-28s' % nm
-    for mode in ('fp32', 'bf16x3'):
+    for mode in MODES:
         a = res[mode][1][off:off + k]
         line += '  %s rel %.2e sum-ratio %.6f' % (mode, ((a - r).norm() / r.norm()).item(), (a.sum() / r.sum()).item())
     print(line)
