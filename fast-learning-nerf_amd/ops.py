@@ -26,7 +26,7 @@ DACT_FLOATS = 2432
 #            fp32 (products ~2^-17 relative), ~2.5x the rate of 'fp32'; rendered RGB still within 1e-6 of the fp32 kernels
 import os
 MATH_MODES = ('fp32', 'bf16x3', 'bf16x6')
-_MATH = os.environ.get('FASTNERF_MATH', 'bf16x3')
+_MATH = os.environ.get('FASTNERF_MATH', 'bf16x6')   # default: the reference's arithmetic width
 assert _MATH in MATH_MODES, 'FASTNERF_MATH must be one of ' + ', '.join(MATH_MODES)
 
 

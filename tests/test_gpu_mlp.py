@@ -81,7 +81,7 @@ def test_pack_roundtrip_bf16(fn, weights):
         got = bf16_pair_to_f32(bt[nt, ks, 0, l, e:e + 1], bt[nt, ks, 1, l, e:e + 1])[0]
         want = Wf[ks * 16 + (l >> 5) * 8 + e, n]
         assert abs(got - want) <= 2.0 ** -16 * abs(want)
-    fn.ops.set_math(os.environ.get('FASTNERF_MATH', 'bf16x3'))
+    fn.ops.set_math(os.environ.get('FASTNERF_MATH', 'bf16x6'))
 
 
 def test_pack_roundtrip(fn, weights):
@@ -103,7 +103,7 @@ def test_pack_roundtrip(fn, weights):
     bt = pb[128 * 256:128 * 256 + 65536].reshape(8, 32, 64, 4)
     for jt, ks, l, t in ((0, 0, 0, 0), (5, 9, 50, 1)):
         assert bt[jt, ks, l, t] == Wf[ks * 8 + (l >> 5) * 4 + t, jt * 32 + (l & 31)]
-    fn.ops.set_math(os.environ.get('FASTNERF_MATH', 'bf16x3'))
+    fn.ops.set_math(os.environ.get('FASTNERF_MATH', 'bf16x6'))
 
 
 @pytest.mark.parametrize('P', [1, 127, 128, 129, 1000])
