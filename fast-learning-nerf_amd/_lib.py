@@ -75,6 +75,9 @@ SIGNATURES = {
     'fastnerf_pp_intersect_sphere': (I, [L, P, P, P, P]),
     'fastnerf_pp_fg_depths': (I, [L, I, F, P, I, P, U64, P, P]),
     'fastnerf_pp_sample_pdf_merge': (I, [L, I, I, P, P, I, P, U64, P, P, P]),
+    'fastnerf_pp_perturb_samples': (I, [L, I, P, P, U64, P, P]),
+    'fastnerf_pp_sample_pdf': (I, [L, I, I, P, P, I, P, U64, P, P]),
+    'fastnerf_pp_depth2pts_outside': (I, [L, I, P, P, P, P, P, P]),
     'fastnerf_pp_composite_fwd': (I, [L, I, I, P, P, P, P, P, P, P, P, P]),
     'fastnerf_pp_composite_bwd': (I, [L, I, I, P, P, P, P, P, P, P, P]),
     'fastnerf_pp_gen_rays': (I, [I, I, P, P, P, P, P]),

@@ -503,3 +503,20 @@ extern "C" int fastnerf_pp_sample_pdf_merge(int64_t n, int S, int Ni, const floa
   FN_LAUNCH_CHECK();
   return 0;
 }
+
+// nerf++ stand-alone sample_pdf(bins [n,M], weights [n,M-1]) -> samples [n,Ni] (ddp_train_nerf.py:84-133 as its callers outside
+// train_step use it): eps 1e-6, index = #(u >= cdf[:M]), +1e-6 bin width.
+extern "C" int fastnerf_pp_sample_pdf(int64_t n, int M, int Ni, const float* bins, const float* weights, int det, const float* u,
+                                      uint64_t seed, float* samples, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && M >= 2 && M + 1 <= WAVE * MAXC && Ni >= 1 && Ni <= 1024, "n>=0, 2<=M<=511, 1<=Ni<=1024");
+  FN_CHECK_ARG(n == 0 || (bins && weights && samples), "null pointer");
+  if (n == 0) return 0;
+  int NP = 1;
+  while (NP < Ni) NP <<= 1;
+  const int S = M + 1;
+  const size_t lds = (size_t)4 * (3 * S + NP) * sizeof(float);
+  hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3(grid_waves(n)), dim3(256), lds, fn::S(stream), n, S, Ni, NP, 1, 1,
+                     bins, weights, det, u, seed, (float*)nullptr, samples, (float*)nullptr);
+  FN_LAUNCH_CHECK();
+  return 0;
+}

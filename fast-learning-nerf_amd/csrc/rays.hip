@@ -454,6 +454,88 @@ extern "C" int fastnerf_pp_fg_depths(int64_t n, int S, float near, const float* 
 }
 
 
+// perturb_samples (ddp_train_nerf.py:72-81): stratified jitter of arbitrary sorted depths, z -> lower + (upper - lower) * u with
+// the mid points as interval borders; u injected ([n,S]) or Philox(seed).
+__global__ void pp_perturb_kernel(int64_t n, int S, const float* __restrict__ zin, const float* __restrict__ t_rand,
+                                  uint64_t seed, float* __restrict__ z) {
+  const int64_t total = n * S;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(i % S);
+    const float zc = zin[i];
+    const float lower = (s > 0) ? fmul(0.5f, fadd(zc, zin[i - 1])) : zc;
+    const float upper = (s < S - 1) ? fmul(0.5f, fadd(zin[i + 1], zc)) : zc;
+    float u;
+    if (t_rand) {
+      u = t_rand[i];
+    } else {
+      uint32_t o[4];
+      philox4x32((uint32_t)i, (uint32_t)(i >> 32), 0x70727462u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+      u = u01(o[0]);
+    }
+    z[i] = fadd(lower, fmul(fsub(upper, lower), u));
+  }
+}
+extern "C" int fastnerf_pp_perturb_samples(int64_t n, int S, const float* z_in, const float* t_rand, uint64_t seed, float* z_out,
+                                           fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 1 && (n == 0 || (z_in && z_out)) && z_in != z_out, "n>=0, S>=1, non-null distinct pointers");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(pp_perturb_kernel, dim3(grid_for(n * S)), dim3(256), 0, fn::S(stream), n, S, z_in, t_rand, seed, z_out);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+// depth2pts_outside (ddp_model.py:16-45): the 4-D inverted-sphere point (x', y', z', 1/r) of every background sample and its
+// conventional depth; the arithmetic (and its order) is the one the fused background MLP kernels evaluate per point.
+__global__ void pp_depth2pts_kernel(int64_t n, int S, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                    const float* __restrict__ depth, float* __restrict__ pts, float* __restrict__ depth_real) {
+  const int64_t total = n * S;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / S;
+    const float o[3] = {ray_o[r * 3], ray_o[r * 3 + 1], ray_o[r * 3 + 2]}, d[3] = {ray_d[r * 3], ray_d[r * 3 + 1], ray_d[r * 3 + 2]};
+    const float dep = depth[i];
+    const float dd = fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2]));
+    const float od = fadd(fadd(fmul(d[0], o[0]), fmul(d[1], o[1])), fmul(d[2], o[2]));
+    const float d1 = -od / dd;
+    float pm_[3], ps[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pm_[c] = fadd(o[c], fmul(d1, d[c]));
+    const float pmn = sqrtf(fadd(fadd(fmul(pm_[0], pm_[0]), fmul(pm_[1], pm_[1])), fmul(pm_[2], pm_[2])));
+    const float dcos = 1.0f / sqrtf(dd);
+    const float d2 = fmul(sqrtf(fsub(1.0f, fmul(pmn, pmn))), dcos);
+    const float d12 = fadd(d1, d2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ps[c] = fadd(o[c], fmul(d12, d[c]));
+    float ax[3] = {fsub(fmul(o[1], ps[2]), fmul(o[2], ps[1])), fsub(fmul(o[2], ps[0]), fmul(o[0], ps[2])),
+                   fsub(fmul(o[0], ps[1]), fmul(o[1], ps[0]))};
+    const float an = sqrtf(fadd(fadd(fmul(ax[0], ax[0]), fmul(ax[1], ax[1])), fmul(ax[2], ax[2])));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ax[c] = ax[c] / an;
+    const float theta = asinf(fmul(pmn, dep));
+    const float ang = fsub(asinf(pmn), theta);
+    const float ca = cosf(ang), sa = sinf(ang);
+    const float cr[3] = {fsub(fmul(ax[1], ps[2]), fmul(ax[2], ps[1])), fsub(fmul(ax[2], ps[0]), fmul(ax[0], ps[2])),
+                         fsub(fmul(ax[0], ps[1]), fmul(ax[1], ps[0]))};
+    const float dot = fadd(fadd(fmul(ax[0], ps[0]), fmul(ax[1], ps[1])), fmul(ax[2], ps[2]));
+    const float omc = fsub(1.0f, ca);
+    float pn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pn[c] = fadd(fadd(fmul(ps[c], ca), fmul(cr[c], sa)), fmul(fmul(ax[c], dot), omc));
+    const float nn = sqrtf(fadd(fadd(fmul(pn[0], pn[0]), fmul(pn[1], pn[1])), fmul(pn[2], pn[2])));
+    pts[i * 4] = pn[0] / nn; pts[i * 4 + 1] = pn[1] / nn; pts[i * 4 + 2] = pn[2] / nn; pts[i * 4 + 3] = dep;
+    if (depth_real) depth_real[i] = fadd(fmul(fmul(1.0f / fadd(dep, 1e-6f), cosf(theta)), dcos), d1);
+  }
+}
+extern "C" int fastnerf_pp_depth2pts_outside(int64_t n, int S, const float* ray_o, const float* ray_d, const float* depth, float* pts,
+                                             float* depth_real, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && S >= 1 && (n == 0 || (ray_o && ray_d && depth && pts)), "n>=0, S>=1, non-null pointers");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(pp_depth2pts_kernel, dim3(grid_for(n * S)), dim3(256), 0, fn::S(stream), n, S, ray_o, ray_d, depth, pts,
+                     depth_real);
+  FN_LAUNCH_CHECK();
+  return 0;
+}
+
+
 // nerf++ ray generator (nerf_sample_ray_split.py:10-34): OpenCV convention, pixel centres at +0.5,
 // d = R * K^-1 * [u, v, 1], evaluated in fp64 like the reference's numpy code and rounded once.
 struct Mat9d { double m[9]; };

@@ -195,14 +195,50 @@ class NerfNetWithAutoExpo(nn.Module):
     def forward(self, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, img_name=None):
         return self.nerf_net(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
 
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's checkpoints: its nets are saved through nn.DataParallel (`module.` prefix, ddp_train_nerf.py:154)."""
+        sd = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        return super().load_state_dict(sd, strict=strict)
+
+    def reference_state_dict(self):
+        """state_dict under the names the reference saves and strictly loads (`module.nerf_net.fg_net. ...`)."""
+        return OrderedDict(('module.' + k, v) for k, v in self.state_dict().items())
+
 
 def intersect_sphere(ray_o, ray_d):
     """ddp_train_nerf.py:54-69."""
     return ops.pp_intersect_sphere(ops.pack_rays(ray_o, ray_d, 0.0, 0.0))
 
 
+def perturb_samples(z_vals):
+    """ddp_train_nerf.py:72-81: stratified jitter of sorted depths [..., S] inside their mid-point intervals (the uniform
+    draws come from a Philox stream keyed from torch's CPU generator, like every device-side draw of this package)."""
+    ops.require_gpu(z_vals)
+    sh = z_vals.shape
+    return ops.pp_perturb_samples(z_vals.reshape(-1, sh[-1]), seed=_next_seed()).reshape(sh)
+
+
 def sample_pdf(bins, weights, N_samples, det=False):
-    raise NotImplementedError('use ops.pp_sample_pdf_merge (sampler + sort-merge in one kernel)')
+    """ddp_train_nerf.py:84-133: bins [..., M+1], weights [..., M] -> [..., N_samples] (train_step and render_single_image use
+    the fused sampler + sort-merge ops.pp_sample_pdf_merge; this is the stand-alone form for other callers)."""
+    ops.require_gpu(bins, weights)
+    sh = list(weights.shape[:-1])
+    if bins.shape[-1] != weights.shape[-1] + 1:
+        raise ValueError('sample_pdf: bins must have one entry more than weights')
+    out = ops.pp_sample_pdf(bins.reshape(-1, bins.shape[-1]), weights.reshape(-1, weights.shape[-1]), N_samples, det=det,
+                            seed=0 if det else _next_seed())
+    return out.reshape(sh + [N_samples])
+
+
+def depth2pts_outside(ray_o, ray_d, depth):
+    """ddp_model.py:16-45: ray_o / ray_d [..., 3], depth [...] (inverse distance to the sphere origin, in [0, 1]) ->
+    (pts [..., 4], depth_real [...])."""
+    ops.require_gpu(ray_o, ray_d, depth)
+    sh = depth.shape
+    ro = ray_o.expand(list(sh) + [3]).reshape(-1, 3)
+    rd = ray_d.expand(list(sh) + [3]).reshape(-1, 3)
+    pts, dr = ops.pp_depth2pts_outside(ro, rd, depth.reshape(-1, 1))
+    return pts.reshape(list(sh) + [4]), dr.reshape(sh)
 
 
 def render_single_image(models, ray_sampler, chunk_size):
@@ -317,6 +353,13 @@ class QuadTreeManager:
     def __getattr__(self, name):
         return getattr(self.__dict__['_b'], name)
 
+    def __setattr__(self, name, value):
+        # the reference's loop assigns manager state directly (treeManager.epoch_size = ..., ddp_train_nerf.py:282)
+        if name in ('epoch_size', 'cur_level', 'quadTrees', 'childrens') and '_b' in self.__dict__:
+            setattr(self.__dict__['_b'], name, value)
+        else:
+            object.__setattr__(self, name, value)
+
     def gen_rays_v3_multiThread(self, down_scale=16, prob=True, rand=0.7, debug=False, last_epoch=False, compat_rng=True):
         """compat_rng=True: the reference's numpy / torch call order (seeded picks identical, host loop over leaves);
         False: the same distribution drawn for all leaves at once on the device."""
@@ -335,3 +378,128 @@ class QuadTreeManager:
 
     def adjust_tree_multiThread(self, rgb_gt, rgb_pred, thres=0.001, debug=False):
         return self._b.adjust_tree_multiThread(rgb_gt, rgb_pred, thres, debug)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the caller surface of nerf++-ours/ddp_train_nerf.py for config 5: create_nerf (:136-184), train_step (:327-424), the epoch loop
+# with the quadtree fork in it (:187-324).  Same names, arguments, return values and checkpoint files (`model_{epoch:04d}.pth`
+# holding net_<m> / optim_<m> state_dicts, net keys under DataParallel's `module.` prefix); what runs underneath is NerfNet on
+# the HIP kernels through its autograd node and torch.optim.Adam on the flat-buffer parameter views.  (The fused, autograd-free
+# engine for the same batch is CascadeTrainer.)
+# ---------------------------------------------------------------------------------------------------------------------
+def _ckpt_iter(path):
+    import os
+    stem = os.path.basename(path)[:-4]
+    return int(stem[stem.rfind('_') + 1:])
+
+
+def create_nerf(rank, args, device='cuda'):
+    """ddp_train_nerf.py:136-184 -> (start, models): models = OrderedDict(cascade_level, cascade_samples, net_<m>, optim_<m>); the
+    newest `*.pth` of basedir/expname (or args.ckpt_path) is reloaded unless args.no_reload.  Networks are initialised under
+    torch.manual_seed(777) like the reference, so that every process starts from the same weights."""
+    import os
+    if getattr(args, 'optim_autoexpo', False):
+        raise NotImplementedError('optim_autoexpo is dead code in the reference loop (train_step passes img_name=None)')
+    torch.manual_seed(777)
+    models = OrderedDict()
+    models['cascade_level'] = args.cascade_level
+    models['cascade_samples'] = [int(x.strip()) for x in args.cascade_samples.split(',')]
+    for m in range(models['cascade_level']):
+        net = NerfNetWithAutoExpo(args, optim_autoexpo=False, device=device)
+        models['net_{}'.format(m)] = net
+        models['optim_{}'.format(m)] = torch.optim.Adam(net.parameters(), lr=args.lrate)
+    start = 0
+    ckpt_path = getattr(args, 'ckpt_path', None)
+    d = os.path.join(args.basedir, args.expname)
+    if ckpt_path is not None and os.path.isfile(ckpt_path):
+        ckpts = [ckpt_path]
+    else:
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith('.pth')] if os.path.isdir(d) else []
+    ckpts = sorted(ckpts, key=_ckpt_iter)
+    if len(ckpts) > 0 and not getattr(args, 'no_reload', False):
+        start = _ckpt_iter(ckpts[-1])
+        to_load = torch.load(ckpts[-1], map_location=device, weights_only=False)
+        for m in range(models['cascade_level']):
+            for name in ('net_{}'.format(m), 'optim_{}'.format(m)):
+                models[name].load_state_dict(to_load[name])
+    return start, models
+
+
+def save_models(models, path):
+    """ddp_train_nerf.py:306-314: net_<m> / optim_<m> state_dicts, net keys as the reference's DataParallel wrapper names them."""
+    to_save = OrderedDict()
+    for m in range(models['cascade_level']):
+        to_save['net_{}'.format(m)] = models['net_{}'.format(m)].reference_state_dict()
+        to_save['optim_{}'.format(m)] = models['optim_{}'.format(m)].state_dict()
+    torch.save(to_save, path)
+
+
+def train_step(models, rays_o, rays_d, target_rgb, args):
+    """ddp_train_nerf.py:327-424: one pass over the epoch's rays in batches of args.batch_size; per batch every cascade level
+    draws its depths (level 0: perturbed uniform fg steps up to the unit sphere + perturbed uniform inverse-depth bg steps;
+    finer levels: sample_pdf on the previous level's inner weights, merged and sorted), renders, and takes an Adam step on
+    img2mse.  Returns the last level's colours of every ray [n, 3] on the host (what adjust_tree_multiThread consumes)."""
+    dev = models['net_0'].nerf_net.flat.device
+    n_total = rays_o.shape[0]
+    collect = []
+    train_step.last_log = log = OrderedDict()
+    for b0 in range(0, n_total, args.batch_size):
+        ray_o = rays_o[b0:b0 + args.batch_size].to(dev).float().contiguous()
+        ray_d = rays_d[b0:b0 + args.batch_size].to(dev).float().contiguous()
+        rgb_gt = target_rgb[b0:b0 + args.batch_size].to(dev).float()
+        fg_far = intersect_sphere(ray_o, ray_d)
+        fg_near = 1e-4 * torch.ones_like(ray_d[..., 0])
+        ret = fg_depth = bg_depth = None
+        for m in range(models['cascade_level']):
+            net, optim = models['net_{}'.format(m)], models['optim_{}'.format(m)]
+            N = models['cascade_samples'][m]
+            if m == 0:
+                step = (fg_far - fg_near) / (N - 1)
+                fg_depth = perturb_samples(torch.stack([fg_near + i * step for i in range(N)], dim=-1))
+                bg_depth = perturb_samples(torch.linspace(0., 1., N, device=dev).expand(ray_d.shape[0], N).contiguous())
+            else:
+                fg_new = sample_pdf(.5 * (fg_depth[..., 1:] + fg_depth[..., :-1]), ret['fg_weights'].detach()[..., 1:-1], N)
+                fg_depth, _ = torch.sort(torch.cat((fg_depth, fg_new), dim=-1))
+                bg_new = sample_pdf(.5 * (bg_depth[..., 1:] + bg_depth[..., :-1]), ret['bg_weights'].detach()[..., 1:-1], N)
+                bg_depth, _ = torch.sort(torch.cat((bg_depth, bg_new), dim=-1))
+            optim.zero_grad()
+            ret = net(ray_o, ray_d, fg_far, fg_depth, bg_depth, img_name=None)
+            loss = torch.mean((ret['rgb'] - rgb_gt) ** 2)
+            loss.backward()
+            optim.step()
+            log['level_{}/loss'.format(m)] = loss.detach()
+        collect.append(ret['rgb'].detach().cpu())
+    return torch.cat(collect, 0)
+
+
+def ddp_train_nerf(args, ray_samplers, log=print, device='cuda', stop_after=None):
+    """The epoch loop of ddp_train_nerf.py:187-324 on in-memory ray samplers (the directory reader is data_loader_split.py):
+    quadtree manager with the MEAN split criterion, per epoch variance-weighted picks (prob=True, rand=args.randSamp_perc;
+    the last epoch uniform over every pixel), train_step, subdivision every args.subdivide_every epochs except the last two,
+    `model_{epoch:04d}.pth` after every epoch.  Returns (models, treeManager, per-epoch records)."""
+    import os
+    os.makedirs(os.path.join(args.basedir, args.expname), exist_ok=True)
+    start, models = create_nerf(0, args, device=device)
+    tree = QuadTreeManager(ray_samplers, mseThres=0.0, max_depth=args.init_level, device=device)
+    records = []
+    for epoch_id in range(start + 1, args.n_epoch + 1):
+        if stop_after is not None and epoch_id > stop_after:
+            break
+        last = epoch_id == args.n_epoch
+        if last:
+            tree.epoch_size = tree.n_images * tree.h * tree.w
+            rays_o, rays_d, target = tree.gen_rays_v3_multiThread(down_scale=args.rays_downscale, prob=False, last_epoch=True)
+        else:
+            rays_o, rays_d, target = tree.gen_rays_v3_multiThread(down_scale=args.rays_downscale, prob=True, rand=args.randSamp_perc,
+                                                                  last_epoch=False)
+        leaves_before = sum(tree.num_leaves(i) for i in range(tree.n_images))
+        pred = train_step(models, rays_o, rays_d, target, args)
+        if epoch_id % args.subdivide_every == 0 and epoch_id < args.n_epoch - 1:
+            tree.adjust_tree_multiThread(target.cpu(), pred, thres=args.subdivide_thres)
+        save_models(models, os.path.join(args.basedir, args.expname, 'model_{:04d}.pth'.format(epoch_id)))
+        mse = float(torch.mean((pred - target.cpu()) ** 2))
+        records.append({'epoch': epoch_id, 'rays': int(rays_o.shape[0]), 'mse': mse, 'leaves_before': leaves_before,
+                        'leaves_after': sum(tree.num_leaves(i) for i in range(tree.n_images)), 'cur_level': tree.cur_level})
+        log('epoch {}: {} rays, mse {:.5f}, leaves {} -> {}'.format(epoch_id, rays_o.shape[0], mse, leaves_before,
+                                                                    records[-1]['leaves_after']))
+    return models, tree, records

@@ -482,6 +482,43 @@ def pp_sample_pdf_merge(z, weights, Ni, det=False, u=None, seed=0):
     return z_out, z_samples
 
 
+def pp_perturb_samples(z, t_rand=None, seed=0):
+    """perturb_samples (ddp_train_nerf.py:72-81) on [n,S] sorted depths."""
+    require_gpu(z, t_rand)
+    z = _f32(z)
+    n, S = z.shape
+    out = torch.empty_like(z)
+    if t_rand is not None:
+        t_rand = _f32(t_rand)
+        assert t_rand.shape == z.shape
+    check(lib().fastnerf_pp_perturb_samples(n, S, ptr(z), ptr(t_rand), int(seed), ptr(out), stream()), 'fastnerf_pp_perturb_samples')
+    return out
+
+
+def pp_sample_pdf(bins, weights, Ni, det=False, u=None, seed=0):
+    """nerf++ sample_pdf (ddp_train_nerf.py:84-133): bins [n,M], weights [n,M-1] -> [n,Ni]."""
+    require_gpu(bins, weights, u)
+    n, M = bins.shape
+    out = torch.empty(n, Ni, device=bins.device, dtype=torch.float32)
+    if u is not None:
+        u = _f32(u)
+    check(lib().fastnerf_pp_sample_pdf(n, M, Ni, ptr(_f32(bins)), ptr(_f32(weights)), int(bool(det)), ptr(u), int(seed), ptr(out),
+                                       stream()), 'fastnerf_pp_sample_pdf')
+    return out
+
+
+def pp_depth2pts_outside(ray_o, ray_d, depth):
+    """depth2pts_outside (ddp_model.py:16-45): ray_o / ray_d [n,3], depth [n,S] -> (pts [n,S,4], depth_real [n,S])."""
+    require_gpu(ray_o, ray_d, depth)
+    depth = _f32(depth)
+    n, S = depth.shape
+    pts = torch.empty(n, S, 4, device=depth.device, dtype=torch.float32)
+    dr = torch.empty(n, S, device=depth.device, dtype=torch.float32)
+    check(lib().fastnerf_pp_depth2pts_outside(n, S, ptr(_f32(ray_o)), ptr(_f32(ray_d)), ptr(depth), ptr(pts), ptr(dr), stream()),
+          'fastnerf_pp_depth2pts_outside')
+    return pts, dr
+
+
 def pp_composite_fwd(part, raw, z, rays11, fg_far=None):
     require_gpu(raw, z, rays11, fg_far)
     n, S = z.shape

@@ -211,6 +211,17 @@ int fastnerf_pp_fg_depths(int64_t n, int S, float near, const float* fg_far, int
 /* nerf++ sample_pdf + sort-merge (ddp_train_nerf.py:84-133, 369-382). */
 int fastnerf_pp_sample_pdf_merge(int64_t n, int S, int Ni, const float* z, const float* weights, int det,
                                  const float* u, uint64_t seed, float* z_out, float* z_samples, fn_stream_t stream);
+/* perturb_samples (ddp_train_nerf.py:72-81): z_out = lower + (upper - lower) * u over the mid-point intervals of the sorted
+ * depths z_in [n,S]; t_rand [n,S] injected or NULL (Philox(seed)).  z_out must not alias z_in. */
+int fastnerf_pp_perturb_samples(int64_t n, int S, const float* z_in, const float* t_rand, uint64_t seed, float* z_out,
+                                fn_stream_t stream);
+/* stand-alone nerf++ sample_pdf (ddp_train_nerf.py:84-133): bins [n,M], weights [n,M-1] -> samples [n,Ni]. */
+int fastnerf_pp_sample_pdf(int64_t n, int M, int Ni, const float* bins, const float* weights, int det, const float* u,
+                           uint64_t seed, float* samples, fn_stream_t stream);
+/* depth2pts_outside (ddp_model.py:16-45): ray_o / ray_d [n,3], depth [n,S] (inverse distance to the sphere origin) ->
+ * pts [n,S,4] = (x', y', z', 1/r), depth_real [n,S] (may be NULL). */
+int fastnerf_pp_depth2pts_outside(int64_t n, int S, const float* ray_o, const float* ray_d, const float* depth, float* pts,
+                                  float* depth_real, fn_stream_t stream);
 /* fg (part 0) / bg (part 1) compositing of NerfNet.forward (ddp_model.py:97-135) and its backward.
  * raw is the MLP output in network order (bg: far->near); z is always stored near->far.
  * fwd outputs: rgb_map [n,3], weights [n,S], depth [n] (may be NULL), lambda [n] (part 0 only).

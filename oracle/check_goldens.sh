@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 D=$(mktemp -d /tmp/goldens.XXXXXX)
 export FASTNERF_GOLDEN_OUT="$D"
 for g in make_golden make_golden_pp make_golden_pp_render make_golden_ssim make_golden_loaders make_golden_treepkl \
-         make_golden_pp_loader make_golden_render_path make_golden_noview make_golden_prob; do
+         make_golden_pp_loader make_golden_render_path make_golden_noview make_golden_prob make_golden_pp_ckpt; do
   python oracle/$g.py > "$D/$g.log" 2>&1 || { echo "FAILED $g (see $D/$g.log)"; exit 1; }
 done
 python - "$D" <<'PY'
