@@ -136,6 +136,10 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // bf16(a)
 #define X6_PRIO 1   // s_setprio level of a wave inside the six-product k-loops (0: none)
 #endif
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef X6_ABL_NOSPLIT   // timing-only ablation: no split arithmetic
+  h = __float_as_uint(x0); m = __float_as_uint(x1); l = h ^ m;
+  return;
+#endif
 #if X6_DOT2
   // (-1, 0) and (0, -1) as bf16 pairs, through opaque scalar moves: handed the constant vectors, hipcc (ROCm 7.2) encodes the
   // first one as the inline operand -1.0, which this instruction does not read as a bf16 pair (wrong results on gfx950)
@@ -462,6 +466,19 @@ __device__ __forceinline__ void gemm_seg6(f32x16 (&acc)[2][NT], const float* __r
   float4 a0[2][2], a1[2][2];
   uint4 b0[NT][3], b1[NT][3];
   load_b(b0, 0); load_a(a0, 0);
+#ifdef X6_ABL   // timing-only ablation builds (wrong results): 1 = no weight loads in the loop, 2 = no LDS reads in the loop, 3 = both
+  load_b(b1, 1); load_a(a1, 1);
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks += 2) {
+    if (!(X6_ABL & 1)) load_b(b1, ks + 1);
+    if (!(X6_ABL & 2)) load_a(a1, ks + 1);
+    mfma6<NT>(acc, a0, b0);
+    if (ks + 2 < nks) { if (!(X6_ABL & 1)) load_b(b0, ks + 2); if (!(X6_ABL & 2)) load_a(a0, ks + 2); } else side_copy();
+    mfma6<NT>(acc, a1, b1);
+    asm volatile("" : "+v"(a0[0][0].x), "+v"(a1[0][0].x), "+v"(b0[0][0].x), "+v"(b1[0][0].x));
+  }
+  return;
+#endif
 #if X6_PRIO
   __builtin_amdgcn_s_setprio(X6_PRIO);
 #endif
