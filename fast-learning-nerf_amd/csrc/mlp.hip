@@ -285,6 +285,7 @@ __device__ __forceinline__ int eidx(int m, int k) { return m * 64 + ((((k >> 2) 
 // streaming (non-temporal) 16-byte store: saved activations are written once and read much later,
 // they must not displace the 2.4 MB of weights every CU re-reads from its XCD's 4 MB L2
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_nt(float* p, const float4& v) {
   f32x4v t = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p));
@@ -1288,6 +1289,250 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
   if (RANK1 && tid < KI) partial_r[(int64_t)blockIdx.x * KI + tid] = rsum;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MM_X6 dW.  On this chip a SIMD issues NOTHING VALU-class while one of its waves streams v_mfma_f32_32x32x16_bf16 back to back
+// (tools/micro/coexec_split.hip, profiles/r03_mfma_valu_exclusion.md): the partner wave's VALU work does not hide under the MFMAs,
+// it adds to them; only LDS / memory latency overlaps.  The synchronous stage of mlp_bwd_dw_kernel (global -> registers -> fp32 LDS
+// -> barrier, then every wave gathers and splits the fragments it multiplies) split every dY tile in the WI waves that share it
+// and every X tile in WO waves -- three quarters of that arithmetic was redundant, and all of it was serial with the MFMAs
+// (51 % matrix-pipe busy, profiles/r03_sq_counters.md).  Here
+//   * a k-step is 16 points; its (NO + KI) / 32 operand tiles are split ONCE, each by one wave: a lane loads its 8 consecutive
+//     points of a channel straight from global memory (32 lanes = one 128-byte line per point) into registers TWO k-steps ahead
+//     (counted vmcnt waits: no control flow between a load and its use), splits them (split3_frag) and stores the three bf16
+//     pieces as fragment-ordered 1 KiB planes into the split buffer S; the bias column sums / the rank-1 row come from the same
+//     registers;
+//   * S is double-buffered (2 x 48 KiB for the 256 x 256 jobs): k-step q + 1 is split after k-step q has been multiplied, ONE
+//     barrier per k-step; a wave's MFMA operands are three ds_read_b128 per tile;
+//   * whole k-steps address with a wave-uniform base + immediates (no per-lane address arithmetic); the k-steps that touch the
+//     end of the workgroup's row range clamp their rows and zero them when they are split.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
+mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restrict__ X,
+                   const float* __restrict__ draw, float* __restrict__ partial_w, float* __restrict__ partial_b,
+                   float* __restrict__ partial_r, const int* __restrict__ live_idx, const int* __restrict__ live_cnt) {
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
+  constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  constexpr int CTO = WO * TO, CTI = WI * TI, NTILE = CTO + CTI;
+  constexpr int NW = WO * WI;
+  constexpr int TPW = (NTILE + NW - 1) / NW;         // tiles a wave splits per k-step
+  extern __shared__ __attribute__((aligned(16))) uint4 S6[];   // [2][tile][piece h | m | l][lane]
+  float* const DA = reinterpret_cast<float*>(S6 + 2 * NTILE * 192);   // RANK1: dalpha of the 16 points of a k-step, [2][16]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wo = wave / WI, wi = wave % WI;
+  const int64_t nq_all = (P + 15) / 16;
+  const int64_t per = (nq_all + gridDim.x - 1) / gridDim.x;
+  const int64_t q0 = blockIdx.x * per;
+  int64_t q1 = q0 + per;
+  if (q1 > nq_all) q1 = nq_all;
+  const int nq = (int)(q1 - q0);
+  int64_t Pend = q1 * 16;                             // rows this workgroup may read
+  if (Pend > P) Pend = P;
+
+  f32x16 acc[TO][TI];
+#pragma unroll
+  for (int a = 0; a < TO; ++a)
+#pragma unroll
+    for (int b = 0; b < TI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float ssum[TPW];   // side sums of the tiles THIS wave splits: bias column sums (dY tiles) / rank-1 row (X tiles)
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) ssum[k] = 0.f;
+
+  // the tiles this wave splits: tile t = k * NW + wave; t < CTO: channels t*32.. of dY, else channels (t - CTO)*32.. of X.
+  // Rows are counted from the workgroup's first row.
+  const float* tsrc[TPW];
+  bool tisy[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k) {
+    const int t = k * NW + wave;
+    tisy[k] = t < CTO;
+    tsrc[k] = tisy[k] ? dY + q0 * (16 * NO) + t * 32 : X + q0 * (16 * KI) + (t - CTO) * 32;
+  }
+  const int relmax = (int)(Pend - q0 * 16) - 1;   // last row of this workgroup (nq > 0: >= 0)
+  const int col = lane & 31, half8 = (lane >> 5) * 8;
+  const unsigned boffy = (unsigned)(half8 * NO + col) * 4u, boffx = (unsigned)(half8 * KI + col) * 4u;   // byte offsets of row 0
+  struct Raw { float v[TPW][8]; };
+  auto ldb = [](const float* base, unsigned byte_off) __attribute__((always_inline)) -> float {   // uniform base + 32-bit offset
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  // whole = std::true_type: every row of the k-step exists (straight-line code, counted waits); false_type: rows beyond the range
+  // are clamped to the last row here and zeroed in split_store (the last k-steps of a workgroup, and the two-ahead loads past them)
+  auto load_raw = [&](Raw& r, int st, auto whole) __attribute__((always_inline)) {   // st = k-step of this workgroup
+    if constexpr (decltype(whole)::value) {
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int t = k * NW + wave;
+        if (NTILE % NW == 0 || t < NTILE) {
+          if (tisy[k]) {
+            const float* b = tsrc[k] + (int64_t)st * (16 * NO);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffy + (unsigned)(e * NO * 4));
+          } else {
+            const float* b = tsrc[k] + (int64_t)st * (16 * KI);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffx + (unsigned)(e * KI * 4));
+          }
+        }
+      }
+    } else {
+      unsigned row[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int rr = st * 16 + half8 + e; row[e] = (unsigned)(rr < relmax ? rr : relmax); }
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int t = k * NW + wave;
+        if (NTILE % NW == 0 || t < NTILE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(tsrc[k], (row[e] * (unsigned)(tisy[k] ? NO : KI) + (unsigned)col) * 4u);
+        }
+      }
+    }
+  };
+  // RANK1: d(loss)/d(sigma) = draw[p][3], one point per lane 0..15 of wave 0, staged through LDS one k-step ahead of the split that
+  // multiplies it.  Two dependent loads in live mode (row -> point -> draw), each issued one pair of k-steps ahead of its use.
+  const int* const li = live_idx ? live_idx : reinterpret_cast<const int*>(draw);   // (a valid address when there is no list)
+  auto load_ix = [&](int st) __attribute__((always_inline)) -> int64_t {
+    const int rr = st * 16 + (lane & 15);
+    const int64_t p = q0 * 16 + (rr < relmax ? rr : relmax);
+    const int64_t lv = li[p];
+    return live_idx ? lv : p;
+  };
+  auto split_store = [&](const Raw& r, int buf, int st, auto whole) __attribute__((always_inline)) {
+    const int nv = relmax + 1 - (st * 16 + half8);         // this lane's rows e < nv exist
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int t = k * NW + wave;
+      if (NTILE % NW == 0 || t < NTILE) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = r.v[k][e];
+        if constexpr (!decltype(whole)::value) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = e < nv ? v[e] : 0.f;
+        }
+        uint4 h, m, l;
+        split3_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
+        uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
+        d[0] = h; d[64] = m; d[128] = l;
+        if (BIAS && t < CTO) ssum[k] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        if (RANK1 && t >= CTO) {
+          const float4 d0 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8);
+          const float4 d1 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8 + 4);
+          const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssum[k] = fmaf(da[e], v[e], ssum[k]);
+        }
+      }
+    }
+  };
+  // six-product MFMAs of the k-step held by S[buf]; X tiles two at a time, product-major over the 2 x TO accumulators of the
+  // pair: consecutive MFMAs never target the same accumulator (a dependent MFMA waits for its predecessor's full latency)
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+    const uint4* Sb = S6 + buf * NTILE * 192 + lane;
+    uint4 a[TO][3];
+#pragma unroll
+    for (int i = 0; i < TO; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[i][pl] = Sb[((wo * TO + i) * 3 + pl) * 64];
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int JP = TI >= 2 ? 2 : 1;
+#pragma unroll
+    for (int j0 = 0; j0 < TI; j0 += JP) {
+      uint4 b[JP][3];
+#pragma unroll
+      for (int jj = 0; jj < JP; ++jj)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          if (j0 + jj < TI) b[jj][pl] = Sb[((CTO + wi * TI + j0 + jj) * 3 + pl) * 64];
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int jj = 0; jj < JP; ++jj)
+#pragma unroll
+          for (int i = 0; i < TO; ++i)
+            if (j0 + jj < TI) acc[i][j0 + jj] = mfma_bf16(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
+    }
+  };
+  auto publish = [&]() __attribute__((always_inline)) {   // S pieces written / fragments read: hand the buffers over
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  if (nq > 0) {
+    // k-steps in pairs (S[0] / registers r0 hold the even ones); a trailing odd k-step multiplies a stage of zeros
+    constexpr std::true_type WHOLE{};
+    constexpr std::false_type ANY{};
+    Raw r0, r1;
+    load_raw(r0, 0, ANY);
+    load_raw(r1, 1, ANY);
+    // RANK1, wave 0, lanes 0..15: dalpha of the k-steps 2, 4, ... / 3, 5, ... on their way to DA, and the points after them
+    float dr0 = 0.f, dr1 = 0.f;
+    int64_t ix0 = 0, ix1 = 0;
+    const bool da_lane = RANK1 && wave == 0 && lane < 16;
+    if (da_lane) {
+      DA[lane] = draw[load_ix(0) * 4 + 3];
+      DA[16 + lane] = draw[load_ix(1) * 4 + 3];
+      dr0 = draw[load_ix(2) * 4 + 3];
+      dr1 = draw[load_ix(3) * 4 + 3];
+      ix0 = load_ix(4);
+      ix1 = load_ix(5);
+    }
+    if (RANK1) publish();
+    split_store(r0, 0, 0, ANY);
+    load_raw(r0, 2, ANY);
+    publish();
+    auto pair = [&](int d, auto whole) __attribute__((always_inline)) {
+      const int st = 2 * d;
+      if (da_lane) { DA[lane] = dr0; dr0 = draw[ix0 * 4 + 3]; ix0 = load_ix(st + 6); }
+      multiply(0);
+      split_store(r1, 1, st + 1, whole);
+      load_raw(r1, st + 3, whole);
+      publish();
+      if (da_lane) { DA[16 + lane] = dr1; dr1 = draw[ix1 * 4 + 3]; ix1 = load_ix(st + 7); }
+      multiply(1);
+      split_store(r0, 0, st + 2, whole);
+      load_raw(r0, st + 4, whole);
+      publish();
+    };
+    const int n2 = (nq + 1) / 2;
+    const int nwhole = (relmax + 1) / 16;                     // k-steps 0 .. nwhole - 1 have all their rows
+    int dmain = nwhole >= 5 ? (nwhole - 3) / 2 : 0;           // pairs whose k-steps up to 2 d + 4 are whole
+    if (dmain > n2) dmain = n2;
+#pragma unroll 1
+    for (int d = 0; d < dmain; ++d) pair(d, WHOLE);
+#pragma unroll 1
+    for (int d = dmain; d < n2; ++d) pair(d, ANY);
+  }
+  // write partials (zeros from workgroups without points: reduce_all sums every workgroup's region)
+  float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
+#pragma unroll
+  for (int i = 0; i < TO; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (wo * TO + i) * 32 + crow(r, lane);
+        const int c = (wi * TI + j) * 32 + (lane & 31);
+        pw[(int64_t)o * KI + c] = acc[i][j][r];
+      }
+  if (BIAS || RANK1) {
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int t = k * NW + wave;
+      if (NTILE % NW == 0 || t < NTILE) {
+        const float sv = ssum[k] + __shfl_xor(ssum[k], 32, 64);
+        if (lane < 32) {
+          if (BIAS && t < CTO) partial_b[(int64_t)blockIdx.x * NO + t * 32 + lane] = sv;
+          if (RANK1 && t >= CTO) partial_r[(int64_t)blockIdx.x * KI + (t - CTO) * 32 + lane] = sv;
+        }
+      }
+    }
+  }
+}
+
 // rgb head + alpha bias gradients (VALU reduction over points): per-workgroup partials
 //   out[wg][0..383] = dWr[c][k], [384..386] = dbr[c], [387] = dba
 __global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float* __restrict__ draw,
@@ -1390,6 +1635,24 @@ template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32
 static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* base,
                      int nwg, hipStream_t st, const int* live_idx = nullptr, const int* live_cnt = nullptr) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
+  float* pw = base;
+  float* pb = base + (int64_t)nwg * NO * KI;
+  float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
+#ifndef X6_DW_SYNC   // (-DX6_DW_SYNC=1: the synchronous-stage kernel for MM_X6 too, for A/B timing)
+  if constexpr (MM == MM_X6) {
+    if (ldy != NO || ldx != KI) { fn::set_error("launch_dw: the bf16x6 dW kernel needs ld == width"); return -1; }
+    constexpr int lds6 = 2 * (WO * TO + WI * TI) * 3 * 1024 + 128;
+    auto kern6 = mlp_bwd_dw6_kernel<WO, WI, TO, TI, BIAS, RANK1>;
+    static bool attr6 = false;
+    if (!attr6) {
+      FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern6), hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+      attr6 = true;
+    }
+    hipLaunchKernelGGL(kern6, dim3(nwg), dim3(WO * WI * 64), lds6, st, P, dY, X, draw, pw, pb, pr, live_idx, live_cnt);
+    FN_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
   const size_t lds = 2 * STAGE * sizeof(float);
   auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1, MM>;
@@ -1398,9 +1661,6 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
     FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  float* pw = base;
-  float* pb = base + (int64_t)nwg * NO * KI;
-  float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr, live_idx, live_cnt);
   FN_LAUNCH_CHECK();
   return 0;
@@ -1454,8 +1714,9 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
   };
   // L0
-  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
-  else rc = launch_dw<4, 1, 2, 3, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
+  // (MM_X6: the narrow jobs as 8 / 12 waves of one X tile each -- one workgroup per CU, and a lone wave per SIMD hides nothing)
+  if (PEP == 64) rc = launch_dw<4, (MM == MM_X6 ? 2 : 1), 2, (MM == MM_X6 ? 1 : 2), true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
+  else rc = launch_dw<4, (MM == MM_X6 ? 3 : 1), 2, (MM == MM_X6 ? 1 : 3), true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
   if (rc) return rc;
   segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
   // L1..L7 (h part)
@@ -1464,8 +1725,8 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
   }
   // L5 pe part
-  if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
-  else rc = launch_dw<4, 1, 2, 3, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
+  if (PEP == 64) rc = launch_dw<4, (MM == MM_X6 ? 2 : 1), 2, (MM == MM_X6 ? 1 : 2), false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
+  else rc = launch_dw<4, (MM == MM_X6 ? 3 : 1), 2, (MM == MM_X6 ? 1 : 3), false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
   if (rc) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
