@@ -527,6 +527,26 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
 // C layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Epilogue addressing of an accumulator tile into H.  hidx(m, n) with m = wm*64 + mt*32 + crow(r, lane): the swizzle term m & 15 is
+// (r & 3) | (lane >> 5) << 2 | ((r >> 2) & 1) << 3 -- disjoint bit fields, so the XOR separates: eight column pointers per column
+// tile (j = (r & 3) + 4 * ((r >> 2) & 1)), computed once per epilogue, and everything else of the address is an immediate
+// (< 60 KiB): no per-value address arithmetic (it was 3 of the 5 VALU instructions per value, and VALU time is not hidden under
+// the partner wave's MFMAs: profiles/r03_mfma_valu_exclusion.md).
+template <int NT>
+__device__ __forceinline__ void h_cols(float* Hs, int wm, int wn, int lane, float* (&colp)[NT][8]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (wn * NT + nt) * 32 + (lane & 31);
+    float* const rowp = Hs + (wm * 64 + 4 * h) * 256 + (n & 3);
+    const int q = (n >> 2) ^ (4 * h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colp[nt][j] = rowp + ((q ^ (j & 3) ^ ((j >> 2) << 3)) << 2);
+  }
+}
+// the element (mt, r) of a column tile: &H[hidx(wm*64 + mt*32 + crow(r, lane), n)]
+#define H_AT(colp, nt, mt, r) ((colp)[nt][((r) & 3) + 4 * (((r) >> 2) & 1)][((mt) * 32 + ((r) & 3) + 8 * ((r) >> 2)) * 256])
+
 // forward epilogue: + bias, optional ReLU, write H (LDS) and optionally the saved activation.
 // When `mask_out` is given (training, ReLU layers) the sign pattern of every accumulator register
 // is recorded as one 64-bit ballot; ballot i = (nt*2+mt)*16 + r is kept by lane i and the wave
@@ -546,6 +566,8 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
                                              int valid, unsigned long long* __restrict__ mask_out = nullptr) {
   asm volatile("" : "+v"(lane));
   unsigned long long mymask = 0ull;
+  float* colp[NT][8];
+  h_cols<NT>(Hs, wm, wn, lane, colp);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (wn * NT + nt) * 32 + (lane & 31);
@@ -563,7 +585,7 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
           }
         }
         if (RELU) v = fmaxf(v, 0.f);
-        Hs[hidx(m, n)] = v;
+        H_AT(colp, nt, mt, r) = v;
         if (save != nullptr && m < valid) save[(unsigned)(m * ldsave + n)] = v;
       }
       __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
@@ -977,6 +999,8 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
                                             int valid) {
   asm volatile("" : "+v"(lane));
   const unsigned mlo = pre.mlo, mhi = pre.mhi;
+  float* colp[2][8];
+  h_cols<2>(Hs, wm, wn, lane, colp);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = (wn * 2 + nt) * 32 + (lane & 31);
@@ -995,7 +1019,7 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
           const unsigned word = (lane & 32) ? bhi : blo;
           v = ((word >> (lane & 31)) & 1u) ? v : 0.f;
         }
-        Hs[hidx(m, n)] = v;
+        H_AT(colp, nt, mt, r) = v;
         if (dsave != nullptr && m < valid) dsave[(unsigned)(m * 256 + n)] = v;
       }
       __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
