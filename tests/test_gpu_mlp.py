@@ -178,6 +178,64 @@ def test_mlp_backward_vs_autograd(fn, weights, math_mode):
     assert (grads2.cpu() - 2 * grads).abs().max() < 1e-4 * max(1.0, grads.abs().max().item())
 
 
+@pytest.mark.parametrize('n,S', [(1, 1), (1, 16), (1, 17), (17, 241), (241, 291), (1367, 193)])
+def test_mlp_backward_ragged_point_counts(fn, weights, math_mode, n, S):
+    """The gradient kernels at point counts around their staging granularity (16-point k-steps of the bf16x6 dW kernel, 128-point
+    tiles) and at counts large enough that every workgroup runs its steady-state loop (1367 x 193 = 263 831 points: 65 k-steps per
+    workgroup, the last one partial).
+      * a handful of points: the same gradients as the fp32-MFMA mode (pinned against autograd by test_mlp_backward_vs_autograd);
+      * many points: ADDITIVITY over a split of the rays, G(all) = G(first part) + G(rest), which only the grouping of the fp32
+        partial sums may break (a point's forward, and with it every ReLU decision, does not depend on its batch).  Against the
+        other math mode only a loose bound holds there: among 5e8 pre-activations a few dozen sit within rounding of zero, and a
+        ReLU that flips between two roundings moves a gradient entry by 1e-3 of the tensor's maximum."""
+    gen = torch.Generator().manual_seed(1234 + n)
+    ro = (torch.randn(n, 3, generator=gen) * 0.5).cuda()
+    rd = torch.randn(n, 3, generator=gen).cuda()
+    rb = fn.ops.pack_rays(ro, rd, 2.0, 6.0)
+    z = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, -1).values.cuda()
+    cot = torch.randn(n, S, 4, generator=gen).cuda()
+    flat = flat_of(weights).cuda()
+
+    def grads_in(mode, sl=slice(None)):
+        fn.ops.set_math(mode)
+        try:
+            r, zz, c = rb[sl].contiguous(), z[sl].contiguous(), cot[sl].contiguous()
+            P = r.shape[0] * S
+            pf, pb = fn.ops.mlp_pack(flat)
+            act = torch.empty(fn.ops.act_floats(P)).cuda()
+            fn.ops.mlp_fwd(r, zz, flat, pf, act=act)
+            dact = torch.empty(fn.ops.dact_floats(P)).cuda()
+            partial = torch.empty(fn.ops.mlp_bwd_partial_floats()).cuda()
+            g = torch.full((fn.ops.NET_PARAMS,), float('nan')).cuda()
+            fn.ops.mlp_bwd(c, act, flat, pb, dact, partial, g)
+            return g.double().cpu()
+        finally:
+            fn.ops.set_math(math_mode)
+
+    def compare(got, ref, tol, what):
+        off = 0
+        for name, shape in O.nerf_param_shapes():
+            k = int(np.prod(shape))
+            a, b = got[off:off + k], ref[off:off + k]
+            scale = max(1e-6, b.abs().max().item())
+            assert (a - b).abs().max().item() <= tol * scale, (what, name, n, S, (a - b).abs().max().item(), scale)
+            off += k
+
+    got = grads_in(math_mode)
+    assert torch.isfinite(got).all()
+    if n * S <= 64:
+        if math_mode != 'fp32':
+            compare(got, grads_in('fp32'), 2e-5 if math_mode == 'bf16x6' else 2e-2, 'vs fp32-MFMA')
+        return
+    cut = n // 2 + 1
+    parts = grads_in(math_mode, slice(0, cut)) + grads_in(math_mode, slice(cut, n))
+    compare(got, parts, 5e-6 if math_mode != 'bf16x3' else 2e-5, 'additivity')
+    if math_mode != 'fp32':
+        ref = grads_in('fp32')
+        rel = ((got - ref).norm() / ref.norm()).item()
+        assert rel < (2e-3 if math_mode == 'bf16x6' else 2e-2), ('vs fp32-MFMA, relative L2', rel)
+
+
 def test_run_network_signature(fn, weights):
     net = fn.model.NeRF()
     net.load_state_dict({'module.' + k: v for k, v in weights.items()})
