@@ -560,12 +560,13 @@ __device__ __forceinline__ void load_bias(float (&bv)[NT], const float* __restri
 
 // bias values are loaded by the caller BEFORE the k-loop (load_bias) so that no global load waits
 // behind the activation stores issued at the end of the loop
-template <int NT, bool RELU>
+template <int NT, bool RELU, bool MASKS = false>
 __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const float (&bias_v)[NT], float* Hs,
                                              int wm, int wn, int lane, float* __restrict__ save, int ldsave,
                                              int valid, unsigned long long* __restrict__ mask_out = nullptr) {
   asm volatile("" : "+v"(lane));
-  unsigned long long mymask = 0ull;
+  int mlo = 0, mhi = 0;   // this lane's ballot word (v_writelane: no per-value branch, no select)
+  constexpr bool want_mask = RELU && NT == 2 && MASKS;
   float* colp[NT][8];
   h_cols<NT>(Hs, wm, wn, lane, colp);
 #pragma unroll
@@ -578,13 +579,17 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
       for (int r = 0; r < 16; ++r) {
         const int m = wm * 64 + mt * 32 + crow(r, lane);
         float v = acc[mt][nt][r] + bv;
+        const bool pos = v > 0.f;
         if (RELU && NT == 2) {
-          if (mask_out != nullptr) {
-            const unsigned long long bm = __ballot(v > 0.f);
-            if (lane == (nt * 2 + mt) * 16 + r) mymask = bm;
+          if (want_mask) {   // the compare's lane mask IS the ballot; lane (nt*2+mt)*16 + r keeps it
+            const unsigned long long bm = __ballot(pos);
+            // (s_nop: a v_writelane issued right behind the v_cmp that wrote its scalar source still reads the OLD value --
+            //  measured: the low words came out one value late; the hazard recogniser does not look inside inline asm)
+            asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                : "+v"(mlo), "+v"(mhi) : "s"((unsigned)bm), "s"((unsigned)(bm >> 32)), "n"((nt * 2 + mt) * 16 + r));
           }
         }
-        if (RELU) v = fmaxf(v, 0.f);
+        if (RELU) v = pos ? v : 0.f;   // (one select on the compare the mask needs anyway; fmaxf is two v_max: it canonicalises first)
         H_AT(colp, nt, mt, r) = v;
         if (save != nullptr && m < valid) save[(unsigned)(m * ldsave + n)] = v;
       }
@@ -592,7 +597,7 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
     }
   }
   if (RELU && NT == 2) {
-    if (mask_out != nullptr) mask_out[lane] = mymask;
+    if (want_mask) mask_out[lane] = ((unsigned long long)(unsigned)mhi << 32) | (unsigned long long)(unsigned)mlo;
   }
 }
 
@@ -756,8 +761,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       gemm<MM, 2, 2>(acc, X2, 0, 4, wblock<MM>(packed, lay.PF[0]), PEP / 8, 8, wn * 2, wm, lane, dbg);
       __syncthreads();   // X2 lives in H: everyone must be done with it before H is written
     }
-    epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
-                          SAVE ? maskw + (0 * NWAVES + wave) * 64 : nullptr);
+    epilogue_fwd<2, true, SAVE>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
+                                SAVE ? maskw + (0 * NWAVES + wave) * 64 : nullptr);
     __syncthreads();
     // ---- L1..L7 -----------------------------------------------------------------------
 #pragma unroll 1
@@ -783,8 +788,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         gemm<MM, 2, 0>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
       }
       __syncthreads();  // every wave has finished reading H
-      epilogue_fwd<2, true>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
-                            SAVE ? maskw + (l * NWAVES + wave) * 64 : nullptr);
+      epilogue_fwd<2, true, SAVE>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
+                                  SAVE ? maskw + (l * NWAVES + wave) * 64 : nullptr);
       __syncthreads();
     }
     // ---- alpha head (VALU) + view-direction encoding -> Es ---------------------------

@@ -2,6 +2,8 @@
 
 PyTorch is plumbing here: it owns device memory and the stream; every op calls
 straight into libfastnerf.so with raw pointers.  No op has a CPU fallback."""
+import weakref
+
 import numpy as np
 import torch
 
@@ -59,11 +61,20 @@ _PACK_TAGS = {}
 
 def _tag_packed(t, tag):
     t._fn_math = tag
-    _PACK_TAGS[(t.device.index, t.data_ptr())] = tag
+    key = (t.device.index, t.data_ptr(), t.numel())
+    _PACK_TAGS[key] = tag
+    # the entry lives as long as the tensor object mlp_pack handed out: a freed block that the caching allocator hands to an
+    # unrelated tensor must not inherit the tag
+    weakref.finalize(t, _drop_tag, key, tag)
+
+
+def _drop_tag(key, tag):
+    if _PACK_TAGS.get(key) == tag:
+        del _PACK_TAGS[key]
 
 
 def packed_tag(t):
-    return getattr(t, '_fn_math', None) or _PACK_TAGS.get((t.device.index, t.data_ptr()))
+    return getattr(t, '_fn_math', None) or _PACK_TAGS.get((t.device.index, t.data_ptr(), t.numel()))
 
 
 def _split(kind):

@@ -83,3 +83,20 @@ def test_mlp_fwd_op_checks_the_math_mode_and_r2o_backward_refuses_other_gradient
     rgb, disp, acc, w, depth = torch.ops.fastnerf.raw2outputs(raw, z, r11, None, False)
     with pytest.raises(NotImplementedError):
         (rgb.sum() + depth.sum()).backward()
+
+
+def test_packed_tag_does_not_outlive_the_packed_tensor():
+    """A block the caching allocator hands to another tensor after the packed weights died carries no math tag."""
+    import gc
+    import fastnerf
+    from fastnerf import ops
+    torch.manual_seed(0)
+    flat = fastnerf.model.NeRF().flat
+    pf, pb = ops.mlp_pack(flat)
+    key = (pf.device.index, pf.data_ptr(), pf.numel())
+    assert ops.packed_tag(pf) == ops.get_math() and key in ops._PACK_TAGS
+    del pf, pb
+    gc.collect()
+    assert key not in ops._PACK_TAGS
+    again = torch.empty(key[2], device='cuda')          # most likely the very block that was just freed
+    assert ops.packed_tag(again) is None
