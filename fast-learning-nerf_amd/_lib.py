@@ -109,6 +109,13 @@ SIGNATURES = {
     'fastnerf_mlp_x6_bwd_live': (I, [I, L, I, P, P, P, P, P, P, P, P, P, P]),
     'fastnerf_step_args_size': (L, []),
     'fastnerf_train_step': (I, [C.POINTER(StepArgs), I, P]),
+    'fastnerf_comm_unique_id': (I, [C.c_char_p]),
+    'fastnerf_comm_init': (I, [C.POINTER(P), C.c_char_p, I, I]),
+    'fastnerf_comm_destroy': (I, [P]),
+    'fastnerf_allreduce_grads': (I, [P, P, L, C.c_float, P]),
+    'fastnerf_allreduce_leaf_table': (I, [P, P, L, P]),
+    'fastnerf_leaf_table_reset': (I, [P, L, P]),
+    'fastnerf_leaf_table_read': (I, [P, P, L, P]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfastnerf.so')
-SOURCES = ['rays.hip', 'composite.hip', 'train.hip', 'mlp.hip', 'mlp_bf16.hip', 'tree.cpp', 'render.cpp']
+SOURCES = ['rays.hip', 'composite.hip', 'train.hip', 'mlp.hip', 'mlp_bf16.hip', 'tree.cpp', 'render.cpp', 'comm.cpp']
 # -fno-slp-vectorize: with SLP on, hipcc (ROCm 7.2) packs the epilogues' scalar fp32 adds into v_pk_add_f32; on
 # gfx950 the split-bf16 forward then produced sporadic wrong sums (bias dropped in lanes 48..63 of one register,
 # ~0.1% of points, timing dependent) -- and packed fp32 VALU next to MFMAs is slower anyway.

@@ -432,6 +432,23 @@ def sample_pdf(bins, weights, Ni, det=False, u=None, seed=0):
     return out
 
 
+def leaf_table_reset(table):
+    """Zero the per-(image, leaf) error table on the device (fastnerf_leaf_table_reset)."""
+    require_gpu(table)
+    assert table.dtype == torch.int32 and table.is_contiguous()
+    check(lib().fastnerf_leaf_table_reset(ptr(table), table.numel(), stream()), 'fastnerf_leaf_table_reset')
+    return table
+
+
+def leaf_table_read(table):
+    """The table as host floats (max |gt - pred| per leaf), waited for: what the split rule of tree.py:629-652 consumes."""
+    require_gpu(table)
+    assert table.dtype == torch.int32 and table.is_contiguous()
+    out = torch.empty(table.shape, dtype=torch.float32)
+    check(lib().fastnerf_leaf_table_read(ptr(table), out.data_ptr(), table.numel(), stream()), 'fastnerf_leaf_table_read')
+    return out
+
+
 def mse_leafmax(rgb, rgb0, target, grad_scale=1.0, want_grads=True, leaf_tag=None, max_leaves=0, table=None):
     require_gpu(rgb, rgb0, target, leaf_tag, table)
     rgb, target = _f32(rgb), _f32(target)

@@ -28,7 +28,85 @@ def init_from_env(device_type=None):
         # FASTNERF_DIST_BACKEND=gloo: plumbing tests of the multi-process path on a box with fewer GPUs than ranks
         backend = os.environ.get('FASTNERF_DIST_BACKEND', 'nccl' if use_cuda else 'gloo')
         dist.init_process_group(backend=backend, rank=rk, world_size=world)
+    _maybe_init_cabi(rk, world)
     return rk, world, local
+
+
+class CabiComm:
+    """One RCCL communicator behind the C ABI (csrc/comm.cpp: fastnerf_comm_* / fastnerf_allreduce_*): the exchange steps of
+    the data-parallel path for a host without torch.distributed.  Collectives are enqueued on a HIP stream, never waited for
+    on the host."""
+
+    def __init__(self, rank, world, comm_id):
+        from . import _lib
+        assert len(comm_id) == 128
+        self._lib = _lib
+        self.rank, self.world = int(rank), int(world)
+        h = _lib.P()
+        _lib.check(_lib.lib().fastnerf_comm_init(_lib.C.byref(h), comm_id, self.rank, self.world), 'fastnerf_comm_init')
+        self._h = h
+        self._side = None
+
+    @staticmethod
+    def unique_id():
+        from . import _lib
+        buf = _lib.C.create_string_buffer(128)
+        _lib.check(_lib.lib().fastnerf_comm_unique_id(buf), 'fastnerf_comm_unique_id')
+        return buf.raw
+
+    def all_reduce_sum(self, flat, scale=1.0, stream=None):
+        L = self._lib
+        L.require_gpu(flat)
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        st = L.stream() if stream is None else stream.cuda_stream
+        L.check(L.lib().fastnerf_allreduce_grads(self._h, L.ptr(flat), flat.numel(), float(scale), st), 'fastnerf_allreduce_grads')
+        return flat
+
+    def all_reduce_sum_async(self, flat, scale=1.0):
+        """The collective on a side stream behind everything enqueued on the current stream so far; .wait() orders the
+        current stream behind it (same contract as torch.distributed's async work handle)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        self.all_reduce_sum(flat, scale, stream=self._side)
+        flat.record_stream(self._side)
+        side = self._side
+
+        class _Work:
+            def wait(self_inner):
+                torch.cuda.current_stream().wait_stream(side)
+        return _Work()
+
+    def all_reduce_leaf_table(self, table_i32):
+        L = self._lib
+        L.require_gpu(table_i32)
+        assert table_i32.dtype == torch.int32 and table_i32.is_contiguous()
+        L.check(L.lib().fastnerf_allreduce_leaf_table(self._h, L.ptr(table_i32), table_i32.numel(), L.stream()),
+                'fastnerf_allreduce_leaf_table')
+        return table_i32
+
+    def destroy(self):
+        if self._h is not None:
+            self._lib.check(self._lib.lib().fastnerf_comm_destroy(self._h), 'fastnerf_comm_destroy')
+            self._h = None
+
+
+_CABI = None   # FASTNERF_COLLECTIVE=cabi: the collectives go through the C ABI instead of torch.distributed
+
+
+def _maybe_init_cabi(rk, world):
+    """torch.distributed only carries the 128-byte RCCL id from rank 0 to the others (any backend)."""
+    global _CABI
+    if _CABI is not None or os.environ.get('FASTNERF_COLLECTIVE', 'torch') != 'cabi' or not torch.cuda.is_available():
+        return
+    if world > 1:
+        box = [CabiComm.unique_id() if rk == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
+    else:
+        comm_id = CabiComm.unique_id()
+    _CABI = CabiComm(rk, world, comm_id)
 
 
 def world_size():
@@ -41,6 +119,8 @@ def rank():
 
 def all_reduce_sum(flat):
     if world_size() > 1:
+        if _CABI is not None and flat.is_cuda:
+            return _CABI.all_reduce_sum(flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
@@ -50,6 +130,8 @@ def all_reduce_sum_async(flat):
     the collective runs on the process group's own stream behind everything enqueued on the current stream so far, beside
     whatever the caller enqueues next; `wait_all` orders the current stream behind it."""
     if world_size() > 1:
+        if _CABI is not None and flat.is_cuda:
+            return _CABI.all_reduce_sum_async(flat)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     return None
 
@@ -64,6 +146,8 @@ def all_reduce_max_int(table_i32):
     """MAX over ranks of the leaf-error table stored as the int32 bit patterns of non-negative
     floats (monotone in the float value) -> exact and order independent."""
     if world_size() > 1:
+        if _CABI is not None and table_i32.is_cuda:
+            return _CABI.all_reduce_leaf_table(table_i32)
         dist.all_reduce(table_i32, op=dist.ReduceOp.MAX)
     return table_i32
 

@@ -379,6 +379,30 @@ typedef struct fn_step_args {
 int64_t fastnerf_step_args_size(void);              /* sizeof(fn_step_args): binding sanity check */
 int fastnerf_train_step(const fn_step_args* args, int phases, fn_stream_t stream);
 
+/* ---- exchange steps of the data-parallel path ---------------------------------------------------
+ * One process per GPU; every rank renders its shard of the ray batch end to end.  The reference's strategies for contrast:
+ * nn.DataParallel around the MLP (nerf-ours/run_nerf.py:70,82,90), torch DDP (nerf++-ours/ddp_train_nerf.py:150-184).
+ * A PyTorch host gets the same collectives from torch.distributed (backend "nccl" = RCCL; parallel.py, the default route);
+ * these entry points serve a host without it.  librccl is resolved at the first call, the library does not link against it.
+ *   fastnerf_comm_unique_id   rank 0: a fresh RCCL id (FASTNERF_COMM_ID_BYTES bytes) to hand to every rank out of band
+ *   fastnerf_comm_init        collective over all ranks, on the caller's current HIP device
+ *   fastnerf_allreduce_grads  in place SUM over ranks of the flat fp32 gradient buffer (or a slice of it: the fine net's half
+ *                             can go while the coarse net's backward runs on another stream), then * scale (1 / world for the
+ *                             global-batch mean of img2mse, run_nerf_helpers.py:9); enqueued on `stream`, no host sync
+ *   fastnerf_allreduce_leaf_table  in place MAX over ranks of the per-(image, leaf) table of fastnerf_mse_leafmax (uint32 bit
+ *                             patterns of non-negative floats: exact, order independent => identical on 1 or 8 GPUs)
+ *   fastnerf_leaf_table_reset / _read   zero the device table / copy it to the host as floats and wait for it (the split
+ *                             rule of tree.py:629-652 runs on the host: fastnerf_tree_adjust)                              */
+#define FASTNERF_COMM_ID_BYTES 128
+typedef struct fn_comm fn_comm; /* opaque: one RCCL communicator */
+int fastnerf_comm_unique_id(char* id);
+int fastnerf_comm_init(fn_comm** out, const char* id, int rank, int world);
+int fastnerf_comm_destroy(fn_comm* comm);
+int fastnerf_allreduce_grads(fn_comm* comm, float* grads, int64_t n, float scale, fn_stream_t stream);
+int fastnerf_allreduce_leaf_table(fn_comm* comm, uint32_t* table, int64_t n, fn_stream_t stream);
+int fastnerf_leaf_table_reset(uint32_t* table, int64_t n, fn_stream_t stream);
+int fastnerf_leaf_table_read(const uint32_t* table, float* host_out, int64_t n, fn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,6 +162,25 @@ def test_overlapped_allreduce_is_bit_identical_and_replicas_agree(tmp_path):
         assert torch.equal(res['1'][0][k], res['0'][0][k]), k       # overlapping changes no bit
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL refuses two ranks on one device: needs two GPUs')
+def test_collectives_through_the_c_abi_match_torch_distributed(tmp_path):
+    """FASTNERF_COLLECTIVE=cabi (csrc/comm.cpp: fastnerf_allreduce_grads on a side stream, fastnerf_allreduce_leaf_table) against the
+    default torch.distributed route: same parameters, Adam moments and first gradient, bit for bit, replicas identical."""
+    script = str(tmp_path / 'worker.py')
+    res = {}
+    for route in ('cabi', 'torch'):
+        out = str(tmp_path / ('%s_%%d.pt' % route))
+        with open(script, 'w') as f:
+            f.write(_SHARD_WORKER % {'root': ROOT, 'out': out})
+        _two_ranks(script, dict(os.environ, FASTNERF_COMPACT='0', FASTNERF_COLLECTIVE=route), 29557)
+        res[route] = [torch.load((out % 2) + '.rank%d' % r) for r in range(2)]
+        a, b = res[route]
+        for k in ('flat', 'm', 'v', 'grad0'):
+            assert torch.equal(a[k], b[k]), (route, k)
+    for k in ('flat', 'm', 'v', 'grad0'):
+        assert torch.equal(res['cabi'][0][k], res['torch'][0][k]), k
+
+
 def test_ranks_that_disagree_on_compaction_stay_identical(tmp_path):
     """Rank 0 runs the plain backward, rank 1 the compacted one (in production each rank's LivePolicy follows its own shard's live
     fraction): their gradient contributions differ in fp32 summation grouping, the all-reduced sum is the same tensor on

@@ -85,6 +85,7 @@ def test_mlp_fwd_op_checks_the_math_mode_and_r2o_backward_refuses_other_gradient
         (rgb.sum() + depth.sum()).backward()
 
 
+@pytest.mark.gpu
 def test_packed_tag_does_not_outlive_the_packed_tensor():
     """A block the caching allocator hands to another tensor after the packed weights died carries no math tag."""
     import gc
