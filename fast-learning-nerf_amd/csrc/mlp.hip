@@ -1324,7 +1324,7 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
 // it adds to them; only LDS / memory latency overlaps.  The synchronous stage of mlp_bwd_dw_kernel (global -> registers -> fp32 LDS
 // -> barrier, then every wave gathers and splits the fragments it multiplies) split every dY tile in the WI waves that share it
 // and every X tile in WO waves -- three quarters of that arithmetic was redundant, and all of it was serial with the MFMAs
-// (51 % matrix-pipe busy, profiles/r03_sq_counters.md).  Here
+// (51 % matrix-pipe busy; 66 % with this kernel, profiles/r03_sq_counters.md).  Here
 //   * a k-step is 16 points; its (NO + KI) / 32 operand tiles are split ONCE, each by one wave: a lane loads its 8 consecutive
 //     points of a channel straight from global memory (32 lanes = one 128-byte line per point) into registers TWO k-steps ahead
 //     (counted vmcnt waits: no control flow between a load and its use), splits them (split3_frag) and stores the three bf16
@@ -1660,6 +1660,9 @@ extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
   return dw_job_base(12, num_cus(), 96) + (int64_t)HEAD_MAX_WG * 388;   // sized for the widest layout
 }
 
+#ifndef X6_DW_SYNC
+#define X6_DW_SYNC 0
+#endif
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32>
 static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* base,
                      int nwg, hipStream_t st, const int* live_idx = nullptr, const int* live_cnt = nullptr) {
@@ -1667,8 +1670,7 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
   float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
-#ifndef X6_DW_SYNC   // (-DX6_DW_SYNC=1: the synchronous-stage kernel for MM_X6 too, for A/B timing)
-  if constexpr (MM == MM_X6) {
+  if constexpr (MM == MM_X6 && !X6_DW_SYNC) {
     if (ldy != NO || ldx != KI) { fn::set_error("launch_dw: the bf16x6 dW kernel needs ld == width"); return -1; }
     constexpr int lds6 = 2 * (WO * TO + WI * TI) * 3 * 1024 + 128;
     auto kern6 = mlp_bwd_dw6_kernel<WO, WI, TO, TI, BIAS, RANK1>;
@@ -1680,19 +1682,19 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
     hipLaunchKernelGGL(kern6, dim3(nwg), dim3(WO * WI * 64), lds6, st, P, dY, X, draw, pw, pb, pr, live_idx, live_cnt);
     FN_LAUNCH_CHECK();
     return 0;
+  } else {   // MM_F32 (and, in -DX6_DW_SYNC=1 builds, MM_X6 on the synchronous-stage kernel for A/B timing)
+    constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
+    const size_t lds = 2 * STAGE * sizeof(float);
+    auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1, MM>;
+    static bool attr = false;
+    if (!attr) {
+      FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr, live_idx, live_cnt);
+    FN_LAUNCH_CHECK();
+    return 0;
   }
-#endif
-  constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
-  const size_t lds = 2 * STAGE * sizeof(float);
-  auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1, MM>;
-  static bool attr = false;
-  if (!attr) {
-    FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(WO * WI * 64), lds, st, P, dY, ldy, X, ldx, draw, pw, pb, pr, live_idx, live_cnt);
-  FN_LAUNCH_CHECK();
-  return 0;
 }
 
 static void add_seg(RedTable& T, int64_t src, int64_t wg_stride, int nwg, int rows, int cols, int64_t dst, int ld,
