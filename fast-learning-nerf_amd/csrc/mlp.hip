@@ -1577,16 +1577,17 @@ __global__ void __launch_bounds__(128) head_grads_kernel(int64_t P, const float*
   if (pb > P) pb = P;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, sb = 0.f;
   int64_t p = pa;
-  for (; p + 4 <= pb; p += 4) {  // 4 independent points in flight
-    float4 d[4];
-    float h[4];
+  constexpr int NF = 16;   // independent points in flight (8 waves per CU: latency, not bandwidth, set the pace at 4); same sum order
+  for (; p + NF <= pb; p += NF) {
+    float4 d[NF];
+    float h[NF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NF; ++i) {
       d[i] = *reinterpret_cast<const float4*>(dptr(p + i));
       h[i] = hv[(p + i) * 128 + k];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NF; ++i) {
       s0 = fmaf(d[i].x, h[i], s0); s1 = fmaf(d[i].y, h[i], s1); s2 = fmaf(d[i].z, h[i], s2);
       if (k < 4) sb += (k == 0) ? d[i].x : (k == 1) ? d[i].y : (k == 2) ? d[i].z : d[i].w;
     }
