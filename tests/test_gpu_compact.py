@@ -93,7 +93,8 @@ def _live(fn, rb, z, cot, flat, pf, pb, idx=None, cnt=None):
     return g, idx, cnt
 
 
-@pytest.mark.parametrize('n,S,dead_frac', [(9, 50, 0.5), (64, 192, 0.55), (300, 64, 0.97), (7, 9, 0.4)])
+# (1367, 193): 130 k live points -- every dW workgroup runs its steady-state loop over the live list (32 k-steps each, a partial last one)
+@pytest.mark.parametrize('n,S,dead_frac', [(9, 50, 0.5), (64, 192, 0.55), (300, 64, 0.97), (7, 9, 0.4), (1367, 193, 0.5)])
 def test_dead_points_contribute_exact_zeros_and_live_kernels_are_the_plain_kernels(fn, weights, math_mode, n, S, dead_frac):
     rb, z, cot, dead, flat, pf, pb = _setup(fn, weights, n, S, 11 * n + S, dead_frac)
     g_plain = _plain(fn, rb, z, cot, flat, pf, pb)
