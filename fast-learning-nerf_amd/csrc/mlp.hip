@@ -1335,11 +1335,16 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
 //   * whole k-steps address with a wave-uniform base + immediates (no per-lane address arithmetic); the k-steps that touch the
 //     end of the workgroup's row range clamp their rows and zero them when they are split.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>
+// CTI2 > 0: the last CTI2 of the WI * TI input tiles come from a second tensor X2 of width 32 * CTI2 (the view layer's two inputs,
+// feature and encoded direction, ride in ONE job: their common dY is read and split once).
+// CTO2 > 0: the last CTO2 of the WO * TO output tiles come from a second gradient tensor dY2 of width 32 * CTO2 (layers 0 and 5 both
+// multiply the positional encoding: it is read and split once); bias sums are taken over dY only.
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int CTI2 = 0, int CTO2 = 0>
 __global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restrict__ X,
                    const float* __restrict__ draw, float* __restrict__ partial_w, float* __restrict__ partial_b,
-                   float* __restrict__ partial_r, const int* __restrict__ live_idx, const int* __restrict__ live_cnt) {
+                   float* __restrict__ partial_r, const int* __restrict__ live_idx, const int* __restrict__ live_cnt,
+                   const float* __restrict__ X2 = nullptr, const float* __restrict__ dY2 = nullptr) {
   if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int CTO = WO * TO, CTI = WI * TI, NTILE = CTO + CTI;
@@ -1373,17 +1378,24 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 
   // the tiles this wave splits: tile t = k * NW + wave; t < CTO: channels t*32.. of dY, else channels (t - CTO)*32.. of X.
   // Rows are counted from the workgroup's first row.
+  constexpr int CTI1 = CTI - CTI2, KI1 = CTI1 * 32, KI2 = CTI2 * 32;   // row widths of X and X2 (KI = KI1 + KI2 partial columns)
+  static_assert(!(RANK1 && CTI2), "the rank-1 row is taken over X only");
+  constexpr int CTO1 = CTO - CTO2, NO1 = CTO1 * 32, NO2 = CTO2 * 32;   // row widths of dY and dY2 (NO = NO1 + NO2 partial rows)
+  static_assert(!(RANK1 && CTO2) && !(CTI2 && CTO2), "one second tensor per job");
   const float* tsrc[TPW];
-  bool tisy[TPW];
+  bool tisy[TPW], tis2[TPW];   // tis2: the tile comes from the second tensor of its side
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int t = k * NW + wave;
     tisy[k] = t < CTO;
-    tsrc[k] = tisy[k] ? dY + q0 * (16 * NO) + t * 32 : X + q0 * (16 * KI) + (t - CTO) * 32;
+    tis2[k] = (CTI2 > 0 && t >= CTO + CTI1) || (CTO2 > 0 && t >= CTO1 && t < CTO);
+    tsrc[k] = tisy[k] ? (tis2[k] ? dY2 + q0 * (16 * NO2) + (t - CTO1) * 32 : dY + q0 * (16 * NO1) + t * 32)
+                      : (tis2[k] ? X2 + q0 * (16 * KI2) + (t - CTO - CTI1) * 32 : X + q0 * (16 * KI1) + (t - CTO) * 32);
   }
   const int relmax = (int)(Pend - q0 * 16) - 1;   // last row of this workgroup (nq > 0: >= 0)
   const int col = lane & 31, half8 = (lane >> 5) * 8;
-  const unsigned boffy = (unsigned)(half8 * NO + col) * 4u, boffx = (unsigned)(half8 * KI + col) * 4u;   // byte offsets of row 0
+  const unsigned boffy = (unsigned)(half8 * NO1 + col) * 4u, boffy2 = (unsigned)(half8 * NO2 + col) * 4u,
+                 boffx = (unsigned)(half8 * KI1 + col) * 4u, boffx2 = (unsigned)(half8 * KI2 + col) * 4u;   // byte offsets of row 0
   struct Raw { float v[TPW][8]; };
   auto ldb = [](const float* base, unsigned byte_off) __attribute__((always_inline)) -> float {   // uniform base + 32-bit offset
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -1396,14 +1408,22 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
       for (int k = 0; k < TPW; ++k) {
         const int t = k * NW + wave;
         if (NTILE % NW == 0 || t < NTILE) {
-          if (tisy[k]) {
-            const float* b = tsrc[k] + (int64_t)st * (16 * NO);
+          if (tisy[k] && CTO2 > 0 && tis2[k]) {
+            const float* b = tsrc[k] + (int64_t)st * (16 * NO2);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffy + (unsigned)(e * NO * 4));
+            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffy2 + (unsigned)(e * NO2 * 4));
+          } else if (tisy[k]) {
+            const float* b = tsrc[k] + (int64_t)st * (16 * NO1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffy + (unsigned)(e * NO1 * 4));
+          } else if (CTI2 > 0 && tis2[k]) {
+            const float* b = tsrc[k] + (int64_t)st * (16 * KI2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffx2 + (unsigned)(e * KI2 * 4));
           } else {
-            const float* b = tsrc[k] + (int64_t)st * (16 * KI);
+            const float* b = tsrc[k] + (int64_t)st * (16 * KI1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffx + (unsigned)(e * KI * 4));
+            for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(b, boffx + (unsigned)(e * KI1 * 4));
           }
         }
       }
@@ -1416,7 +1436,8 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
         const int t = k * NW + wave;
         if (NTILE % NW == 0 || t < NTILE) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) r.v[k][e] = ldb(tsrc[k], (row[e] * (unsigned)(tisy[k] ? NO : KI) + (unsigned)col) * 4u);
+          for (int e = 0; e < 8; ++e)
+            r.v[k][e] = ldb(tsrc[k], (row[e] * (unsigned)(tisy[k] ? (tis2[k] ? NO2 : NO1) : (tis2[k] ? KI2 : KI1)) + (unsigned)col) * 4u);
         }
       }
     }
@@ -1447,7 +1468,7 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
         split3_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
         uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
         d[0] = h; d[64] = m; d[128] = l;
-        if (BIAS && t < CTO) ssum[k] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        if (BIAS && t < CTO1) ssum[k] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         if (RANK1 && t >= CTO) {
           const float4 d0 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8);
           const float4 d1 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8 + 4);
@@ -1554,7 +1575,7 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
       if (NTILE % NW == 0 || t < NTILE) {
         const float sv = ssum[k] + __shfl_xor(ssum[k], 32, 64);
         if (lane < 32) {
-          if (BIAS && t < CTO) partial_b[(int64_t)blockIdx.x * NO + t * 32 + lane] = sv;
+          if (BIAS && t < CTO1) partial_b[(int64_t)blockIdx.x * NO1 + t * 32 + lane] = sv;
           if (RANK1 && t >= CTO) partial_r[(int64_t)blockIdx.x * KI + (t - CTO) * 32 + lane] = sv;
         }
       }
@@ -1652,10 +1673,16 @@ static int64_t dw_job_floats(int j, int pe_pad) {
   const DwJobDesc d = dw_job(j, pe_pad);
   return (int64_t)d.NO * d.KI + (d.bias ? d.NO : 0) + (d.rank1 ? d.KI : 0);
 }
+// regions in the order 0, 8, 1..7, 9, 10, 11 (then the head partials, "job 12"): the pairs that the bf16x6 path runs as ONE job
+// (0 + 8: both multiply the positional encoding; 10 + 11: both multiply dYv) are neighbours
 static int64_t dw_job_base(int j, int ncu, int pe_pad) {
+  static const int order[12] = {0, 8, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11};
   int64_t o = 0;
-  for (int i = 0; i < j; ++i) o += dw_job_floats(i, pe_pad) * ncu;
-  return o;
+  for (int i = 0; i < 12; ++i) {
+    if (order[i] == j) return o;
+    o += dw_job_floats(order[i], pe_pad) * ncu;
+  }
+  return o;   // j == 12: everything
 }
 extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
   return dw_job_base(12, num_cus(), 96) + (int64_t)HEAD_MAX_WG * 388;   // sized for the widest layout
@@ -1664,26 +1691,31 @@ extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
 #ifndef X6_DW_SYNC
 #define X6_DW_SYNC 0
 #endif
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32>
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32, int CTI2 = 0, int CTO2 = 0>
 static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* base,
-                     int nwg, hipStream_t st, const int* live_idx = nullptr, const int* live_cnt = nullptr) {
+                     int nwg, hipStream_t st, const int* live_idx = nullptr, const int* live_cnt = nullptr,
+                     const float* X2 = nullptr, const float* dY2 = nullptr) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
-  float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
+  float* pr = pb + (BIAS ? (int64_t)nwg * (NO - CTO2 * 32) : 0);
   if constexpr (MM == MM_X6 && !X6_DW_SYNC) {
-    if (ldy != NO || ldx != KI) { fn::set_error("launch_dw: the bf16x6 dW kernel needs ld == width"); return -1; }
+    if (ldy != NO - CTO2 * 32 || ldx != KI - CTI2 * 32 || (CTI2 > 0) != (X2 != nullptr) || (CTO2 > 0) != (dY2 != nullptr)) {
+      fn::set_error("launch_dw: the bf16x6 dW kernel needs ld == width (and X2 / dY2 exactly when CTI2 / CTO2 > 0)");
+      return -1;
+    }
     constexpr int lds6 = 2 * (WO * TO + WI * TI) * 3 * 1024 + 128;
-    auto kern6 = mlp_bwd_dw6_kernel<WO, WI, TO, TI, BIAS, RANK1>;
+    auto kern6 = mlp_bwd_dw6_kernel<WO, WI, TO, TI, BIAS, RANK1, CTI2, CTO2>;
     static bool attr6 = false;
     if (!attr6) {
       FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern6), hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
       attr6 = true;
     }
-    hipLaunchKernelGGL(kern6, dim3(nwg), dim3(WO * WI * 64), lds6, st, P, dY, X, draw, pw, pb, pr, live_idx, live_cnt);
+    hipLaunchKernelGGL(kern6, dim3(nwg), dim3(WO * WI * 64), lds6, st, P, dY, X, draw, pw, pb, pr, live_idx, live_cnt, X2, dY2);
     FN_LAUNCH_CHECK();
     return 0;
   } else {   // MM_F32 (and, in -DX6_DW_SYNC=1 builds, MM_X6 on the synchronous-stage kernel for A/B timing)
+    static_assert(CTI2 == 0 && CTO2 == 0, "two-tensor jobs exist for the bf16x6 dW kernel only");
     constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
     const size_t lds = 2 * STAGE * sizeof(float);
     auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1, MM>;
@@ -1745,30 +1777,52 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     if (d.bias) { add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO); o += (int64_t)nwg * d.NO; }
     if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
   };
-  // L0
-  // (MM_X6: the narrow jobs as 8 / 12 waves of one X tile each -- one workgroup per CU, and a lone wave per SIMD hides nothing)
-  if (PEP == 64) rc = launch_dw<4, (MM == MM_X6 ? 2 : 1), 2, (MM == MM_X6 ? 1 : 2), true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
-  else rc = launch_dw<4, (MM == MM_X6 ? 3 : 1), 2, (MM == MM_X6 ? 1 : 3), true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
-  if (rc) return rc;
-  segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
+  // L0 (+ L5's pe part in the same job under MM_X6: one read and one split of the positional encoding for both;
+  //     8 waves x (64 outputs x all pe tiles), partials [512][pe] + bias [256] across the neighbouring regions of jobs 0 and 8)
+  if constexpr (MM == MM_X6 && !X6_DW_SYNC) {
+    if (PEP == 64) rc = launch_dw<8, 1, 2, 2, true, false, MM, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
+    else rc = launch_dw<8, 1, 2, 3, true, false, MM, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
+    if (rc) return rc;
+    const int64_t b0 = dw_job_base(0, ncu, PEP);
+    add_seg(T, b0, (int64_t)512 * PEP, nwg, 256, PEP, L.LW[0], L.in_pe, L.in_pe);
+    add_seg(T, b0 + (int64_t)256 * PEP, (int64_t)512 * PEP, nwg, 256, PEP, L.LW[5], 256 + L.in_pe, L.in_pe);
+    add_seg(T, b0 + (int64_t)nwg * 512 * PEP, 256, nwg, 1, 256, L.LB[0], 256, 256);
+  } else {
+    if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
+    else rc = launch_dw<4, 1, 2, 3, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
+    if (rc) return rc;
+    segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
+  }
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
     if ((rc = launch_dw<4, 2, 2, 4, true, false, MM>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
   }
-  // L5 pe part
-  if (PEP == 64) rc = launch_dw<4, (MM == MM_X6 ? 2 : 1), 2, (MM == MM_X6 ? 1 : 2), false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
-  else rc = launch_dw<4, (MM == MM_X6 ? 3 : 1), 2, (MM == MM_X6 ? 1 : 3), false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
-  if (rc) return rc;
-  segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
+  // L5 pe part (MM_X6: done with L0 above)
+  if constexpr (!(MM == MM_X6 && !X6_DW_SYNC)) {
+    if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
+    else rc = launch_dw<4, 1, 2, 3, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
+    if (rc) return rc;
+    segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
+  }
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
   if ((rc = launch_dw<4, 2, 2, 4, true, true, MM>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
   segs(9, L.FW, 256, 256, L.FB, L.AW);
   // view layer
-  if ((rc = launch_dw<2, 4, 2, 2, true, false, MM>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st, live_idx, live_cnt))) return rc;
-  segs(10, L.VW, 283, 256, L.VB, 0);
-  if ((rc = launch_dw<4, 1, 1, 1, false, false, MM>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
-  segs(11, L.VW + 256, 283, 27, 0, 0);
+  if constexpr (MM == MM_X6 && !X6_DW_SYNC) {
+    // one job for both inputs of the view layer (feature [P,256] | encoded direction [P,32]): dYv is read and split once; 12 waves,
+    // partials [128][288] + bias [128] across the (adjacent) regions of jobs 10 and 11
+    if ((rc = launch_dw<4, 3, 1, 3, true, false, MM, 1>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st,
+                                                        live_idx, live_cnt, act + act_vpe(P, PEP)))) return rc;
+    const int64_t b10 = dw_job_base(10, ncu, PEP);
+    add_seg(T, b10, 128 * 288, nwg, 128, 288, L.VW, 283, 283);
+    add_seg(T, b10 + (int64_t)nwg * 128 * 288, 128, nwg, 1, 128, L.VB, 128, 128);
+  } else {
+    if ((rc = launch_dw<2, 4, 2, 2, true, false, MM>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st, live_idx, live_cnt))) return rc;
+    segs(10, L.VW, 283, 256, L.VB, 0);
+    if ((rc = launch_dw<4, 1, 1, 1, false, false, MM>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
+    segs(11, L.VW + 256, 283, 27, 0, 0);
+  }
   // rgb head + alpha bias
   {
     const int hg = HEAD_MAX_WG;
