@@ -436,9 +436,16 @@ __device__ __forceinline__ void gemm_seg6(f32x16 (&acc)[2][NT], const float* __r
     arow[mt] = As + m * (AMODE == 0 ? 256 : (AMODE == 1 ? 64 : 32));
     axor[mt] = (AMODE == 2) ? ((m >> 1) & 7) : (m & 15);
   }
-  const uint4* bptr[NT];
+  // weight pieces: wave-uniform block pointers + ONE 32-bit lane offset + immediates, so that the loads take the scalar-base form
+  // (global_load_dwordx4 v, v_off, s[base] offset:imm) and the pointers advance by scalar adds: no per-lane 64-bit address arithmetic
+  // in the loop (VALU time is not hidden under the partner wave's MFMAs).  The lane offset is redefined by an empty asm inside
+  // load_b: left loop-invariant, the compiler folds it into per-lane pointers and increments those.  Measured on one box against
+  // the per-lane-pointer form: step 20.25 -> 19.95 ms; a pair-contiguous packing (one base for all six loads) and a peeled last
+  // k-step pair (no branch in the loop, no v_mov, but 70 - 145 spilled SGPRs) were slower than this (20.0 / 20.25).
+  const char* bptr[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 192 + lane;
+  for (int nt = 0; nt < NT; ++nt) bptr[nt] = reinterpret_cast<const char*>(Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 192);
+  unsigned blane = (unsigned)lane * 16u;
   auto load_a = [&](float4 (&a)[2][2], int ks) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -447,10 +454,11 @@ __device__ __forceinline__ void gemm_seg6(f32x16 (&acc)[2][NT], const float* __r
         a[mt][j] = *reinterpret_cast<const float4*>(arow[mt] + ((((a_ks0 + ks) * 4 + kb * 2 + j) ^ axor[mt]) << 2));
   };
   auto load_b = [&](uint4 (&b)[NT][3], int ks) {
+    asm volatile("" : "+v"(blane));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[nt][pl] = bptr[nt][ks * 192 + pl * 64];
+      for (int pl = 0; pl < 3; ++pl) b[nt][pl] = *reinterpret_cast<const uint4*>((bptr[nt] + (ks * 192 + pl * 64) * 16) + blane);
   };
   auto side_copy = [&]() {   // (see gemm_seg)
     if (AMODE == 0 && save_dst != nullptr) {
