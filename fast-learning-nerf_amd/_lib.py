@@ -114,6 +114,7 @@ SIGNATURES = {
     'fastnerf_comm_destroy': (I, [P]),
     'fastnerf_allreduce_grads': (I, [P, P, L, C.c_float, P]),
     'fastnerf_allreduce_leaf_table': (I, [P, P, L, P]),
+    'fastnerf_allreduce_leaf_sumcount': (I, [P, P, P, L, P]),
     'fastnerf_leaf_table_reset': (I, [P, L, P]),
     'fastnerf_leaf_table_read': (I, [P, P, L, P]),
 }

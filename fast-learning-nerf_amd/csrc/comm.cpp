@@ -10,6 +10,8 @@
 // librccl is resolved at the first call (symbols already in the process -- PyTorch ships its own copy -- else librccl.so.1):
 // libfastnerf.so itself has no link-time dependency on it and loads on a box without RCCL.
 #include <dlfcn.h>
+#include <link.h>
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -36,13 +38,28 @@ bool sym(void* h, const char* name, F& f) {
   f = reinterpret_cast<F>(dlsym(h, name));
   return f != nullptr;
 }
-void load_rccl() {
-  void* h = RTLD_DEFAULT;
-  if (dlsym(h, "ncclCommInitRank") == nullptr) {
-    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (h == nullptr) return;
+// an RCCL that is ALREADY in the process but not in the global symbol scope (PyTorch loads its bundled torch/lib/librccl.so as an
+// RTLD_LOCAL dependency of libtorch_hip.so): found by walking the loaded objects, re-opened with RTLD_NOLOAD -- the same copy,
+// never a second one next to it
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  const char* name = info->dlpi_name;
+  if (name && std::strstr(name, "librccl")) {
+    void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+    if (h && dlsym(h, "ncclCommInitRank")) { *static_cast<void**>(out) = h; return 1; }
   }
+  return 0;
+}
+// Resolution order: (1) FASTNERF_RCCL_LIB=<path> if set; (2) the global symbol scope; (3) a librccl already loaded in the process
+// (RTLD_NOLOAD); (4) only then the system librccl.so.1 -- a SECOND RCCL beside PyTorch's would come from another ROCm build than the
+// process's HIP runtime, so it is the last resort and only reached when the process holds no RCCL at all.
+void load_rccl() {
+  void* h = nullptr;
+  if (const char* p = getenv("FASTNERF_RCCL_LIB")) h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+  if (h == nullptr && dlsym(RTLD_DEFAULT, "ncclCommInitRank") != nullptr) h = RTLD_DEFAULT;
+  if (h == nullptr) dl_iterate_phdr(find_loaded_rccl, &h);
+  if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (h == nullptr) return;
   g_rccl.ok = sym(h, "ncclGetUniqueId", g_rccl.GetUniqueId) && sym(h, "ncclCommInitRank", g_rccl.CommInitRank) &&
               sym(h, "ncclCommDestroy", g_rccl.CommDestroy) && sym(h, "ncclAllReduce", g_rccl.AllReduce) &&
               sym(h, "ncclGetErrorString", g_rccl.GetErrorString);
@@ -121,6 +138,18 @@ extern "C" int fastnerf_allreduce_leaf_table(fn_comm* c, uint32_t* table, int64_
   if (!rccl_ready(__func__)) return -2;
   // bit patterns of non-negative floats are monotone in the float: MAX on them is exact and order independent
   FN_RCCL(g_rccl.AllReduce(table, table, (size_t)n, ncclUint32, ncclMax, c->comm, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+// nerf++ fork (MEAN rule, nerf++-ours/tree.py:609-632): the per-(image, leaf) fp64 sums and int32 ray counts of fastnerf_leaf_sumcount,
+// summed over ranks.  The sums hold multiples of 2^-30 (train.hip): fp64 addition of them is exact, so whatever order the ring
+// reduces in, every rank ends with the bit pattern a single rank would have accumulated over all rays.
+extern "C" int fastnerf_allreduce_leaf_sumcount(fn_comm* c, double* sum, int32_t* count, int64_t n, fn_stream_t stream) {
+  FN_CHECK_ARG(c != nullptr && n >= 0 && ((sum != nullptr && count != nullptr) || n == 0), "comm / sum / count");
+  if (n == 0) return 0;
+  if (!rccl_ready(__func__)) return -2;
+  FN_RCCL(g_rccl.AllReduce(sum, sum, (size_t)n, ncclDouble, ncclSum, c->comm, static_cast<hipStream_t>(stream)));
+  FN_RCCL(g_rccl.AllReduce(count, count, (size_t)n, ncclInt32, ncclSum, c->comm, static_cast<hipStream_t>(stream)));
   return 0;
 }
 

@@ -503,14 +503,171 @@ __device__ __forceinline__ void gemm_seg6(f32x16 (&acc)[2][NT], const float* __r
 #endif
 }
 
+// ---- MM_X6, software-pipelined k-loop (X6_PIPE) ------------------------------------------------------------------------------
+// On a SIMD the VALU instructions of one wave do not issue while the OTHER wave streams MFMAs back to back, but a wave's own
+// independent instructions do issue in the shadow of its own MFMA (32 cycles of matrix pipe per v_mfma_f32_32x32x16_bf16 = 8 issue
+// slots, about five of them usable: MI355X_MICROARCH.md, "single-issue instructions hidden per MFMA gap").  gemm_seg6 splits a
+// k-step's activation fragments in one clump of ~70 VALU instructions and then issues its 24 MFMAs: the clump is paid in full.
+// Here the split of k-step q + 1 is spread BETWEEN the MFMAs of k-step q (one pair of values = 11 plain VALU instructions per
+// three MFMAs; sched_group_barrier pins the interleave), the pieces are double buffered (+ 24 registers), the raw fragments are
+// single buffered: the LDS reads of k-step q + 2 refill each row tile's registers as soon as that row tile has been split.  The
+// loop body is branch free (k-step indices of the look-ahead loads are clamped), so that the whole body is one scheduling region.
+#ifndef X6_PIPE
+#define X6_PIPE 1
+#endif
+#ifndef X6_PIPE_DOT2
+#define X6_PIPE_DOT2 0   // 1: the 7-instruction v_dot2c split inside the pipelined loop (v_dot2c costs more than its slot beside MFMAs)
+#endif
+__device__ __forceinline__ void split3_pair_p(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#if X6_PIPE_DOT2
+  split3_pair(x0, x1, h, m, l);
+#else
+#ifdef X6_ABL_NOSPLIT
+  h = __float_as_uint(x0); m = __float_as_uint(x1); l = h ^ m;
+  return;
+#endif
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  l = cvt_pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+#endif
+}
+struct Pieces { unsigned v[3][2][4]; };   // [piece h | m | l][row tile][pair of k]
+__device__ __forceinline__ uint4 piece_frag(const Pieces& p, int pl, int mt) {
+  return make_uint4(p.v[pl][mt][0], p.v[pl][mt][1], p.v[pl][mt][2], p.v[pl][mt][3]);
+}
+__device__ __forceinline__ void split_one_pair(const float4 (&ar)[2][2], Pieces& pn, int pair) {
+  const int mt = pair >> 2, q = pair & 3;
+  const float4& s = ar[mt][q >> 1];
+  const float x0 = (q & 1) ? s.z : s.x, x1 = (q & 1) ? s.w : s.y;
+  split3_pair_p(x0, x1, pn.v[0][mt][q], pn.v[1][mt][q], pn.v[2][mt][q]);
+}
+// the schedule of a stage: MFMA i, then its share of the 8 pair splits (X6_PIPE_VP VALU instructions each)
+#ifndef X6_PIPE_VP
+#define X6_PIPE_VP (X6_PIPE_DOT2 ? 8 : 11)
+#endif
+template <int I, int NM>
+__device__ __forceinline__ void interleave6() {
+  if constexpr (I < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int nv = ((I + 1) * 8 * X6_PIPE_VP) / NM - (I * 8 * X6_PIPE_VP) / NM;
+    if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+    interleave6<I + 1, NM>();
+  }
+}
+// one k-step: the MFMAs on the pieces `pc` and the weight pieces `b`; between them the split of the raw fragments `ar` (the
+// NEXT k-step) into `pn`, and `refill(mt)` -- the LDS reads that reload row tile mt's raw registers -- right after its last split
+template <int NT, typename RF>
+__device__ __forceinline__ void stage6(f32x16 (&acc)[2][NT], const Pieces& pc, const uint4 (&b)[NT][3], float4 (&ar)[2][2],
+                                       Pieces& pn, RF&& refill) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int NM = 12 * NT;
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int i = (t * 2 + mt) * NT + nt;
+        acc[mt][nt] = mfma_bf16(piece_frag(pc, PA[t], mt), b[nt][PB[t]], acc[mt][nt]);
+#pragma unroll
+        for (int pair = (i * 8) / NM; pair < ((i + 1) * 8) / NM; ++pair) {
+          split_one_pair(ar, pn, pair);
+          if ((pair & 3) == 3) refill(pair >> 2);
+        }
+      }
+  // the interleave: one MFMA, then its share of the split (11 VALU per pair in the subtract form, 7 + moves in the dot2 form)
+  interleave6<0, NM>();
+}
+template <int NT, int AMODE>
+__device__ __forceinline__ void gemm_seg6p(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks,
+                                           const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int wm, int lane,
+                                           float* __restrict__ save_dst, int save_valid, int wave) {
+  asm volatile("" : "+v"(lane));
+  const int lrow = lane & 31, kb = lane >> 5;
+  const float* arow[2];
+  int axor[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = wm * 64 + mt * 32 + lrow;
+    arow[mt] = As + m * (AMODE == 0 ? 256 : (AMODE == 1 ? 64 : 32));
+    axor[mt] = (AMODE == 2) ? ((m >> 1) & 7) : (m & 15);
+  }
+  const char* bptr[NT];   // (scalar-base weight loads: see gemm_seg6)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bptr[nt] = reinterpret_cast<const char*>(Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 192);
+  unsigned blane = (unsigned)lane * 16u;
+  const int klast = nks - 1;
+  auto load_a1 = [&](float4 (&a)[2][2], int mt, int ks) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      a[mt][j] = *reinterpret_cast<const float4*>(arow[mt] + ((((a_ks0 + ks) * 4 + kb * 2 + j) ^ axor[mt]) << 2));
+  };
+  auto load_b = [&](uint4 (&b)[NT][3], int ks) {
+    asm volatile("" : "+v"(blane));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[nt][pl] = *reinterpret_cast<const uint4*>((bptr[nt] + (ks * 192 + pl * 64) * 16) + blane);
+  };
+  float4 ar[2][2];
+  Pieces p0, p1;
+  uint4 b0[NT][3], b1[NT][3];
+  load_b(b0, 0);
+  load_a1(ar, 0, 0); load_a1(ar, 1, 0);
+  load_b(b1, 1);                             // (nks >= 2 for every segment)
+#pragma unroll
+  for (int pair = 0; pair < 8; ++pair) {     // k-step 0 is split up front; its registers then take k-step 1
+    split_one_pair(ar, p0, pair);
+    if ((pair & 3) == 3) load_a1(ar, pair >> 2, 1);
+  }
+#if X6_PRIO
+  __builtin_amdgcn_s_setprio(X6_PRIO);
+#endif
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ks += 2) {   // nks is even for every segment
+    const int k2 = ks + 2 < klast ? ks + 2 : klast, k3 = ks + 3 < klast ? ks + 3 : klast;
+#ifdef X6_ABL   // timing-only ablation builds (wrong results): 1 = no weight loads in the loop, 2 = no LDS reads in the loop, 3 = both
+    stage6<NT>(acc, p0, b0, ar, p1, [&](int mt) { if (!(X6_ABL & 2)) load_a1(ar, mt, k2); });
+    if (!(X6_ABL & 1)) load_b(b0, k2);
+    stage6<NT>(acc, p1, b1, ar, p0, [&](int mt) { if (!(X6_ABL & 2)) load_a1(ar, mt, k3); });
+    if (!(X6_ABL & 1)) load_b(b1, k3);
+    asm volatile("" : "+v"(ar[0][0].x), "+v"(ar[1][0].x), "+v"(b0[0][0].x), "+v"(b1[0][0].x));
+#else
+    stage6<NT>(acc, p0, b0, ar, p1, [&](int mt) { load_a1(ar, mt, k2); });
+    load_b(b0, k2);
+    stage6<NT>(acc, p1, b1, ar, p0, [&](int mt) { load_a1(ar, mt, k3); });
+    load_b(b1, k3);
+#endif
+  }
+#if X6_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  if (AMODE == 0 && save_dst != nullptr) {   // the tile's rows, streamed out in one burst behind the loop's loads (see gemm_seg)
+#pragma unroll 4
+    for (int i = 0; i < TM / NWAVES; ++i) {
+      const int m = i * NWAVES + wave;
+      if (m < save_valid) {
+        const float4 v = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
+        store_nt(save_dst + (unsigned)(m * 256 + ((lane ^ (m & 15)) << 2)), v);
+      }
+    }
+  }
+}
+
 // one call site for both math modes: k-steps in the 8-wide units of gemm_seg, Bw = the layer's block in this mode's packing
 template <int MM, int NT, int AMODE>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
                                      int KS, int b_ks0, int nt0, int wm, int lane, int dbg = 0,
                                      float* __restrict__ save_dst = nullptr, int save_valid = 0, int wave = 0) {
   if constexpr (MM == MM_X6)
+#if X6_PIPE
+    gemm_seg6p<NT, AMODE>(acc, As, a_ks0 / 2, nks / 2, reinterpret_cast<const uint4*>(Bw), KS / 2, b_ks0 / 2, nt0, wm, lane,
+                          save_dst, save_valid, wave);
+#else
     gemm_seg6<NT, AMODE>(acc, As, a_ks0 / 2, nks / 2, reinterpret_cast<const uint4*>(Bw), KS / 2, b_ks0 / 2, nt0, wm, lane,
                          save_dst, save_valid, wave);
+#endif
   else
     gemm_seg<NT, AMODE>(acc, As, a_ks0, nks, reinterpret_cast<const float4*>(Bw), KS, b_ks0, nt0, wm, lane, dbg, save_dst,
                         save_valid, wave);

@@ -195,10 +195,11 @@ class NerfNetWithAutoExpo(nn.Module):
     def forward(self, ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals, img_name=None):
         return self.nerf_net(ray_o, ray_d, fg_z_max, fg_z_vals, bg_z_vals)
 
-    def load_state_dict(self, state_dict, strict=True):
-        """Accepts the reference's checkpoints: its nets are saved through nn.DataParallel (`module.` prefix, ddp_train_nerf.py:154)."""
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        """Accepts the reference's checkpoints: its nets are saved through nn.DataParallel (`module.` prefix, ddp_train_nerf.py:154).
+        Further keywords of nn.Module.load_state_dict (`assign=`) are passed on."""
         sd = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
-        return super().load_state_dict(sd, strict=strict)
+        return super().load_state_dict(sd, strict=strict, **kwargs)
 
     def reference_state_dict(self):
         """state_dict under the names the reference saves and strictly loads (`module.nerf_net.fg_net. ...`)."""
@@ -280,20 +281,39 @@ def render_single_image(models, ray_sampler, chunk_size):
 
 class CascadeTrainer:
     """Fused train_step batch of ddp_train_nerf.py:347-404 over `cascade_samples` levels, each level
-    with its own net + Adam (no LR decay in this fork), gradients all-reduced when world_size > 1."""
+    with its own net + Adam (no LR decay in this fork), gradients all-reduced when world_size > 1.
+    `perturb=False` (an extension: the reference always jitters) takes the unperturbed depths and the deterministic inverse-CDF
+    positions, so that a sharded run can be compared with the single-rank run on the union of the shards."""
 
-    def __init__(self, nets, cascade_samples=(64, 128), lrate=5e-4, min_depth=1e-4):
+    def __init__(self, nets, cascade_samples=(64, 128), lrate=5e-4, min_depth=1e-4, perturb=True):
         self.nets = [getattr(n, 'nerf_net', n) for n in nets]
         self.cascade_samples = list(cascade_samples)
-        self.lrate, self.min_depth = lrate, min_depth
+        self.lrate, self.min_depth, self.perturb = lrate, min_depth, bool(perturb)
+        self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
         self.m = [torch.zeros_like(n.flat) for n in self.nets]
         self.v = [torch.zeros_like(n.flat) for n in self.nets]
         self.t = [0] * len(self.nets)
 
     def step(self, ray_o, ray_d, target, rand=None, leaf_tag=None, table=None, max_leaves=0, n_global=None,
-             update=True):
+             update=True, sumcount=None):
+        """One batch through every cascade level.  `table`: the MAX table of nerf-ours' rule (int32 bit patterns);
+        `sumcount=(sums fp64, counts int32)`: the nerf++ fork's MEAN rule (nerf++-ours/tree.py:609-632) -- the LAST level's colours
+        of this batch are accumulated per (image, leaf) on the device, no host copy.  n_global: rays of the whole batch when this
+        rank holds a shard of it (the gradient is scaled to the global-batch mean before the all-reduce); a rank whose shard is
+        empty still joins every collective."""
         from . import parallel
         n = ray_o.shape[0]
+        dist = parallel.world_size() > 1
+        if n == 0:
+            for m, net in enumerate(self.nets):
+                net.flat_grad.zero_()
+                if dist:
+                    parallel.all_reduce_sum(net.flat_grad)
+                if update:
+                    self.t[m] += 1
+                    ops.adam_step(net.flat, net.flat_grad, self.m[m], self.v[m], self.lrate, self.t[m])
+            self.last_depths = []
+            return torch.zeros(len(self.nets), device=self.nets[0].flat.device), target.new_zeros((0, 3))
         rays11 = ops.pack_rays(ray_o, ray_d, 0.0, 0.0)
         fg_far = ops.pp_intersect_sphere(rays11)
         losses, ret = [], None
@@ -303,22 +323,27 @@ class CascadeTrainer:
             N = self.cascade_samples[m]
             r = rand[m] if rand is not None else {}
             if m == 0:
-                fg_z = ops.pp_fg_depths(fg_far, N, self.min_depth, True, r.get('fg_t'), _next_seed())
-                bg_z = ops.sample_coarse(ops.pack_rays(ray_o, ray_d, 0.0, 1.0), N, perturb=True, t_rand=r.get('bg_t'),
-                                         seed=_next_seed())
+                fg_z = ops.pp_fg_depths(fg_far, N, self.min_depth, self.perturb, r.get('fg_t'), _next_seed() if self.perturb else 0)
+                bg_z = ops.sample_coarse(ops.pack_rays(ray_o, ray_d, 0.0, 1.0), N, perturb=self.perturb, t_rand=r.get('bg_t'),
+                                         seed=_next_seed() if self.perturb else 0)
             else:
-                fg_z, _ = ops.pp_sample_pdf_merge(fg_z, ret[1], N, u=r.get('fg_u'), seed=_next_seed())
-                bg_z, _ = ops.pp_sample_pdf_merge(bg_z, ret[5], N, u=r.get('bg_u'), seed=_next_seed())
+                det = not self.perturb
+                fg_z, _ = ops.pp_sample_pdf_merge(fg_z, ret[1], N, u=r.get('fg_u'), det=det and r.get('fg_u') is None,
+                                                  seed=0 if det else _next_seed())
+                bg_z, _ = ops.pp_sample_pdf_merge(bg_z, ret[5], N, u=r.get('bg_u'), det=det and r.get('bg_u') is None,
+                                                  seed=0 if det else _next_seed())
             self.last_depths.append((fg_z, bg_z))
             outs, saved = _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save=True)
             fg_rgb, fg_w, fg_depth, lam, bg_rgb, bg_w, bg_depth = outs
             rgb = fg_rgb + lam[:, None] * bg_rgb
             last = m == len(self.nets) - 1
             scale = 1.0 if n_global is None else float(n) / float(n_global)
-            loss2, g, _ = ops.mse_leafmax(rgb, None, target, grad_scale=scale, leaf_tag=leaf_tag if last else None,
+            loss2, g, _ = ops.mse_leafmax(rgb, None, target, grad_scale=scale, leaf_tag=leaf_tag if (last and table is not None) else None,
                                           max_leaves=max_leaves, table=table if last else None)
+            if last and sumcount is not None:
+                ops.leaf_sumcount(rgb, target, leaf_tag, max_leaves, sumcount[0], sumcount[1])
             _nerfnet_backward(net, saved, g)
-            if parallel.world_size() > 1:
+            if dist:
                 parallel.all_reduce_sum(net.flat_grad)
             if update:
                 self.t[m] += 1
@@ -326,6 +351,42 @@ class CascadeTrainer:
             losses.append(loss2[0])
             ret = outs
         return torch.stack(losses), rgb
+
+    # ---- exchange with torch.optim.Adam (the reference's `optim_<m>` entries of model_*.pth, ddp_train_nerf.py:306-314) ----
+    def torch_optimizer_state_dict(self, m):
+        """Level m's Adam state in torch.optim.Adam's format over net.parameters() (= the flat buffer's order)."""
+        state, off = {}, 0
+        for i, p in enumerate(self.nets[m].parameters()):
+            k = p.numel()
+            state[i] = {'step': torch.tensor(float(self.t[m])), 'exp_avg': self.m[m][off:off + k].view(p.shape).clone(),
+                        'exp_avg_sq': self.v[m][off:off + k].view(p.shape).clone()}
+            off += k
+        assert off == self.nets[m].flat.numel()
+        group = {'lr': self.lrate, 'betas': (self.beta1, self.beta2), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(len(state)))}
+        return {'state': state if self.t[m] > 0 else {}, 'param_groups': [group]}
+
+    def load_torch_optimizer(self, m, opt):
+        """Take over level m's moments / step count from a torch.optim.Adam (or its state_dict) over the same parameters."""
+        sd = opt.state_dict() if hasattr(opt, 'state_dict') else opt
+        st = sd['state']
+        if len(st) == 0:
+            self.m[m].zero_(); self.v[m].zero_(); self.t[m] = 0
+            return
+        off, steps = 0, set()
+        for i, p in enumerate(self.nets[m].parameters()):
+            k = p.numel()
+            e = st.get(i)
+            if e is None:
+                self.m[m][off:off + k].zero_(); self.v[m][off:off + k].zero_()
+            else:
+                self.m[m][off:off + k].copy_(torch.as_tensor(e['exp_avg']).reshape(-1))
+                self.v[m][off:off + k].copy_(torch.as_tensor(e['exp_avg_sq']).reshape(-1))
+                steps.add(int(float(e['step'])))
+            off += k
+        assert off == self.nets[m].flat.numel() and len(steps) == 1, 'optimizer state does not match the parameter list'
+        self.t[m] = steps.pop()
 
 
 class QuadTreeManager:
@@ -393,6 +454,13 @@ def _ckpt_iter(path):
     return int(stem[stem.rfind('_') + 1:])
 
 
+def _is_ckpt_name(fname):
+    """`model_<int>.pth`: what this loop and the reference's write (ddp_train_nerf.py:306).  (The reference's path2iter raises on
+    any other *.pth in the experiment directory; here a stray file is skipped instead of turning a resume into a crash.)"""
+    import re
+    return re.fullmatch(r'model_\d+\.pth', fname) is not None
+
+
 def create_nerf(rank, args, device='cuda'):
     """ddp_train_nerf.py:136-184 -> (start, models): models = OrderedDict(cascade_level, cascade_samples, net_<m>, optim_<m>); the
     newest `*.pth` of basedir/expname (or args.ckpt_path) is reloaded unless args.no_reload.  Networks are initialised under
@@ -414,7 +482,7 @@ def create_nerf(rank, args, device='cuda'):
     if ckpt_path is not None and os.path.isfile(ckpt_path):
         ckpts = [ckpt_path]
     else:
-        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith('.pth')] if os.path.isdir(d) else []
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if _is_ckpt_name(f)] if os.path.isdir(d) else []
     ckpts = sorted(ckpts, key=_ckpt_iter)
     if len(ckpts) > 0 and not getattr(args, 'no_reload', False):
         start = _ckpt_iter(ckpts[-1])
@@ -472,11 +540,20 @@ def train_step(models, rays_o, rays_d, target_rgb, args):
     return torch.cat(collect, 0)
 
 
-def ddp_train_nerf(args, ray_samplers, log=print, device='cuda', stop_after=None):
+def ddp_train_nerf(args, ray_samplers, log=print, device='cuda', stop_after=None, fused=None):
     """The epoch loop of ddp_train_nerf.py:187-324 on in-memory ray samplers (the directory reader is data_loader_split.py):
     quadtree manager with the MEAN split criterion, per epoch variance-weighted picks (prob=True, rand=args.randSamp_perc;
     the last epoch uniform over every pixel), train_step, subdivision every args.subdivide_every epochs except the last two,
-    `model_{epoch:04d}.pth` after every epoch.  Returns (models, treeManager, per-epoch records)."""
+    `model_{epoch:04d}.pth` after every epoch.  Returns (models, treeManager, per-epoch records).
+
+    fused (default: args.fused, else True): the data-parallel engine -- CascadeTrainer on the HIP kernels without autograd, every
+    batch sharded rows r::world over the ranks of torch.distributed (one process per GPU), per-level gradient all-reduce, the MEAN
+    rule's per-(image, leaf) SUM / COUNT tables accumulated on the device and all-reduced once per subdivide epoch (no host copy
+    per batch).  fused=False: the reference-shaped single-process route (train_step above: autograd + torch.optim.Adam)."""
+    if fused is None:
+        fused = bool(getattr(args, 'fused', True))
+    if fused:
+        return _ddp_train_fused(args, ray_samplers, log, device, stop_after)
     import os
     os.makedirs(os.path.join(args.basedir, args.expname), exist_ok=True)
     start, models = create_nerf(0, args, device=device)
@@ -502,4 +579,72 @@ def ddp_train_nerf(args, ray_samplers, log=print, device='cuda', stop_after=None
                         'leaves_after': sum(tree.num_leaves(i) for i in range(tree.n_images)), 'cur_level': tree.cur_level})
         log('epoch {}: {} rays, mse {:.5f}, leaves {} -> {}'.format(epoch_id, rays_o.shape[0], mse, leaves_before,
                                                                     records[-1]['leaves_after']))
+    return models, tree, records
+
+
+def _ddp_train_fused(args, ray_samplers, log, device, stop_after):
+    """Config 5 as a data-parallel loop (ddp_train_nerf.py:187-324, tree.py:609-632).  Every rank holds the same
+    nets (torch.manual_seed(777) in create_nerf), the same trees and -- seeds broadcast from rank 0 before every epoch's picks --
+    the same epoch of rays; of each batch b0 .. b0 + batch_size it renders and back-propagates rows b0 + r :: world.  Exchanges:
+    one gradient all-reduce per cascade level and batch; one all-reduce(SUM) of the per-(image, leaf) fp64 error sums and int32
+    counts per subdivide epoch (exact: the tables are bit-identical to a single rank's, so every rank splits the same leaves);
+    one fp64 scalar per epoch for the logged mse.  Rank 0 writes `model_{epoch:04d}.pth` in the reference's layout."""
+    import os
+    from . import parallel
+    rk, world = parallel.rank(), parallel.world_size()
+    d = os.path.join(args.basedir, args.expname)
+    if rk == 0:
+        os.makedirs(d, exist_ok=True)
+    parallel.barrier()
+    start, models = create_nerf(rk, args, device=device)
+    L = models['cascade_level']
+    trainer = CascadeTrainer([models['net_{}'.format(m)] for m in range(L)], models['cascade_samples'], lrate=args.lrate,
+                             perturb=bool(getattr(args, 'perturb', 1)))
+    for m in range(L):
+        trainer.load_torch_optimizer(m, models['optim_{}'.format(m)])   # (a resumed run continues from the file's moments)
+    tree = QuadTreeManager(ray_samplers, mseThres=0.0, max_depth=args.init_level, device=device)
+    dev = torch.device(device)
+    records = []
+    for epoch_id in range(start + 1, args.n_epoch + 1):
+        if stop_after is not None and epoch_id > stop_after:
+            break
+        parallel.sync_seed()          # the epoch's pixel picks are drawn redundantly on every rank: same seed, same picks
+        last = epoch_id == args.n_epoch
+        if last:
+            tree.epoch_size = tree.n_images * tree.h * tree.w
+            rays_o, rays_d, target = tree.gen_rays_v3_multiThread(down_scale=args.rays_downscale, prob=False, last_epoch=True)
+        else:
+            rays_o, rays_d, target = tree.gen_rays_v3_multiThread(down_scale=args.rays_downscale, prob=True, rand=args.randSamp_perc,
+                                                                  last_epoch=False)
+        tags = tree.result_leaf_tag
+        ml = tree.max_leaves()
+        sums = torch.zeros(tree.n_images * ml, device=dev, dtype=torch.float64)
+        counts = torch.zeros(tree.n_images * ml, device=dev, dtype=torch.int32)
+        sq = torch.zeros(1, device=dev, dtype=torch.float64)
+        n_total = rays_o.shape[0]
+        leaves_before = sum(tree.num_leaves(i) for i in range(tree.n_images))
+        for b0 in range(0, n_total, args.batch_size):
+            b1 = min(b0 + args.batch_size, n_total)
+            rows = slice(b0 + rk, b1, world)
+            tg = target[rows].float().contiguous()
+            _, rgb = trainer.step(rays_o[rows].float().contiguous(), rays_d[rows].float().contiguous(), tg,
+                                  leaf_tag=tags[rows].contiguous(), max_leaves=ml, n_global=b1 - b0, sumcount=(sums, counts))
+            if rgb.shape[0]:
+                sq += ((rgb - tg).double() ** 2).sum()
+        if epoch_id % args.subdivide_every == 0 and epoch_id < args.n_epoch - 1:
+            parallel.all_reduce_leaf_sumcount(sums, counts)
+            tree.adjust_tree_from_sumcount(sums, counts, args.subdivide_thres)
+        parallel.all_reduce_sum(sq)
+        mse = float(sq.item()) / (3.0 * max(1, n_total))
+        if rk == 0:
+            for m in range(L):
+                models['optim_{}'.format(m)].load_state_dict(trainer.torch_optimizer_state_dict(m))
+            save_models(models, os.path.join(d, 'model_{:04d}.pth'.format(epoch_id)))
+        parallel.barrier()
+        records.append({'epoch': epoch_id, 'rays': int(n_total), 'mse': mse, 'leaves_before': leaves_before,
+                        'leaves_after': sum(tree.num_leaves(i) for i in range(tree.n_images)), 'cur_level': tree.cur_level})
+        if rk == 0:
+            log('epoch {}: {} rays ({} per rank and batch), mse {:.5f}, leaves {} -> {}'.format(
+                epoch_id, n_total, -(-args.batch_size // world), mse, leaves_before, records[-1]['leaves_after']))
+    ddp_train_nerf.last_trainer = trainer
     return models, tree, records

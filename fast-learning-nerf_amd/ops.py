@@ -60,21 +60,36 @@ _PACK_TAGS = {}
 
 
 def _tag_packed(t, tag):
+    """Tag a packed-weight buffer with its math mode.  The persistent buffers of NeRF.packed() / NerfNet.packed() are re-packed in
+    place on every step: ONE finalizer per tensor object (a token the object carries), later calls only update the tag."""
     t._fn_math = tag
     key = (t.device.index, t.data_ptr(), t.numel())
-    _PACK_TAGS[key] = tag
+    token = getattr(t, '_fn_token', None)
+    entry = _PACK_TAGS.get(key)
+    if token is not None and entry is not None and entry[1] is token:
+        if entry[0] != tag:
+            _PACK_TAGS[key] = (tag, token)
+        return
+    token = object()
+    t._fn_token = token
+    _PACK_TAGS[key] = (tag, token)
     # the entry lives as long as the tensor object mlp_pack handed out: a freed block that the caching allocator hands to an
     # unrelated tensor must not inherit the tag
-    weakref.finalize(t, _drop_tag, key, tag)
+    weakref.finalize(t, _drop_tag, key, token)
 
 
-def _drop_tag(key, tag):
-    if _PACK_TAGS.get(key) == tag:
+def _drop_tag(key, token):
+    entry = _PACK_TAGS.get(key)
+    if entry is not None and entry[1] is token:
         del _PACK_TAGS[key]
 
 
 def packed_tag(t):
-    return getattr(t, '_fn_math', None) or _PACK_TAGS.get((t.device.index, t.data_ptr(), t.numel()))
+    tag = getattr(t, '_fn_math', None)
+    if tag:
+        return tag
+    entry = _PACK_TAGS.get((t.device.index, t.data_ptr(), t.numel()))
+    return entry[0] if entry else None
 
 
 def _split(kind):

@@ -7,6 +7,7 @@ and the ONLY exchange per optimiser step is one all-reduce(SUM) of the flat grad
 (2 x 595,844 fp32 = 4.77 MB: latency-bound on xGMI, so one fused buffer instead of 48 tensors),
 plus one all-reduce(MAX) of the per-(image, leaf) error table per subdivide epoch (max is
 associative, so the result is bit-identical to the single-GPU table)."""
+import atexit
 import os
 
 import torch
@@ -86,6 +87,15 @@ class CabiComm:
                 'fastnerf_allreduce_leaf_table')
         return table_i32
 
+    def all_reduce_leaf_sumcount(self, sums_f64, counts_i32):
+        L = self._lib
+        L.require_gpu(sums_f64, counts_i32)
+        assert sums_f64.dtype == torch.float64 and counts_i32.dtype == torch.int32 and sums_f64.numel() == counts_i32.numel()
+        assert sums_f64.is_contiguous() and counts_i32.is_contiguous()
+        L.check(L.lib().fastnerf_allreduce_leaf_sumcount(self._h, L.ptr(sums_f64), L.ptr(counts_i32), sums_f64.numel(), L.stream()),
+                'fastnerf_allreduce_leaf_sumcount')
+        return sums_f64, counts_i32
+
     def destroy(self):
         if self._h is not None:
             self._lib.check(self._lib.lib().fastnerf_comm_destroy(self._h), 'fastnerf_comm_destroy')
@@ -107,6 +117,18 @@ def _maybe_init_cabi(rk, world):
     else:
         comm_id = CabiComm.unique_id()
     _CABI = CabiComm(rk, world, comm_id)
+    atexit.register(shutdown_cabi)
+
+
+def shutdown_cabi():
+    """Destroy the C-ABI communicator (idempotent; registered with atexit, call it before dist.destroy_process_group())."""
+    global _CABI
+    if _CABI is not None:
+        try:
+            torch.cuda.synchronize()
+            _CABI.destroy()
+        finally:
+            _CABI = None
 
 
 def world_size():
@@ -150,6 +172,18 @@ def all_reduce_max_int(table_i32):
             return _CABI.all_reduce_leaf_table(table_i32)
         dist.all_reduce(table_i32, op=dist.ReduceOp.MAX)
     return table_i32
+
+
+def all_reduce_leaf_sumcount(sums_f64, counts_i32):
+    """SUM over ranks of the nerf++ fork's per-(image, leaf) fp64 error sums and int32 ray counts (MEAN split rule,
+    nerf++-ours/tree.py:609-632).  ops.leaf_sumcount accumulates multiples of 2^-30: fp64 addition of them is exact, so the
+    reduced tables are bit-identical to a single rank's over all rays, whatever the reduction order."""
+    if world_size() > 1:
+        if _CABI is not None and sums_f64.is_cuda:
+            return _CABI.all_reduce_leaf_sumcount(sums_f64, counts_i32)
+        dist.all_reduce(sums_f64, op=dist.ReduceOp.SUM)
+        dist.all_reduce(counts_i32, op=dist.ReduceOp.SUM)
+    return sums_f64, counts_i32
 
 
 def shard(n, rk=None, world=None):

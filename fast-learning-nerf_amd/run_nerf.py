@@ -297,10 +297,7 @@ class Trainer:
             self._regions, self._block_floats = _step_regions(n, S0, Ni)
             a.n, a.net_floats = n, ops.NET_PARAMS
             a.math_mode = ops.mode_id()
-            a.N_samples, a.N_importance, a.lindisp, a.perturb = S0, Ni, int(bool(self.lindisp)), int(bool(self.perturb))
-            a.white_bkgd, a.ndc, a.H, a.W = int(bool(self.white_bkgd)), int(bool(self.ndc)), int(self.H), int(self.W)
-            a.focal, a.near_plane, a.far_plane = float(self.K[0][0]), float(self.near), float(self.far)
-            a.beta1, a.beta2, a.eps = self.beta1, self.beta2, self.eps
+            a.N_samples, a.N_importance = S0, Ni
             a.params, a.grads, a.adam_m, a.adam_v = self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
             a.packed_fwd_c, a.packed_bwd_c = self.pc[0].data_ptr(), self.pc[1].data_ptr()
             if Ni > 0:
@@ -312,6 +309,12 @@ class Trainer:
             a.partial_ws = _Workspace.partial(dev).data_ptr()
             a.counts = self.live_counts.data_ptr()
             self._keep = [ws]
+        # scalar settings are read from the trainer on EVERY step, like the call-by-call route does (a caller may change
+        # trainer.perturb / white_bkgd / near / far between steps): a handful of ctypes stores
+        a.lindisp, a.perturb = int(bool(self.lindisp)), int(bool(self.perturb))
+        a.white_bkgd, a.ndc, a.H, a.W = int(bool(self.white_bkgd)), int(bool(self.ndc)), int(self.H), int(self.W)
+        a.focal, a.near_plane, a.far_plane = float(self.K[0][0]), float(self.near), float(self.far)
+        a.beta1, a.beta2, a.eps = self.beta1, self.beta2, self.eps
         # the big buffers of the route this step takes (allocated on first use: a run that never falls back to the plain
         # backward never pays for its 11 GB of saved activations)
         if live:

@@ -199,7 +199,8 @@ int fastnerf_render_rays_bwd(int math_mode, int64_t n, int N_samples, int N_impo
 int fastnerf_pp_gen_rays(int H, int W, const double* intrinsics_host, const double* c2w_host, float* rays_o,
                          float* rays_d, fn_stream_t stream);
 /* nerf++ quadtree fork: per-(image, leaf) sum of |gt-pred| over rays and channels (fp64) and ray count
- * feeding the MEAN split criterion (nerf++-ours/tree.py:622); the caller zeroes sum / count. */
+ * feeding the MEAN split criterion (nerf++-ours/tree.py:622); the caller zeroes sum / count.  A ray's term is rounded to a
+ * multiple of 2^-30 before it is added: the sums are exact (< 2^23), order independent and shard independent. */
 int fastnerf_leaf_sumcount(int64_t n, const float* rgb, const float* target, const int32_t* leaf_tag, int max_leaves,
                            double* sum, int32_t* count, fn_stream_t stream);
 /* intersect_sphere (ddp_train_nerf.py:54-69); *n_outside counts rays whose camera is not inside the
@@ -391,6 +392,9 @@ int fastnerf_train_step(const fn_step_args* args, int phases, fn_stream_t stream
  *                             global-batch mean of img2mse, run_nerf_helpers.py:9); enqueued on `stream`, no host sync
  *   fastnerf_allreduce_leaf_table  in place MAX over ranks of the per-(image, leaf) table of fastnerf_mse_leafmax (uint32 bit
  *                             patterns of non-negative floats: exact, order independent => identical on 1 or 8 GPUs)
+ *   fastnerf_allreduce_leaf_sumcount  in place SUM over ranks of the fp64 sums / int32 counts of fastnerf_leaf_sumcount (the
+ *                             nerf++ fork's MEAN rule, nerf++-ours/tree.py:609-632); the sums hold multiples of 2^-30, so the
+ *                             result is exact: bit-identical to one rank accumulating every ray
  *   fastnerf_leaf_table_reset / _read   zero the device table / copy it to the host as floats and wait for it (the split
  *                             rule of tree.py:629-652 runs on the host: fastnerf_tree_adjust)                              */
 #define FASTNERF_COMM_ID_BYTES 128
@@ -400,6 +404,7 @@ int fastnerf_comm_init(fn_comm** out, const char* id, int rank, int world);
 int fastnerf_comm_destroy(fn_comm* comm);
 int fastnerf_allreduce_grads(fn_comm* comm, float* grads, int64_t n, float scale, fn_stream_t stream);
 int fastnerf_allreduce_leaf_table(fn_comm* comm, uint32_t* table, int64_t n, fn_stream_t stream);
+int fastnerf_allreduce_leaf_sumcount(fn_comm* comm, double* sum, int32_t* count, int64_t n, fn_stream_t stream);
 int fastnerf_leaf_table_reset(uint32_t* table, int64_t n, fn_stream_t stream);
 int fastnerf_leaf_table_read(const uint32_t* table, float* host_out, int64_t n, fn_stream_t stream);
 

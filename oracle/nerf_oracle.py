@@ -365,6 +365,18 @@ def train_step(sd_coarse, sd_fine, opt, ray_batch, target, N_samples, N_importan
 # --------------------------------------------------------------------------
 # per-(image, leaf) loss reduction that feeds the quadtree
 # --------------------------------------------------------------------------
+def leaf_loss_sumcount(rgb_gt, rgb_pred, leaf_tag, n_images, max_leaves):
+    """Per-(image, leaf) sum of |gt - pred| over rays and channels + ray count: the inputs of the nerf++ fork's MEAN split rule
+    (nerf++-ours/tree.py:609-632: `torch.mean(torch.abs(gt - pred))` over a leaf's rays).  A ray's term is rounded to a multiple of
+    2^-30 as the device kernel does (csrc/train.hip: exact, order- and shard-independent fp64 sums).  -> (sums f64, counts i32)."""
+    e = torch.abs(rgb_gt.float() - rgb_pred.float()).double().sum(-1)
+    e = torch.round(e * 1073741824.0) / 1073741824.0
+    flat = leaf_tag[:, 0].long() * max_leaves + leaf_tag[:, 1].long()
+    sums = torch.zeros(n_images * max_leaves, dtype=torch.float64).index_add_(0, flat, e)
+    counts = torch.zeros(n_images * max_leaves, dtype=torch.int32).index_add_(0, flat, torch.ones_like(flat, dtype=torch.int32))
+    return sums, counts
+
+
 def leaf_loss_max(rgb_gt, rgb_pred, leaf_tag, n_images, max_leaves):
     """Segmented max of |gt - pred| over rays and channels per (image, leaf)
     (tree.py:538 + 632-642 restated as one table).  leaf_tag [N,2] int64."""

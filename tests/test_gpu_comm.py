@@ -41,6 +41,11 @@ def test_comm_one_rank_contract(fn):
         assert torch.equal(comm.all_reduce_leaf_table(t), keep)              # MAX over one rank
         empty = torch.empty(0, device='cuda')
         assert comm.all_reduce_sum(empty).numel() == 0
+        sums = torch.rand(3 * 64, device='cuda', dtype=torch.float64)
+        counts = torch.randint(0, 1000, (3 * 64,), device='cuda', dtype=torch.int32)
+        ks, kc = sums.clone(), counts.clone()
+        comm.all_reduce_leaf_sumcount(sums, counts)                          # SUM over one rank (nerf++ fork, MEAN rule)
+        assert torch.equal(sums, ks) and torch.equal(counts, kc)
     finally:
         comm.destroy()
     comm.destroy()                                                            # idempotent
@@ -78,3 +83,34 @@ def test_leaf_table_reset_and_read(fn):
         a, b = int(tag[i, 0]), int(tag[i, 1])
         exp[a, b] = max(exp[a, b], float(err[i]))
     assert torch.equal(got, exp)
+
+
+def test_leaf_sumcount_is_exact_and_shard_independent(fn):
+    """The nerf++ fork's SUM / COUNT tables (fastnerf_leaf_sumcount): a ray's term is a multiple of 2^-30, so the fp64 atomics are
+    exact -- the table equals the oracle's bit for bit, does not depend on the order of the rays, and the SUM of the tables of any
+    sharding (what the all-reduce forms) IS the single-rank table."""
+    from oracle import nerf_oracle as O
+    n, ni, ml = 20000, 5, 16
+    gen = torch.Generator().manual_seed(3)
+    pred, gt = torch.rand(n, 3, generator=gen), torch.rand(n, 3, generator=gen)
+    tag = torch.stack([torch.randint(0, ni, (n,), generator=gen), torch.randint(0, ml, (n,), generator=gen)], 1).int()
+
+    def tables(idx):
+        s = torch.zeros(ni * ml, device='cuda', dtype=torch.float64)
+        c = torch.zeros(ni * ml, device='cuda', dtype=torch.int32)
+        if len(idx):
+            fn.ops.leaf_sumcount(pred[idx].cuda(), gt[idx].cuda(), tag[idx].cuda().contiguous(), ml, s, c)
+        return s, c
+    s0, c0 = tables(torch.arange(n))
+    so, co = O.leaf_loss_sumcount(gt, pred, tag.long(), ni, ml)
+    assert torch.equal(s0.cpu(), so) and torch.equal(c0.cpu(), co)
+    s1, c1 = tables(torch.randperm(n, generator=gen))
+    assert torch.equal(s0, s1) and torch.equal(c0, c1)
+    for world in (2, 8):
+        parts = [tables(torch.arange(r, n, world)) for r in range(world)]
+        s = torch.stack([p[0] for p in parts]).sum(0)
+        c = torch.stack([p[1] for p in parts]).sum(0, dtype=torch.int32)
+        assert torch.equal(s, s0) and torch.equal(c, c0)
+    # the mean it feeds differs from the unrounded fp64 mean by < 2^-31 per ray
+    exact = torch.zeros(ni * ml, dtype=torch.float64).index_add_(0, tag[:, 0].long() * ml + tag[:, 1].long(), (gt - pred).abs().double().sum(-1))
+    assert float(((s0.cpu() - exact) / c0.cpu().clamp(min=1)).abs().max()) < 2.0 ** -31

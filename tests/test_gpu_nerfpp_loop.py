@@ -113,9 +113,12 @@ def test_checkpoint_layout_is_the_references(fn, golden_dir, tmp_path):
         assert len(st) == 48 and torch.equal(st[5]['exp_avg'].cpu(), ref['optim_%d' % m]['state'][5]['exp_avg'])
 
 
-def test_epoch_loop_with_the_quadtree_fork_and_resume(fn, tmp_path):
+@pytest.mark.parametrize('fused', [True, False])
+def test_epoch_loop_with_the_quadtree_fork_and_resume(fn, tmp_path, fused):
+    """fused=True: the data-parallel engine (CascadeTrainer, on-device SUM / COUNT tables; one rank here);
+    fused=False: the reference-shaped route (autograd + torch.optim.Adam, predictions collected on the host)."""
     samplers = _samplers(fn)
-    args = _args(fn, str(tmp_path))
+    args = _args(fn, str(tmp_path), fused=fused)
     torch.manual_seed(0)
     np.random.seed(0)
     logs = []
@@ -149,3 +152,79 @@ def test_epoch_loop_with_the_quadtree_fork_and_resume(fn, tmp_path):
     assert ret[1]['rgb'].shape == (24, 32, 3) and torch.isfinite(ret[1]['rgb']).all()
     mse = float(((ret[1]['rgb'].reshape(-1, 3) - torch.from_numpy(samplers[0].img)) ** 2).mean())
     assert mse < 0.1
+
+
+def test_fused_and_reference_shaped_routes_split_the_same_leaves(fn, tmp_path):
+    """One epoch from the same seeds on both routes: same picks, same per-batch arithmetic up to summation order -> the MEAN rule
+    (device SUM / COUNT tables vs host predictions) splits the same leaves; the per-leaf means stay clear of the threshold."""
+    samplers = _samplers(fn)
+    leaves, mses = [], []
+    for fused in (True, False):
+        args = _args(fn, str(tmp_path / ('f%d' % fused)), fused=fused, n_epoch=4)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        _, tree, rec = fn.nerfpp.ddp_train_nerf(args, samplers, log=lambda *_: None, stop_after=1)
+        leaves.append([np.asarray(tree.leaves(i)).copy() for i in range(tree.n_images)])
+        mses.append(rec[0]['mse'])
+    # (the two routes draw their jitter from different streams, so predictions differ at the 1e-2 level; the split decisions of
+    #  this scene are far from the threshold)
+    assert abs(mses[0] - mses[1]) < 0.2 * max(mses)
+    assert all(np.array_equal(a, b) for a, b in zip(*leaves))
+
+
+_PP_WORKER = r"""
+import os, sys, types
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import fastnerf
+from fastnerf import parallel
+from test_gpu_nerfpp_loop import _samplers, _args
+rank, world, local = parallel.init_from_env('cuda')
+torch.cuda.set_device(0 if torch.cuda.device_count() < world else local)
+samplers = _samplers(fastnerf)
+args = _args(fastnerf, %(base)r + '/w%%d' %% world, fused=True, perturb=0, batch_size=250, n_epoch=5, subdivide_thres=0.03)
+torch.manual_seed(11); np.random.seed(11)
+models, tree, rec = fastnerf.nerfpp.ddp_train_nerf(args, samplers, log=lambda *_: None, stop_after=3)
+tr = fastnerf.nerfpp.ddp_train_nerf.last_trainer
+out = {'leaves': [np.asarray(tree.leaves(i)).copy() for i in range(tree.n_images)], 'rec': rec,
+       'flat': [n.flat.cpu() for n in tr.nets], 'm': [x.cpu() for x in tr.m], 't': list(tr.t)}
+torch.save(out, %(base)r + '/res_w%%d_r%%d.pt' %% (world, rank))
+if world > 1:
+    parallel.barrier(); parallel.shutdown_cabi(); torch.distributed.destroy_process_group()
+"""
+
+
+def test_two_rank_loop_equals_single_rank(tmp_path):
+    """Config 5 data-parallel (SURVEY 8(e)): two ranks (gloo on a 1-GPU box, RCCL otherwise) run ddp_train_nerf on rows r::2 of
+    every batch (batch 250: uneven shards never occur, 768 rays per epoch: a ragged last batch does); deterministic depths
+    (perturb=0) make the run comparable with the single-rank run on the union.  Replicas bit-identical; leaf lists identical to the
+    single-rank run after three epochs with two subdivisions; per-leaf SUM / COUNT tables are exact, so the decision only differs if
+    a mean sits within the 1e-6 that summation grouping moves the predictions -- the test checks it does not."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = str(tmp_path / 'pp_worker.py')
+    with open(script, 'w') as f:
+        f.write(_PP_WORKER % {'root': root, 'base': str(tmp_path)})
+    r1 = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env['FASTNERF_DIST_BACKEND'] = 'gloo'
+    r2 = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                         '127.0.0.1', '--master-port', '29561', script], env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    one = torch.load(str(tmp_path / 'res_w1_r0.pt'), weights_only=False)
+    ra, rb = (torch.load(str(tmp_path / ('res_w2_r%d.pt' % r)), weights_only=False) for r in (0, 1))
+    # replicas: bit-identical parameters, moments, step counts, trees and records
+    for k in ('flat', 'm'):
+        assert all(torch.equal(x, y) for x, y in zip(ra[k], rb[k])), k
+    assert ra['t'] == rb['t'] == one['t'] and ra['rec'] == rb['rec']
+    assert all(np.array_equal(x, y) for x, y in zip(ra['leaves'], rb['leaves']))
+    # against the single rank on the union: same trees, parameters within summation-order noise
+    assert [r['leaves_after'] for r in ra['rec']] == [r['leaves_after'] for r in one['rec']]
+    assert all(np.array_equal(x, y) for x, y in zip(ra['leaves'], one['leaves']))
+    assert one['rec'][0]['leaves_after'] > one['rec'][0]['leaves_before']
+    for x, y in zip(ra['flat'], one['flat']):
+        assert float((x - y).abs().max()) < 5e-4 * float(y.abs().max())
+    assert abs(ra['rec'][-1]['mse'] - one['rec'][-1]['mse']) < 1e-3 * one['rec'][-1]['mse'] + 1e-7
