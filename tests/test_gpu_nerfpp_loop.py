@@ -184,10 +184,22 @@ rank, world, local = parallel.init_from_env('cuda')
 torch.cuda.set_device(0 if torch.cuda.device_count() < world else local)
 samplers = _samplers(fastnerf)
 args = _args(fastnerf, %(base)r + '/w%%d' %% world, fused=True, perturb=0, batch_size=250, n_epoch=5, subdivide_thres=0.03)
+# (1) one batch through CascadeTrainer.step without the update: the all-reduced gradient of rows r::world with n_global
+_, m0 = fastnerf.nerfpp.create_nerf(rank, args)
+ct = fastnerf.nerfpp.CascadeTrainer([m0['net_0'], m0['net_1']], [16, 16], perturb=False)
+gen = torch.Generator().manual_seed(2)
+N = 301                                           # uneven shards
+ro = torch.from_numpy(np.concatenate([s.rays_o for s in samplers]))[torch.randperm(3 * 24 * 32, generator=gen)[:N]].cuda()
+rd = torch.from_numpy(np.concatenate([s.rays_d for s in samplers]))[torch.randperm(3 * 24 * 32, generator=gen)[:N]].cuda()
+tg = torch.rand(N, 3, generator=gen).cuda()
+sl = slice(rank, N, world)
+ct.step(ro[sl].contiguous(), rd[sl].contiguous(), tg[sl].contiguous(), n_global=N, update=False)
+grad1 = [n.flat_grad.cpu().clone() for n in ct.nets]
+# (2) the loop
 torch.manual_seed(11); np.random.seed(11)
 models, tree, rec = fastnerf.nerfpp.ddp_train_nerf(args, samplers, log=lambda *_: None, stop_after=3)
 tr = fastnerf.nerfpp.ddp_train_nerf.last_trainer
-out = {'leaves': [np.asarray(tree.leaves(i)).copy() for i in range(tree.n_images)], 'rec': rec,
+out = {'leaves': [np.asarray(tree.leaves(i)).copy() for i in range(tree.n_images)], 'rec': rec, 'grad1': grad1,
        'flat': [n.flat.cpu() for n in tr.nets], 'm': [x.cpu() for x in tr.m], 't': list(tr.t)}
 torch.save(out, %(base)r + '/res_w%%d_r%%d.pt' %% (world, rank))
 if world > 1:
@@ -225,6 +237,12 @@ def test_two_rank_loop_equals_single_rank(tmp_path):
     assert [r['leaves_after'] for r in ra['rec']] == [r['leaves_after'] for r in one['rec']]
     assert all(np.array_equal(x, y) for x, y in zip(ra['leaves'], one['leaves']))
     assert one['rec'][0]['leaves_after'] > one['rec'][0]['leaves_before']
+    # one batch, no update: the all-reduced gradient of the shards IS the single-rank gradient (summation grouping only) ...
+    for x, y in zip(ra['grad1'], one['grad1']):
+        assert float((x - y).abs().max()) < 5e-6 * float(y.abs().max())
+    assert all(torch.equal(x, y) for x, y in zip(ra['grad1'], rb['grad1']))
+    # ... whereas 36 Adam steps later the two runs have decorrelated entry by entry (Adam's lr * g / (|g| + eps) turns 1e-9 of
+    # gradient noise on |g| ~ 1e-8 entries into full-size steps); what is compared is the fit they reach
+    assert abs(ra['rec'][-1]['mse'] - one['rec'][-1]['mse']) < 0.1 * one['rec'][-1]['mse']
     for x, y in zip(ra['flat'], one['flat']):
-        assert float((x - y).abs().max()) < 5e-4 * float(y.abs().max())
-    assert abs(ra['rec'][-1]['mse'] - one['rec'][-1]['mse']) < 1e-3 * one['rec'][-1]['mse'] + 1e-7
+        assert float((x - y).norm() / y.norm()) < 0.2
