@@ -1,73 +1,134 @@
-"""The reference's training loop SHAPE on the product imports (INTEGRATION.md option A) -- run as a script by
-tests/test_gpu_reference_loop.py, twice (start, fresh-process resume).
+"""Drop-in check of INTEGRATION.md option A, run as a script by tests/test_gpu_reference_loop.py (start, then fresh-process resumes).
 
-The body restates, statement by statement, what nerf-ours/run_nerf.py does around the hot path:
-  :76-99   create_nerf's model wrapping (nn.DataParallel) + torch.optim.Adam over grad_vars
-  :109-127 checkpoint discovery / reload
-  :337-345 QuadTreeManager(...) + treeDivide_{global_epoch:04d}.pkl reload through `quadTrees`, `get_children`, `cur_level`
-  :367-423 center-crop warm-up (the coordinate count is clamped to the crop: the tiny test images are smaller than
-           N_rand*500/n_images, where the reference's np.random.choice(replace=False) would raise)
-  :436-530 epoch loop: gen_rays_v3_multiThread, render(...), img2mse x2, loss.backward(), optimizer.step(), LR rule,
-           rgb_gt_collect / rgb_pred_collect, adjust_tree_multiThread
-  :532-544 torch.save of the .tar + pickle.dump(treeManager.quadTrees) -- here through the manager's save_trees, which
-           writes the same `tree.QuadTree` pickle the reference's dump produces
-Prints one JSON line with what the test asserts on."""
+What it proves: a caller that uses the package the way nerf-ours' driver uses its own modules -- create_nerf's 6-tuple and
+render_kwargs, `render(..., retraw=True)`, `img2mse`, `loss.backward()`, a torch.optim.Adam over grad_vars with the decayed learning
+rate, QuadTreeManager.gen_rays_v3_multiThread / adjust_tree_multiThread, `{epoch:03d}.tar` + `treeDivide_{epoch:04d}.pkl` -- gets a
+working, resumable training run, and that the files it writes and the files the fused `train()` writes are interchangeable.
+
+Layout of this script (its own, not the reference's): a `Run` object holds the state; `Run.fit` is the only place that
+optimises (one list of (rays_o, rays_d, colours) in, per-batch losses and predictions out); `PLAN` below is the table of
+stages a fresh or resumed run goes through.  Reference lines the stages answer to: checkpoint discovery run_nerf.py:109-127,
+tree reload :337-345, centre-crop warm-up :367-423 (the pick count is clamped to the crop: the test images are smaller than
+N_rand * 500 / n_images, where the reference's draw without replacement would raise), epoch loop :436-530, saves :532-544.
+Prints one `LOOPLOG {json}` line."""
 import argparse
 import json
 import os
-import pickle
 import sys
 
 import numpy as np
 import torch
-import torch.nn as nn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import fastnerf                                                   # noqa: E402
-from fastnerf.run_nerf_helpers import *                           # noqa: E402,F401,F403
-from fastnerf.model import NeRF                                   # noqa: E402
-from fastnerf.render import render_rays, render_path, render      # noqa: E402,F401
-from fastnerf.tree import QuadTreeManager, get_children           # noqa: E402
+import fastnerf                                                           # noqa: E402
+from fastnerf.render import render                                        # noqa: E402
+from fastnerf.run_nerf_helpers import img2mse, mse2psnr                   # noqa: E402
+from fastnerf.tree import QuadTreeManager, get_children                   # noqa: E402
 
-device = torch.device('cuda')
+H = W = 32
+NEAR, FAR = 2., 6.
+DEV = torch.device('cuda')
 
 
-def create_nerf(args):
-    """run_nerf.py:67-153 (the reference's own function body shape, with the product NeRF)."""
-    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
-    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
-    output_ch = 5 if args.N_importance > 0 else 4
-    skips = [4]
-    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
-                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
-    model = nn.DataParallel(model, device_ids=[0])
-    grad_vars = list(model.parameters())
-    model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch, skips=skips,
-                      input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
-    model_fine = nn.DataParallel(model_fine, device_ids=[0])
-    grad_vars += list(model_fine.parameters())
-    network_query_fn = lambda inputs, viewdirs, network_fn: fastnerf.run_nerf.run_network(
-        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=args.netchunk)
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
-    start_epoch, start_iter = 0, 0
-    basedir, expname = args.basedir, args.expname
-    os.makedirs(os.path.join(basedir, expname), exist_ok=True)
-    ckpts = [os.path.join(basedir, expname, f) for f in sorted(os.listdir(os.path.join(basedir, expname))) if 'tar' in f]
-    if len(ckpts) > 0 and not args.no_reload:
-        ckpt = torch.load(ckpts[-1], weights_only=False)
-        start_epoch, start_iter = ckpt['global_epoch'], ckpt['global_iter']
-        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
-        model.load_state_dict(ckpt['network_fn_state_dict'])            # strict, DataParallel-prefixed keys
-        model_fine.load_state_dict(ckpt['network_fine_state_dict'])
-    render_kwargs_train = {'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
-                           'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
-                           'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd,
-                           'raw_noise_std': args.raw_noise_std, 'ndc': False, 'lindisp': args.lindisp}
-    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
-    render_kwargs_test['perturb'] = False
-    render_kwargs_test['raw_noise_std'] = 0.
-    return render_kwargs_train, render_kwargs_test, start_epoch, start_iter, grad_vars, optimizer
+def slices(n, size):
+    return [slice(lo, min(lo + size, n)) for lo in range(0, n, size)]
+
+
+class Run:
+    def __init__(self, cli):
+        self.args = a = fastnerf.run_nerf.make_args(
+            N_importance=16, N_samples=16, perturb=1.0, white_bkgd=True, N_rand=256, n_epoch=cli.n_epoch, init_level=2,
+            subdivide_every=1, subdivide_thres=0.05, lrate=5e-4, lrate_decay=500, basedir=cli.basedir, expname='loop', no_reload=False)
+        self.dir = os.path.join(a.basedir, a.expname)
+        os.makedirs(self.dir, exist_ok=True)
+        images, poses, focal = fastnerf.synthetic.make_dataset(n_images=4, H=H, W=W)
+        self.K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        # the newest .tar of basedir/expname, if any, is loaded by create_nerf itself (nets strict, Adam state)
+        self.kw_train, self.kw_test, self.epoch, self.iters, self.grad_vars, self.opt = fastnerf.run_nerf.create_nerf(a, device=DEV)
+        for kw in (self.kw_train, self.kw_test):
+            kw.update(near=NEAR, far=FAR)
+        self.mgr = QuadTreeManager(H, W, self.K, images, poses, mseThres=0.0, max_depth=a.init_level)
+        self.log = {'resumed_from': self.epoch, 'iter_at_start': self.iters, 'epochs': []}
+
+    # ---- the one optimisation routine ------------------------------------------------------------------------------
+    def fit(self, rays_o, rays_d, colours):
+        """Every batch of N_rand rays once: render -> fine + coarse mse -> backward -> Adam -> learning-rate rule.
+        -> (losses, [gt], [pred]) of the fine pass, on the host."""
+        a, losses, gts, preds = self.args, [], [], []
+        for s in slices(rays_o.shape[0], a.N_rand):
+            gt = colours[s].to(DEV)
+            rgb, _, _, extras = render(H, W, self.K, chunk=a.chunk, rays=torch.stack([rays_o[s].to(DEV), rays_d[s].to(DEV)], 0),
+                                       retraw=True, **self.kw_train)
+            assert extras['raw'].shape[-1] == 4 and 'rgb0' in extras
+            fine, coarse = img2mse(rgb, gt), img2mse(extras['rgb0'], gt)
+            self.opt.zero_grad()
+            (fine + coarse).backward()
+            self.opt.step()
+            for group in self.opt.param_groups:                      # rate for the NEXT step, from the count BEFORE its increment
+                group['lr'] = a.lrate * 0.1 ** (self.iters / (a.lrate_decay * 1000))
+            self.iters += 1
+            losses.append(float(fine))
+            gts.append(gt.detach().cpu())
+            preds.append(rgb.detach().cpu())
+        return losses, gts, preds
+
+    # ---- stages ----------------------------------------------------------------------------------------------------
+    def restore_trees(self):
+        path = fastnerf.run_nerf.tree_pkl_path(self.args, self.epoch)
+        self.log['loaded_tree'] = os.path.exists(path)
+        if self.log['loaded_tree']:
+            self.mgr.load_trees(path)
+            # the assignments a reference-shaped caller makes after unpickling go through the manager's settable views
+            self.mgr.quadTrees = self.mgr.quadTrees
+            self.mgr.childrens = [get_children(t.root) for t in self.mgr.quadTrees]
+            self.mgr.cur_level = self.epoch
+        self.log['leaves_at_start'] = self.leaves()
+
+    def warmup(self):
+        if self.epoch != 0:
+            return                                                    # a resumed run does not repeat it
+        rows = torch.arange(H // 2 - H // 4, H // 2 + H // 4)
+        cols = torch.arange(W // 2 - W // 4, W // 2 + W // 4)
+        grid = torch.cartesian_prod(rows, cols)
+        take = min(int(self.args.N_rand * 500 / self.mgr.n_images), grid.shape[0])
+        pick = grid[torch.from_numpy(np.random.choice(grid.shape[0], size=[take], replace=False))]
+        r, c = pick[:, 0], pick[:, 1]
+        per_image = [(self.mgr.origins[i][r, c], self.mgr.dirs[i][r, c], self.mgr.images[i][r, c]) for i in range(self.mgr.n_images)]
+        losses, _, _ = self.fit(*(torch.cat(parts, 0) for parts in zip(*per_image)))
+        self.log['warmup_loss'] = losses[-1]
+
+    def one_epoch(self, e):
+        a, m = self.args, self.mgr
+        final = e == a.n_epoch
+        if final:
+            m.epoch_size = m.n_images * m.h * m.w
+        rays = m.gen_rays_v3_multiThread(down_scale=1, prob=False, last_epoch=final) if final else \
+            m.gen_rays_v3_multiThread(down_scale=1, prob=False, randSamp_proc=a.randSamp_perc, last_epoch=False)
+        losses, gts, preds = self.fit(*rays)
+        before = sum(len(c) for c in m.childrens)
+        if a.subdivide_every > 0 and e % a.subdivide_every == 0 and e < a.n_epoch - 1:
+            m.adjust_tree_multiThread(torch.cat(gts, 0), torch.cat(preds, 0), thres=a.subdivide_thres, debug=False)
+        self.epoch = e
+        self.save()
+        self.log['epochs'].append({
+            'epoch': e, 'iters': len(losses), 'rays': int(rays[0].shape[0]), 'loss_first': losses[0],
+            'loss_last': float(np.mean(losses[-3:])), 'leaves_before': before, 'leaves_after': sum(len(c) for c in m.childrens),
+            'cur_level': m.cur_level, 'lr': self.opt.param_groups[0]['lr'], 'psnr': float(mse2psnr(torch.tensor(losses[-1])))})
+
+    def save(self):
+        ref_names = fastnerf.run_nerf.reference_state_dict          # the `module.` prefix the reference's strict load expects
+        torch.save({'global_epoch': self.epoch, 'global_iter': self.iters,
+                    'network_fn_state_dict': ref_names(self.kw_train['network_fn']),
+                    'network_fine_state_dict': ref_names(self.kw_train['network_fine']),
+                    'optimizer_state_dict': self.opt.state_dict()}, os.path.join(self.dir, '{:03d}.tar'.format(self.epoch)))
+        self.mgr.save_trees(fastnerf.run_nerf.tree_pkl_path(self.args, self.epoch))
+
+    def leaves(self):
+        return [self.mgr.leaves(i).tolist() for i in range(self.mgr.n_images)]
+
+
+PLAN = ('restore_trees', 'warmup', 'epochs')
 
 
 def main():
@@ -77,125 +138,20 @@ def main():
     ap.add_argument('--n_epoch', type=int, default=4)
     ap.add_argument('--seed', type=int, default=0)
     cli = ap.parse_args()
-    args = fastnerf.run_nerf.make_args(N_importance=16, N_samples=16, perturb=1.0, white_bkgd=True, N_rand=256,
-                                       n_epoch=cli.n_epoch, init_level=2, subdivide_every=1, subdivide_thres=0.05,
-                                       lrate=5e-4, lrate_decay=500, basedir=cli.basedir, expname='loop', no_reload=False)
     torch.manual_seed(cli.seed)
     np.random.seed(cli.seed)
-    images, poses, focal = fastnerf.synthetic.make_dataset(n_images=4, H=32, W=32)
-    H = W = 32
-    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
-    near, far = 2., 6.
-    render_kwargs_train, render_kwargs_test, global_epoch, global_iter, grad_vars, optimizer = create_nerf(args)
-    resumed_from = global_epoch
-    bds_dict = {'near': near, 'far': far}
-    render_kwargs_train.update(bds_dict)
-    render_kwargs_test.update(bds_dict)
-    N_rand = args.N_rand
-    basedir, expname = args.basedir, args.expname
-
-    treeManager = QuadTreeManager(H, W, K, images, poses, mseThres=0.0, max_depth=args.init_level)
-    tree_pkl_filename = os.path.join(args.basedir, args.expname, 'treeDivide_{:04d}.pkl'.format(global_epoch))
-    loaded_tree = False
-    if os.path.exists(tree_pkl_filename):
-        treeManager.load_trees(tree_pkl_filename)                                   # f.read + class mapping
-        treeManager.quadTrees = treeManager.quadTrees
-        treeManager.childrens = [get_children(treeManager.quadTrees[i].root) for i in range(treeManager.n_images)]
-        treeManager.cur_level = global_epoch
-        loaded_tree = True
-    leaves_at_start = [treeManager.leaves(i).tolist() for i in range(treeManager.n_images)]
-
-    log = {'resumed_from': resumed_from, 'loaded_tree': loaded_tree, 'leaves_at_start': leaves_at_start,
-           'iter_at_start': global_iter, 'epochs': []}
-
-    if global_epoch == 0:
-        dH, dW = H // 4, W // 4
-        coords = torch.stack(torch.meshgrid(torch.linspace(H // 2 - dH, H // 2 + dH - 1, 2 * dH),
-                                            torch.linspace(W // 2 - dW, W // 2 + dW - 1, 2 * dW), indexing='ij'), -1).reshape(-1, 2)
-        randNum = min(int(N_rand * 500 / treeManager.n_images), coords.shape[0])
-        select_inds = np.random.choice(coords.shape[0], size=[randNum], replace=False)
-        select_coords = coords[select_inds].long()
-        rays_o, rays_d, target_rgb = [], [], []
-        origins, dirs = treeManager.origins, treeManager.dirs                         # [n,H,W,3] like tree.py:179-180
-        for i in range(treeManager.n_images):
-            rays_o.append(origins[i][select_coords[:, 0], select_coords[:, 1]])
-            rays_d.append(dirs[i][select_coords[:, 0], select_coords[:, 1]])
-            target_rgb.append(treeManager.images[i][select_coords[:, 0], select_coords[:, 1]])
-        rays_o, rays_d, target_rgb = torch.cat(rays_o, 0), torch.cat(rays_d, 0), torch.cat(target_rgb, 0)
-        epoch_size, batch_begin, batch_end = rays_o.shape[0], 0, 0
-        while batch_end < epoch_size:
-            batch_end = min(batch_begin + N_rand, epoch_size)
-            batch_rays = torch.stack([rays_o[batch_begin:batch_end].to(device), rays_d[batch_begin:batch_end].to(device)], 0)
-            target_s = target_rgb[batch_begin:batch_end].to(device)
-            rgb, disp, acc, extras = render(H, W, K, chunk=args.chunk, rays=batch_rays, retraw=True, **render_kwargs_train)
-            optimizer.zero_grad()
-            img_loss = img2mse(rgb, target_s)
-            loss = img_loss + img2mse(extras['rgb0'], target_s)
-            loss.backward()
-            optimizer.step()
-            batch_begin = batch_end
-        log['warmup_loss'] = float(img_loss)
-
-    for epoch_id in range(global_epoch + 1, args.n_epoch + 1):
-        if epoch_id == args.n_epoch:
-            treeManager.epoch_size = treeManager.n_images * treeManager.h * treeManager.w
-            rays_o, rays_d, target_rgb = treeManager.gen_rays_v3_multiThread(down_scale=1, prob=False, last_epoch=True)
-        else:
-            rays_o, rays_d, target_rgb = treeManager.gen_rays_v3_multiThread(down_scale=1, prob=False,
-                                                                             randSamp_proc=args.randSamp_perc, last_epoch=False)
-        epoch_size, batch_begin, batch_end, it = rays_o.shape[0], 0, 0, 0
-        rgb_gt_collect, rgb_pred_collect, losses = [], [], []
-        while batch_end < epoch_size:
-            batch_end = min(batch_begin + N_rand, epoch_size)
-            batch_origins = rays_o[batch_begin:batch_end].to(device)
-            batch_dirs = rays_d[batch_begin:batch_end].to(device)
-            target_s = target_rgb[batch_begin:batch_end].to(device)
-            batch_rays = torch.stack([batch_origins, batch_dirs], 0)
-            rgb, disp, acc, extras = render(H, W, K, chunk=args.chunk, rays=batch_rays, retraw=True, **render_kwargs_train)
-            optimizer.zero_grad()
-            img_loss = img2mse(rgb, target_s)
-            trans = extras['raw'][..., -1]
-            loss = img_loss
-            psnr = mse2psnr(img_loss.cpu())
-            if 'rgb0' in extras:
-                img_loss0 = img2mse(extras['rgb0'], target_s)
-                loss = loss + img_loss0
-                psnr0 = mse2psnr(img_loss0.cpu())
-            loss.backward()
-            optimizer.step()
-            decay_rate = 0.1
-            decay_steps = args.lrate_decay * 1000
-            new_lrate = args.lrate * (decay_rate ** (global_iter / decay_steps))
-            for param_group in optimizer.param_groups:
-                param_group['lr'] = new_lrate
-            rgb_gt_collect.append(target_s.cpu().detach())
-            rgb_pred_collect.append(rgb.cpu().detach())
-            losses.append(float(img_loss))
-            global_iter += 1
-            it += 1
-            batch_begin = batch_end
-        n_before = sum(len(c) for c in treeManager.childrens)
-        if args.subdivide_every > 0 and epoch_id % args.subdivide_every == 0 and epoch_id < args.n_epoch - 1:
-            rgb_gt = torch.cat(rgb_gt_collect, 0)
-            rgb_pred = torch.cat(rgb_pred_collect, 0)
-            treeManager.adjust_tree_multiThread(rgb_gt, rgb_pred, thres=args.subdivide_thres, debug=False)
-        path = os.path.join(basedir, expname, '{:03d}.tar'.format(epoch_id))
-        torch.save({'global_epoch': epoch_id, 'global_iter': global_iter,
-                    'network_fn_state_dict': render_kwargs_train['network_fn'].state_dict(),
-                    'network_fine_state_dict': render_kwargs_train['network_fine'].state_dict(),
-                    'optimizer_state_dict': optimizer.state_dict()}, path)
-        tree_pkl_filename = os.path.join(args.basedir, args.expname, 'treeDivide_{:04d}.pkl'.format(epoch_id))
-        treeManager.save_trees(tree_pkl_filename)
-        log['epochs'].append({'epoch': epoch_id, 'iters': it, 'rays': int(epoch_size), 'loss_first': losses[0],
-                              'loss_last': float(np.mean(losses[-3:])), 'leaves_before': n_before,
-                              'leaves_after': sum(len(c) for c in treeManager.childrens), 'cur_level': treeManager.cur_level,
-                              'lr': optimizer.param_groups[0]['lr'], 'psnr': float(psnr[0])})
-        if cli.stop_after and epoch_id >= cli.stop_after:
-            break
-    log['leaves_at_end'] = [treeManager.leaves(i).tolist() for i in range(treeManager.n_images)]
-    log['global_iter'] = global_iter
-    log['adam_step'] = int(float(optimizer.state_dict()['state'][0]['step']))
-    print('LOOPLOG ' + json.dumps(log))
+    run = Run(cli)
+    for stage in PLAN:
+        if stage != 'epochs':
+            getattr(run, stage)()
+            continue
+        for e in range(run.epoch + 1, run.args.n_epoch + 1):
+            run.one_epoch(e)
+            if cli.stop_after and e >= cli.stop_after:
+                break
+    run.log.update(leaves_at_end=run.leaves(), global_iter=run.iters,
+                   adam_step=int(float(run.opt.state_dict()['state'][0]['step'])))
+    print('LOOPLOG ' + json.dumps(run.log))
 
 
 if __name__ == '__main__':

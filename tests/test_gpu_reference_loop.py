@@ -1,7 +1,8 @@
-"""INTEGRATION.md option A end to end: the reference's epoch loop (tests/ref_loop_driver.py restates
-run_nerf.py:67-153, 337-345, 367-546 on the product imports, incl. `from ... import QuadTreeManager, get_children`)
-runs 4 epochs on the synthetic set with a save -> FRESH-PROCESS resume after epoch 2; the .tar and treeDivide pkl
-files written by that loop load in the fused train() path and in a reference-shaped reader, and vice versa."""
+"""INTEGRATION.md option A end to end: tests/ref_loop_driver.py uses the package the way the reference's driver uses its own
+modules (create_nerf's 6-tuple, render(retraw=True), img2mse, loss.backward(), torch.optim.Adam, the decayed learning rate,
+`from ... import QuadTreeManager, get_children`, .tar / treeDivide pkl files) for 4 epochs on the synthetic set with a save ->
+FRESH-PROCESS resume after epoch 2; the files written by that loop load in the fused train() path and in a reference-shaped
+reader, and vice versa."""
 import json
 import os
 import pickle

@@ -145,8 +145,12 @@ def test_train_step_g8_gradients_against_the_reference(fn, golden_dir, math_mode
     assert np.abs(out['z0'].cpu().numpy() - g['z0']).max() <= 1e-6            # coarse depths: the reference's to an ulp
     zf = out['z_vals'].cpu().numpy()
     moved = np.abs(zf - g['z_vals']) > 2e-5                                   # the fine depths are NOT: most agree,
-    assert moved.mean() < 0.10 and np.abs(zf - g['z_vals']).max() < 0.2       # a few sit an inverse-CDF bin away (and shift their
-                                                                              # neighbours' ranks in the sorted list)
+    # measured (round 4, recorded by this test): 3.58 % of the fine depths move (4.89 % in the narrower bf16x3 mode), none by more than
+    # 1.4e-3 (2.0e-3) -- a few sit an inverse-CDF bin away and shift their neighbours' ranks in the sorted list.  Gated at twice that.
+    frac, far = float(moved.mean()), float(np.abs(zf - g['z_vals']).max())
+    print('G8 fine depths moved by > 2e-5: %.4f of the samples (mode %s), max %.4f' % (frac, math_mode, far))
+    lim_frac, lim_far = (0.098, 4.0e-3) if math_mode == 'bf16x3' else (0.072, 2.8e-3)
+    assert frac < lim_frac and far < lim_far, (frac, far)
     shapes = O.nerf_param_shapes()
 
     def check(flat, pre):
