@@ -23,6 +23,9 @@ Everything else rides in the same JSON line as named sibling blocks and never fe
   drop_in_route      INTEGRATION option A, the reference's loop verbatim (render(); loss.backward(); torch.optim.Adam.step());
   psnr_vs_cpu        the metric's second half: PSNR after N iterations on the analytic scene, GPU (both modes) vs the CPU
                      oracle on identical batches / injected randoms (SURVEY 8d "PSNR runs");
+  other_configs      BASELINE configs[2] (quadtree train() end to end), [3] (LLFF / NDC, 64+64, sigma noise), [4] (nerf++ cascade,
+                     1920 rays) at the headline arithmetic on ONE GPU, each with the roofline of its dominant launch (timed live) and a
+                     short CPU-oracle baseline at the same shape;
   inference          render()-style rays/s;   cpu_baseline   the CPU oracle timed on this box's host cores.
 
   python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
@@ -53,14 +56,18 @@ BWD_FLOP_PER_POINT = 2 * (2 * MAC_PER_POINT - 35712)   # dX (without the input-s
 TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + S1)  # 893.2 MFLOP
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 matrix peak
-PROFILE_ROUND = 'r03'
+PROFILE_ROUND = 'r04'
 MAIN_MODE = 'bf16x6'                        # the headline's arithmetic: fp32-width products on the bf16 matrix cores (docstring)
-MODE_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 1.0, 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'mlp_fwd_kernel', ''),
+MODE_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 1.0, 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'mlp_fwd_kernel', ', 0'),
              'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6.0, 6.0, 'dense bf16 MFMA 2500 TFLOP/s / 6 piece products per fp32 product', 'mlp_fwd_kernel', ', 1'),
              'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 3.0, 'dense bf16 MFMA 2500 TFLOP/s / 3 split terms per product', 'mlp_fwd_bf16_kernel', '')}
 H = W = 800
 FOCAL = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
 PSNR_ITERS, PSNR_RAYS, PSNR_HELD_OUT = 200, 512, 2048
+MAC_PER_POINT_BG = MAC_PER_POINT + 2 * 21 * 256   # nerf++ background MLPNet: 84 instead of 63 input channels into layers 0 and 5
+# measured ceiling of a bare v_mfma_f32_32x32x16_bf16 stream on uniform(-1, 1) data (tools/micro/mfma_power.hip, gap_probe.hip:
+# 1848 - 1871 TFLOP/s issued at the 1.79 GHz the power management grants it) -- a REPO CONSTANT from earlier runs, not measured here
+BF16_MFMA_REAL_DATA_TFLOPS = 1871.0
 
 
 def cpu_model():
@@ -83,9 +90,10 @@ def cpu_threads():
 
 def cpu_baseline(protocol='full'):
     """The CPU oracle (a port of the reference's step, validated against it by tests/) timed on the host cores of this
-    box, SURVEY 8(d): the identical step (64+128 samples, fp32) at N = 1024 rays, 2 warm-up + 6 timed steps, median, with 32
+    box, SURVEY 8(d): the identical step (64+128 samples, fp32) at N = 1024 rays, 3 warm-up + 10 timed steps, median, with 32
     threads (where torch's CPU GEMMs peak on this box: 64 / 128 / 256 threads measured 0.47x / 0.24x / 0.003x in round 2,
-    tools/cpu_threads_probe.py); one step at N = 4096 as a confirmation.  About 40 s.  `short` = 1 + 3 steps of 256 rays."""
+    tools/cpu_threads_probe.py -- the one deviation from 8(d)'s "all cores", which would time a slower baseline); one step at
+    N = 4096 as a confirmation.  About 55 s.  `short` = 1 + 3 steps of 256 rays."""
     from oracle import nerf_oracle as O
     avail, t32 = cpu_threads()
     gen = torch.Generator().manual_seed(0)
@@ -114,14 +122,76 @@ def cpu_baseline(protocol='full'):
                     sample=f'1 warm-up + 3 timed steps of 256 rays x (64+128) samples, median, torch CPU fp32, {t32} threads '
                            '(oracle/nerf_oracle.py train_step)')
         return base
-    v1024 = run(1024, t32, 2, 6)
+    v1024 = run(1024, t32, 3, 10)
     v4096 = run(4096, t32, 0, 1)
     base.update(value=v1024, rays_per_s_n1024=v1024, rays_per_s_n4096=v4096,
                 more_threads='measured slower in round 2 on this CPU model: 64 threads 0.47x, 128 threads 0.24x, all 256 hardware '
                              'threads ~1 ray/s (tools/cpu_threads_probe.py); not repeated per run',
-                sample=f'SURVEY 8(d): N=1024 rays x (64+128) samples per step, 2 warm-up + 6 timed steps, median, torch CPU fp32 '
+                sample=f'SURVEY 8(d): N=1024 rays x (64+128) samples per step, 3 warm-up + 10 timed steps, median, torch CPU fp32 '
                        f'with {t32} threads; one step at N=4096 (oracle/nerf_oracle.py train_step)')
     return base
+
+
+def cpu_baseline_llff():
+    """configs[3] shape on the host cores: NDC rays of a 1008 x 756 forward-facing camera, 64 + 64 samples, raw_noise_std = 1
+    (oracle/nerf_oracle.py train_step), 1 warm-up + 3 timed steps of 1024 rays, median."""
+    from oracle import nerf_oracle as O
+    _, t32 = cpu_threads()
+    torch.set_num_threads(t32)
+    gen = torch.Generator().manual_seed(0)
+    sdc, sdf = O.init_nerf_params(gen), O.init_nerf_params(gen)
+    opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
+    Hl, Wl, fl = 756, 1008, 815.13
+    ro, rd = O.get_rays(Hl, Wl, O.intrinsics(Hl, Wl, fl), torch.eye(4)[:3, :4])
+    n = 1024
+    sel = torch.randint(0, Hl * Wl, (n,), generator=gen)
+    rb = O.make_ray_batch(ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel], 0.0, 1.0, Hl, Wl, fl, ndc=True)
+    tgt = torch.rand(n, 3, generator=gen)
+    times = []
+    for it in range(4):
+        t_rand, u = torch.rand(n, 64, generator=gen), torch.rand(n, 64, generator=gen)
+        n0, n1 = torch.randn(n, 64, generator=gen), torch.randn(n, 128, generator=gen)
+        t0 = time.time()
+        O.train_step(sdc, sdf, opt, rb, tgt, 64, 64, False, t_rand=t_rand, u=u, noise0=n0, noise1=n1)
+        times.append(time.time() - t0)
+    return {'value': n / float(np.median(times[1:])), 'unit': 'rays/s', 'cores': t32, 'kind': 'port',
+            'sample': '1 warm-up + 3 timed steps of 1024 NDC rays x (64+64) samples with sigma noise, median (oracle/nerf_oracle.py)'}
+
+
+def cpu_baseline_nerfpp():
+    """configs[4] shape on the host cores: one two-level cascade batch (64 / 128 samples: 512 MLP evaluations per ray through the fg
+    and the 4-D inverted-sphere bg net) + Adam per level (oracle/nerfpp_oracle.py cascade_step), 1 warm-up + 3 timed batches of
+    240 rays, median."""
+    from oracle import nerf_oracle as O
+    from oracle import nerfpp_oracle as OP
+    _, t32 = cpu_threads()
+    torch.set_num_threads(t32)
+    gen = torch.Generator().manual_seed(0)
+
+    def init(input_ch):
+        sd = {}
+        for name, shp in OP.mlpnet_param_shapes(input_ch):
+            fan_in = shp[1] if len(shp) == 2 else 256
+            sd[name] = (torch.rand(shp, generator=gen) * 2 - 1) / fan_in ** 0.5
+        return sd
+    levels = [(init(63), init(84)) for _ in range(2)]
+    opts = [O.Adam(list(fg.values()) + list(bg.values()), lr=5e-4) for fg, bg in levels]
+    n = 240
+    ro = (torch.rand(n, 3, generator=gen) - 0.5) * 0.6
+    rd = torch.randn(n, 3, generator=gen)
+    tgt = torch.rand(n, 3, generator=gen)
+    times = []
+    for it in range(4):
+        rand = [{'fg_t': torch.rand(n, 64, generator=gen), 'bg_t': torch.rand(n, 64, generator=gen)},
+                {'fg_u': torch.rand(n, 128, generator=gen), 'bg_u': torch.rand(n, 128, generator=gen)}]
+        t0 = time.time()
+        outs = OP.cascade_step(levels, ro, rd, tgt, [64, 128], rand)
+        for m, o in enumerate(outs):
+            opts[m].step(o[1])
+        times.append(time.time() - t0)
+    return {'value': n / float(np.median(times[1:])), 'unit': 'rays/s', 'cores': t32, 'kind': 'port',
+            'sample': '1 warm-up + 3 timed cascade batches of 240 rays (2 levels x (fg + bg), 64 / 128 samples) + Adam, median '
+                      '(oracle/nerfpp_oracle.py)'}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -392,16 +462,119 @@ def main():
             pass
         roof = {'bound': 'mfma', 'kernel': dom['kernel'] + ' (fine pass; ' + dom['what'] + ')', 'achieved': dom['achieved'],
                 'peak': peak, 'unit': 'TFLOP/s', 'frac': dom['frac'],
-                'peak_note': peak_note,
+                'peak_note': peak_note, 'measured_in_this_run': ['achieved', 'frac', 'avg_launch_ms', 'launches'],
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/%s_pmc_traffic.json)' % PROFILE_ROUND,
+                'traffic_source': 'REPO CONSTANT: read from the committed PMC passes (separate rocprofv3 --pmc runs of the same workload), '
+                                  'not collected in this run',
                 'step_traffic': step_traffic, 'avg_launch_ms': dom['avg_launch_ms'], 'flop_per_launch': dom['flop_per_launch'],
                 'mfma_tflops_issued': n_prod * dom['achieved'], 'launches': rows}
         if mode != 'fp32':
             # tools/micro/mfma_power.hip: a saturated v_mfma_f32_32x32x16_bf16 stream holds 2.24-2.38 GHz on constant operands
             # but only 1.79 GHz = 1871 TFLOP/s on uniform(-1,1) bf16 data (power management)
-            roof['peak_measured_real_data'] = 1871.0 / n_prod
-            roof['frac_of_measured_peak'] = dom['achieved'] / (1871.0 / n_prod)
+            roof['peak_measured_real_data'] = BF16_MFMA_REAL_DATA_TFLOPS / n_prod
+            roof['peak_measured_real_data_source'] = 'REPO CONSTANT (tools/micro/mfma_power.hip on an earlier box), not measured in this run'
+            roof['frac_of_measured_peak'] = dom['achieved'] / (BF16_MFMA_REAL_DATA_TFLOPS / n_prod)
         return roof
+
+    def launch_roofline(kernel, what, fn_, flop, mode):
+        """roofline block of ONE launch timed live with HIP events (the dominant kernel of a sibling config)."""
+        peak = MODE_PEAK[mode][0]
+        ms = time_launch(fn_, 5)
+        ach = flop / (ms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': kernel + ' (' + what + ')', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                'avg_launch_ms': ms, 'flop_per_launch': flop, 'traffic': None, 'peak_note': MODE_PEAK[mode][2]}
+
+    # =====================================================================================================================
+    # BASELINE configs[2], [3], [4] at the headline arithmetic (siblings: never `value`)
+    # =====================================================================================================================
+    def config2_quadtree():
+        """configs[2]: the whole epoch loop of run_nerf.train() with quadtree ray selection -- per-epoch one-launch ray generation from
+        the leaf plans, fused steps feeding the on-device leaf-error table, tree adjustment -- END TO END incl. all host work."""
+        ops.set_math(MAIN_MODE)
+        fastnerf.render.set_compact('0')
+        Hq = Wq = 400
+        imgs, qposes, focal = synthetic.make_dataset(n_images=10, H=Hq, W=Wq, device='cuda')
+        torch.manual_seed(0); np.random.seed(0)
+        qa = fastnerf.run_nerf.make_args(N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, perturb=1.0, white_bkgd=True, no_reload=True,
+                                         N_rand=N_RAYS, n_epoch=3, init_level=2, subdivide_every=1, subdivide_thres=0.02, lrate=5e-4,
+                                         lrate_decay=500)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, qtr, mgr, hist = fastnerf.run_nerf.train(imgs, qposes, Hq, Wq, focal, qa, log=lambda *_: None, compat_rng=False)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        epochs = [{'epoch': ep, 'steps': it, 'seconds': sec, 'rays_per_s': it * N_RAYS / sec, 'psnr_db': float(psnr)} for ep, it, _, psnr, sec in hist]
+        rays = sum(e['steps'] for e in epochs) * N_RAYS
+        secs = sum(e['seconds'] for e in epochs)
+        return {'workload': 'BASELINE configs[2]: nerf-ours with quadtree adaptive ray selection, 10 analytic views of 400x400, init_level 2, '
+                            'subdivide every epoch (thres 0.02), 4096 rays x (64+128) samples per step, 3 epochs incl. centre-crop warm-up, '
+                            'device ray generation (compat_rng=False), plain backward', 'math_mode': MAIN_MODE,
+                'value': rays / secs, 'unit': 'rays/s', 'what': 'rays trained per second of epoch wall time: ray generation, fused steps, leaf '
+                'table, tree adjustment, all host work included', 'epochs': epochs, 'wall_seconds_incl_warmup_and_setup': wall,
+                'leaves_max': int(mgr.max_leaves()), 'fraction_of_headline_step_rate': (rays / secs) / (n_step * a.steps / dt),
+                'roofline': dict(roof, note='the step is the headline step (same kernels, same 4096 x 192 fine pass): its roofline block applies')}
+
+    def config3_llff():
+        """configs[3] shape on one GPU: forward-facing cameras of 1008 x 756, NDC rays, 64 + 64 samples, raw_noise_std = 1."""
+        ops.set_math(MAIN_MODE)
+        fastnerf.render.set_compact('0')
+        Hl, Wl, fl = 756, 1008, 815.13
+        Kl = np.array([[fl, 0, 0.5 * Wl], [0, fl, 0.5 * Hl], [0, 0, 1]])
+        torch.manual_seed(0)
+        la = fastnerf.run_nerf.make_args(N_importance=64, N_samples=64, perturb=1.0, raw_noise_std=1.0, no_reload=True, dataset_type='llff',
+                                         lrate=5e-4, lrate_decay=250)
+        lk = fastnerf.run_nerf.create_nerf(la, device=dev)[0]
+        lposes = torch.eye(4)[None, :3, :4].repeat(20, 1, 1)
+        lposes[:, 0, 3] = torch.linspace(-0.3, 0.3, 20)
+        g = torch.Generator().manual_seed(1)
+        lb = []
+        for _ in range(8):
+            pix = torch.stack([torch.randint(0, 20, (N_RAYS,), generator=g), torch.randint(0, Hl, (N_RAYS,), generator=g),
+                               torch.randint(0, Wl, (N_RAYS,), generator=g)], 1).int().to(dev)
+            lb.append(ops.gen_rays_pixels(pix, lposes.to(dev), Kl) + (torch.rand(N_RAYS, 3, generator=g).to(dev),))
+        ltr = fastnerf.run_nerf.Trainer(lk, Hl, Wl, Kl, 0.0, 1.0, lrate=5e-4, lrate_decay=250)
+        assert ltr.ndc and ltr.raw_noise_std == 1.0
+        tl_, ll_, _ = timed(lambda i: ltr.step(*lb[i % 8])[0], 0, 3, 20)
+        P = N_RAYS * 128
+        rays11 = ops.pack_rays(lb[0][0], lb[0][1], 0.0, 1.0)
+        z = torch.sort(torch.rand(N_RAYS, 128, device=dev), -1).values
+        act, raw = torch.empty(ops.act_floats(P), device=dev), torch.empty(N_RAYS, 128, 4, device=dev)
+        blk = leg(tl_, 20, warmup=3, backward='plain', final_loss=[float(x) for x in ll_.tolist()])   # (siblings run at world == 1)
+        blk.update(workload='BASELINE configs[3] shape, ONE GPU (the config names 8): LLFF-like forward-facing cameras 1008x756, NDC rays, 4096 '
+                            'rays x (64+64) samples per step, raw_noise_std=1, U[0,1) targets, random-init nets, plain backward',
+                   math_mode=MAIN_MODE,
+                   roofline=launch_roofline('mlp_fwd_kernel<true, false, 1>', 'fine pass, saves activations, %d points' % P,
+                                            lambda: ops.mlp_fwd(rays11, z, ltr.net_f.flat, ltr.pf[0], act=act, raw=raw), P * FWD_FLOP_PER_POINT, MAIN_MODE))
+        return blk
+
+    def config4_nerfpp():
+        """configs[4] shape on one GPU: the nerf++ cascade batch (2 levels x (fg + bg) nets, 64 / 128 samples) at the config's 1920 rays."""
+        from fastnerf import nerfpp
+        ops.set_math(MAIN_MODE)
+        torch.manual_seed(0)
+        nets = [nerfpp.NerfNet(device=dev) for _ in range(2)]
+        ptr_ = nerfpp.CascadeTrainer(nets, cascade_samples=(64, 128))
+        g = torch.Generator().manual_seed(1)
+        n = 1920
+        pb_ = [(((torch.rand(n, 3, generator=g) - 0.5) * 0.6).to(dev), torch.randn(n, 3, generator=g).to(dev), torch.rand(n, 3, generator=g).to(dev))
+               for _ in range(8)]
+        tp_, lp_, _ = timed(lambda i: ptr_.step(*pb_[i % 8])[0], 0, 3, 10)
+        P = n * 192
+        rays11 = ops.pack_rays(pb_[0][0], pb_[0][1], 0.0, 0.0)
+        zb = torch.sort(torch.rand(n, 192, device=dev), -1).values
+        bg = nets[1].bg_net
+        act = torch.empty(ops.act_floats(P, 2), device=dev)
+        blk = {'ms_per_step': 1e3 * tp_ / 10, 'value': n * 10 / tp_, 'unit': 'rays/s', 'steps': 10, 'warmup': 3,
+               'final_loss': [float(x) for x in lp_.tolist()],
+               'workload': 'BASELINE configs[4] shape, ONE GPU (the config names 8): nerf++-ours inverted-sphere fg / bg dual MLP, cascade of 2 '
+                           'levels (64, then 64+128 samples per net): 512 MLP evaluations per ray, 1920 rays per batch (the config\'s batch), random '
+                           'cameras inside the unit sphere, U[0,1) targets, Adam per level (CascadeTrainer: the engine of the sharded ddp_train_nerf)',
+               'math_mode': MAIN_MODE,
+               'roofline': launch_roofline('mlp_fwd_kernel<true, true, 1>', 'level-1 background net, 4-D inverted-sphere encoding, saves activations, '
+                                           '%d points' % P,
+                                           lambda: ops.mlp_fwd(rays11, zb, bg.flat, bg.packed(refresh=False)[0], act=act, kind=2),
+                                           P * 2 * MAC_PER_POINT_BG, MAIN_MODE)}
+        return blk
 
     # =====================================================================================================================
     # headline: fp32-width arithmetic (MAIN_MODE), SURVEY 8(d) protocol, plain backward
@@ -435,7 +608,7 @@ def main():
     # =====================================================================================================================
     # siblings (1 GPU, rank 0): never part of `value`
     # =====================================================================================================================
-    split_block = fp32_block = drop_in = infer = psnr_block = None
+    split_block = fp32_block = drop_in = infer = psnr_block = cfg_blocks = None
     trb = kte_b = kte_32 = None
     if not a.no_siblings:
         # ---- the same protocol (random init, noise targets, plain backward) in the other two modes; every rank takes part -----
@@ -532,6 +705,9 @@ def main():
                 'train_psnr_std_db': float(np.std([e['train_psnr_db'] for e in ens], ddof=1)),
                 'held_out_psnr_std_db': float(np.std([e['held_out_psnr_db'] for e in ens], ddof=1))}
 
+        # ---- the other BASELINE configs at the headline arithmetic --------------------------------------------------------------
+        cfg_blocks = {'configs[2]_quadtree': config2_quadtree(), 'configs[3]_llff_ndc': config3_llff(), 'configs[4]_nerfpp': config4_nerfpp()}
+
         # ---- inference rays/s (render_path-style, perturb=0, no saved activations) -------------------------------
         ops.set_math(MAIN_MODE)
         n_inf = 32768
@@ -584,6 +760,14 @@ def main():
                     if p and os.path.exists(p):
                         os.remove(p)
             cpu = cpu_baseline(a.cpu_protocol)
+            if cfg_blocks is not None:
+                cfg_blocks['configs[2]_quadtree']['cpu_baseline'] = dict(
+                    cpu, note='the step of configs[2] is configs[1]\'s (the quadtree only chooses the rays): the same CPU figure; the reference\'s '
+                              'host-side quadtree work is not timed on top')
+                cfg_blocks['configs[3]_llff_ndc']['cpu_baseline'] = cpu_baseline_llff()
+                cfg_blocks['configs[4]_nerfpp']['cpu_baseline'] = cpu_baseline_nerfpp()
+                for b in cfg_blocks.values():
+                    b['vs_cpu_baseline'] = b['value'] / b['cpu_baseline']['value']
         rays_per_s = n_step * a.steps / dt
         out = {
             'metric': 'training rays/sec (Lego-like 800x800, 64+128 samples) + PSNR@N-iters', 'value': rays_per_s, 'unit': 'rays/s',
@@ -599,7 +783,7 @@ def main():
                        'rays_per_gpu_per_step': n_local, 'rays_per_step': n_step, 'parallelism': f'dp{world}'},
             'device': {'name': torch.cuda.get_device_name(dev), 'compute_units': torch.cuda.get_device_properties(dev).multi_processor_count},
             'final_loss': [float(x) for x in loss2.tolist()], 'backward': 'plain (every sample)',
-            'per_rank_ms_per_step': per_rank_ms, 'allreduce_ms': allreduce_ms,
+            'per_rank_ms_per_step': per_rank_ms, 'allreduce_ms': allreduce_ms, 'collective': parallel.collective_route(),
             'step_tflops_per_gpu': step_tflops, 'step_frac_of_peak': step_tflops / MODE_PEAK[MAIN_MODE][0],
             'step_frac_of_fp32_mfma_peak': step_tflops / FP32_MFMA_PEAK_TFLOPS,
             'step_tflops_note': 'rays/s x the algorithmic FLOPs of a step (893.2 MFLOP/ray, SURVEY 8d); the fp32-MFMA roofline of the step is '
@@ -610,6 +794,7 @@ def main():
             'fp32_mfma_mode': fp32_block,
             'split_bf16_mode': split_block,
             'drop_in_route': drop_in,
+            'other_configs': cfg_blocks,
             'inference': infer,
             'cpu_baseline': cpu,
         }

@@ -130,8 +130,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // bf16(a)
 // packed piece times (-1, 0) or (0, -1), accumulated onto x: every intermediate is exactly representable), instead of an
 // unpack (shift / mask) and a subtraction: 7 VALU instructions per pair of values.
 #ifndef X6_DOT2
-#define X6_DOT2 1
-#endif
+#define X6_DOT2 0   // 1: residuals through v_dot2c_f32_bf16 (7 instead of 11 instructions per pair, but ONE v_dot2c beside an MFMA stream costs
+#endif              //    ~20 cycles, tools/micro/gap_probe.hip; the dW kernel's backward 10.06 -> 9.92 ms with 0)
 #ifndef X6_PRIO
 #define X6_PRIO 1   // s_setprio level of a wave inside the six-product k-loops (0: none)
 #endif
@@ -287,6 +287,10 @@ __device__ __forceinline__ int eidx(int m, int k) { return m * 64 + ((((k >> 2) 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_nt(float* p, const float4& v) {
+#ifdef X6_ABL_NOSTORE   // timing-only ablation (wrong results): no saved-tensor store leaves the CU -- the upper bound of ANY scheme
+  if (v.x == 1.2345e-30f) *p = v.y;   // that writes fewer activation / gradient bytes (profiles/r04_hbm_side.md)
+  return;
+#endif
   f32x4v t = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p));
 }
@@ -546,13 +550,13 @@ __device__ __forceinline__ void split_one_pair(const float4 (&ar)[2][2], Pieces&
 #ifndef X6_PIPE_VP
 #define X6_PIPE_VP (X6_PIPE_DOT2 ? 8 : 11)
 #endif
-template <int I, int NM>
+template <int I, int NM, int NVALU = 8 * X6_PIPE_VP>   // NM MFMAs with NVALU VALU instructions spread evenly between them
 __device__ __forceinline__ void interleave6() {
   if constexpr (I < NM) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    constexpr int nv = ((I + 1) * 8 * X6_PIPE_VP) / NM - (I * 8 * X6_PIPE_VP) / NM;
+    constexpr int nv = ((I + 1) * NVALU) / NM - (I * NVALU) / NM;
     if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
-    interleave6<I + 1, NM>();
+    interleave6<I + 1, NM, NVALU>();
   }
 }
 // one k-step: the MFMAs on the pieces `pc` and the weight pieces `b`; between them the split of the raw fragments `ar` (the
@@ -597,7 +601,6 @@ __device__ __forceinline__ void gemm_seg6p(f32x16 (&acc)[2][NT], const float* __
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bptr[nt] = reinterpret_cast<const char*>(Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 192);
   unsigned blane = (unsigned)lane * 16u;
-  const int klast = nks - 1;
   auto load_a1 = [&](float4 (&a)[2][2], int mt, int ks) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -624,9 +627,11 @@ __device__ __forceinline__ void gemm_seg6p(f32x16 (&acc)[2][NT], const float* __
 #if X6_PRIO
   __builtin_amdgcn_s_setprio(X6_PRIO);
 #endif
+  const bool saving = AMODE == 0 && save_dst != nullptr;
+  // all k-step pairs but the last: look-ahead loads and splits, no branch inside (one scheduling region per stage pair)
 #pragma unroll 1
-  for (int ks = 0; ks < nks; ks += 2) {   // nks is even for every segment
-    const int k2 = ks + 2 < klast ? ks + 2 : klast, k3 = ks + 3 < klast ? ks + 3 : klast;
+  for (int ks = 0; ks < nks - 2; ks += 2) {   // nks is even for every segment
+    const int k2 = ks + 2, k3 = ks + 3;
 #ifdef X6_ABL   // timing-only ablation builds (wrong results): 1 = no weight loads in the loop, 2 = no LDS reads in the loop, 3 = both
     stage6<NT>(acc, p0, b0, ar, p1, [&](int mt) { if (!(X6_ABL & 2)) load_a1(ar, mt, k2); });
     if (!(X6_ABL & 1)) load_b(b0, k2);
@@ -640,10 +645,53 @@ __device__ __forceinline__ void gemm_seg6p(f32x16 (&acc)[2][NT], const float* __
     load_b(b1, k3);
 #endif
   }
+  // the last pair: k-step nks - 2 still splits k-step nks - 1; k-step nks - 1 has nothing left to prepare, and every load of the
+  // segment has been issued -- which is where the saving kernels stream the tile's rows out (16 rows per wave: one ds_read_b128 +
+  // one non-temporal 16-byte store each), pinned one per MFMA shadow.  Rows beyond the tile's valid count are clamped to the last
+  // valid row (it is written again with the same bytes): no branch, so the stage stays one scheduling region.
+  stage6<NT>(acc, p0, b0, ar, p1, [](int) {});
+#ifndef X6_TAIL_BURST
+#define X6_TAIL_BURST 1   // 0: the row burst behind the last MFMA instead of between the MFMAs of the last k-step
+#endif
+  if (saving && X6_TAIL_BURST) {
+    constexpr int NM = 12 * NT, ROWS = TM / NWAVES;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    const int last_row = save_valid - 1;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int i = (t * 2 + mt) * NT + nt;
+          acc[mt][nt] = mfma_bf16(piece_frag(p1, PA[t], mt), b1[nt][PB[t]], acc[mt][nt]);
+#pragma unroll
+          for (int r = (i * ROWS) / NM; r < ((i + 1) * ROWS) / NM; ++r) {
+            int m = r * NWAVES + wave;
+            m = m < last_row ? m : last_row;
+            const float4 v = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
+            store_nt(save_dst + (unsigned)(m * 256 + ((lane ^ (m & 15)) << 2)), v);
+          }
+        }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // at most one row read ...
+      __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // ... and one row store per MFMA
+    }
+  } else {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(piece_frag(p1, PA[t], mt), b1[nt][PB[t]], acc[mt][nt]);
+  }
 #if X6_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
-  if (AMODE == 0 && save_dst != nullptr) {   // the tile's rows, streamed out in one burst behind the loop's loads (see gemm_seg)
+  if (saving && !X6_TAIL_BURST) {
 #pragma unroll 4
     for (int i = 0; i < TM / NWAVES; ++i) {
       const int m = i * NWAVES + wave;
@@ -1699,6 +1747,9 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
     split_store(r0, 0, 0, ANY);
     load_raw(r0, 2, ANY);
     publish();
+    // (pinning the split of k-step q + 1 between the MFMAs of k-step q with sched_group_barrier, as gemm_seg6p does, measured equal
+    //  here: 10.06 vs 10.09 ms of backward -- the compiler only interleaves the tail, and this kernel's split is done once per value
+    //  anyway; profiles/r04_power_limit.md)
     auto pair = [&](int d, auto whole) __attribute__((always_inline)) {
       const int st = 2 * d;
       if (da_lane) { DA[lane] = dr0; dr0 = draw[ix0 * 4 + 3]; ix0 = load_ix(st + 6); }

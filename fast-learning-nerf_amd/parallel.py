@@ -105,10 +105,36 @@ class CabiComm:
 _CABI = None   # FASTNERF_COLLECTIVE=cabi: the collectives go through the C ABI instead of torch.distributed
 
 
+_CABI_NOTE = None   # why FASTNERF_COLLECTIVE=cabi was NOT honoured (shown by collective_route(), printed to stderr once)
+
+
+def collective_route():
+    """Which implementation the data-path collectives of this process go through (bench.py reports it)."""
+    if world_size() <= 1:
+        return 'none (single process)'
+    if _CABI is not None:
+        return 'cabi: RCCL behind the C ABI (csrc/comm.cpp)'
+    backend = dist.get_backend()
+    return 'torch.distributed/' + backend + ('' if _CABI_NOTE is None else ' -- FASTNERF_COLLECTIVE=cabi NOT honoured: ' + _CABI_NOTE)
+
+
 def _maybe_init_cabi(rk, world):
     """torch.distributed only carries the 128-byte RCCL id from rank 0 to the others (any backend)."""
-    global _CABI
-    if _CABI is not None or os.environ.get('FASTNERF_COLLECTIVE', 'torch') != 'cabi' or not torch.cuda.is_available():
+    global _CABI, _CABI_NOTE
+    if _CABI is not None or os.environ.get('FASTNERF_COLLECTIVE', 'torch') != 'cabi':
+        return
+    why = None
+    if not torch.cuda.is_available():
+        why = 'no GPU in this process'
+    elif world > torch.cuda.device_count():
+        # RCCL refuses two ranks of one communicator on the same device: the collectives stay on torch.distributed (whose backend the
+        # caller chose) -- said loudly, never silently
+        why = '%d ranks share %d device(s); RCCL needs one device per rank' % (world, torch.cuda.device_count())
+    if why is not None:
+        _CABI_NOTE = why
+        import sys
+        print('[fastnerf.parallel] rank %d: FASTNERF_COLLECTIVE=cabi requested but %s -> collectives through torch.distributed' % (rk, why),
+              file=sys.stderr, flush=True)
         return
     if world > 1:
         box = [CabiComm.unique_id() if rk == 0 else None]

@@ -47,6 +47,40 @@ def test_bench_two_ranks(scaling):
     assert j['psnr_vs_cpu'] is None and j['drop_in_route'] is None  # 1-GPU legs
 
 
+@pytest.mark.parametrize('scaling', ['strong', 'weak'])
+def test_bench_eight_ranks_on_what_the_box_has(scaling):
+    """Multi-GPU readiness without the hardware: `bench.py --gpus 8` launched exactly as the driver launches it.  On a box with fewer
+    than 8 GPUs the ranks share devices and the collectives run over gloo (plumbing only: 8 shards, n_local / N_global scaling, the two
+    half-buffer collectives, max-over-ranks timing, one JSON line); FASTNERF_COLLECTIVE=cabi must then fall back LOUDLY (RCCL cannot
+    put two ranks of a communicator on one device) and say so in the JSON.  No scaling number is claimed from this."""
+    env = dict(os.environ, FASTNERF_COLLECTIVE='cabi')
+    shared = torch.cuda.device_count() < 8
+    if shared:
+        env['FASTNERF_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', '29571' if scaling == 'strong' else '29573', os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2',
+           '--warmup', '1', '--sustained-steps', '0', '--no-siblings', '--scaling', scaling]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    per_gpu = 4096 if scaling == 'weak' else 512
+    assert j['n_gpus'] == 8 and j['scaling'] == scaling and j['config']['parallelism'] == 'dp8'
+    assert j['config']['rays_per_gpu_per_step'] == per_gpu and j['config']['rays_per_step'] == 8 * per_gpu
+    assert len(j['per_rank_ms_per_step']) == 8 and all(x > 0 for x in j['per_rank_ms_per_step'])
+    assert abs(j['value'] - 8 * per_gpu * 2 / (j['ms_per_step'] * 2e-3)) < 1e-6 * j['value']
+    assert j['ms_per_step'] >= max(j['per_rank_ms_per_step']) * 0.999          # MAX over ranks
+    ar = j['allreduce_ms']
+    assert ar['fine_half'] > 0 and ar['coarse_half'] > 0 and ar['whole_buffer'] > 0
+    assert all(abs(x) < 1.0 for x in j['final_loss']) and j['cpu_baseline'] is None
+    if shared:
+        assert 'NOT honoured' in j['collective'] and 'share' in j['collective'] and j['collective'].startswith('torch.distributed/gloo')
+        assert out.stderr.count('FASTNERF_COLLECTIVE=cabi requested but') == 8      # every rank said so
+    else:
+        assert j['collective'].startswith('cabi')
+
+
 _SHARD_WORKER = r"""
 import os, sys, json
 import numpy as np, torch

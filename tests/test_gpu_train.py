@@ -71,7 +71,7 @@ def test_psnr_300_iterations_both_modes(fn):
     n_iters, n_prefix, N = 300, 40, 192       # (at 60 iterations single seeds are already 0.3 dB apart)
     n_seeds, n_full = 128, 4                  # seeds 0..3 additionally run the compacted backward and the CPU oracle's prefix
     old, old_c = fn.ops.get_math(), fn.render.get_compact()
-    keys = ('fp32', 'bf16x3', 'fp32_compacted', 'bf16x3_compacted')
+    keys = ('fp32', 'bf16x3', 'bf16x6', 'fp32_compacted', 'bf16x3_compacted')
     psnr = {k: [] for k in keys + ('oracle_prefix',) + tuple(k + '_prefix' for k in keys)}
     try:
         for seed in range(n_seeds):
@@ -82,8 +82,8 @@ def test_psnr_300_iterations_both_modes(fn):
                               torch.rand(N, 16, generator=gen)))
             dsched = [(s.cuda(), t.cuda(), u.cuda()) for s, t, u in sched]
             init = None
-            for key in (keys if seed < n_full else keys[:2]):
-                fn.ops.set_math('bf16x3' if key.startswith('bf16x3') else 'fp32')
+            for key in (keys if seed < n_full else keys[:3]):
+                fn.ops.set_math(key.split('_')[0])
                 fn.render.set_compact('1' if key.endswith('compacted') else '0')
                 torch.manual_seed(seed)
                 args = fn.run_nerf.make_args(N_importance=16, N_samples=16, perturb=1.0, white_bkgd=True, no_reload=True,
@@ -116,7 +116,7 @@ def test_psnr_300_iterations_both_modes(fn):
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)
     m = {k: float(np.mean(v)) for k, v in psnr.items()}
-    a32, a16 = np.array(psnr['fp32']), np.array(psnr['bf16x3'])
+    a32, a16, a6 = np.array(psnr['fp32']), np.array(psnr['bf16x3']), np.array(psnr['bf16x6'])
     # About one seed in six never leaves the empty-scene solution within 300 iterations (the SAME seeds in both modes: a property
     # of the initial weights; training PSNR 6.5 dB), and a few sit on the edge of it, where a rounding decides between 6 and 29 dB.
     # The modes are compared on the seeds whose runs train in BOTH modes; how many collapse must agree too.
@@ -129,6 +129,15 @@ def test_psnr_300_iterations_both_modes(fn):
           'per-seed std %.3f, standard error %.3f' % (len(d), n_seeds, a32[ok].mean(), a16[ok].mean(), float(d.mean()), float(np.std(d, ddof=1)), se))
     assert se < 0.045, se                                                    # the comparison has the power to see 0.1 dB (2.2 standard errors) ...
     assert abs(float(d.mean())) < 0.1, (float(d.mean()), se)                 # ... and the modes agree within it (north_star)
+    # the headline arithmetic (bf16x6) against the fp32 FMA chain, same seeds, same statistic
+    ok6 = (a32 > 20) & (a6 > 20)
+    assert ok6.sum() >= 0.7 * n_seeds and abs(int((a32 > 20).sum()) - int((a6 > 20).sum())) <= 3, (int((a32 > 20).sum()), int((a6 > 20).sum()))
+    d6 = a6[ok6] - a32[ok6]
+    se6 = float(np.std(d6, ddof=1) / np.sqrt(len(d6)))
+    print('PSNR300 bf16x6 - fp32: %d seeds, mean per-seed difference %+.3f dB, per-seed std %.3f, standard error %.3f' % (
+        len(d6), float(d6.mean()), float(np.std(d6, ddof=1)), se6))
+    assert se6 < 0.045, se6
+    assert abs(float(d6.mean())) < 0.1, (float(d6.mean()), se6)
     for k in keys:                                                           # vs the oracle, on its prefix (before the divergence)
         assert abs(float(np.mean(psnr[k + '_prefix'][:n_full])) - m['oracle_prefix']) < 0.1, (k, m)
     # the noise floor: same arithmetic, other summation grouping (one seed moves by up to 0.4 dB, the 4-seed mean by 0.12-0.15 dB)
@@ -143,8 +152,10 @@ def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
       1. LOCKSTEP -- the GPU step taken from the CPU run's state before every iteration gives the CPU's loss (median 1e-6) and hence its
          PSNR window to < 0.01 dB (north_star's 0.1 dB with an order of magnitude to spare), in every math mode: there is no bias;
       2. the first iterations of the FREE runs agree to 1e-4 (they decorrelate later: chaotic trajectories);
-      3. at 200 iterations the CPU's free-run PSNR is a member of the GPU's own distribution: within 6 standard deviations (+ 0.1 dB)
-         of a 9-member ensemble of runs (the bench's headline mode) whose initial weights differ by a random ulp.
+      3. (reported, not asserted here) the free runs' PSNR at 200 iterations next to a 9-member ulp-jitter ensemble.  Round 4 showed
+         that such an ensemble is NOT a yardstick for another arithmetic: its members stay closer to each other than to the un-jittered
+         run (tools/psnr_jitter_study.py, profiles/r04_psnr_paired.md).  The falsifiable statement about free runs is the PAIRED test
+         over initialisation seeds against a committed CPU ensemble: test_psnr_paired_with_the_cpu_ensemble_g22.
     The CPU run takes ~5 minutes of host time (PSNR_TEST_ITERS shortens it for local runs); tests/conftest.py starts it when the
     collection is known, so it runs beside the rest of the suite."""
     import json
@@ -184,17 +195,84 @@ def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
             g = np.asarray(free[mode][1][:n0])
             c = np.asarray(cpu['losses'][:n0])
             assert np.max(np.abs(g - c) / c) < 1e-4, (mode, g, c)
-        # 3. the CPU's free run against the GPU's own run-to-run distribution
+        # 3. (the free runs' PSNR at 200 iterations is a statement about distributions: test_psnr_paired_with_the_cpu_ensemble_g22)
         for key, cpu_v in (('train_psnr_db', cpu_train), ('held_out_psnr_db', cpu_held)):
             v = np.array([e[key] for e in ens])
-            sd = float(np.std(v, ddof=1))
-            print('PSNR-vs-CPU free', key, 'cpu %.3f' % cpu_v, 'gpu %s ensemble mean %.3f std %.3f' % (B.MAIN_MODE, v.mean(), sd),
+            print('PSNR-vs-CPU free', key, 'cpu %.3f' % cpu_v, 'gpu %s ensemble mean %.3f std %.3f' % (B.MAIN_MODE, v.mean(), float(np.std(v, ddof=1))),
                   'fp32 %.3f' % free['fp32'][0][key], 'bf16x3 %.3f' % free['bf16x3'][0][key])
-            # (6 sigma + 0.1 dB: the CPU's own run-to-run scatter, measured with an 8-member CPU ensemble at 128 rays per
-            # iteration, is about twice the GPU ensemble's -- profiles/r03_psnr_ensembles.md -- with no shift of the mean)
-            assert abs(cpu_v - v.mean()) < 6 * sd + 0.1, (key, cpu_v, v.tolist())
-            for m in ('fp32', 'bf16x3'):
-                assert abs(free[m][0][key] - v.mean()) < 6 * sd + 0.1, (m, key, free[m][0][key], v.tolist())
+    finally:
+        fn.ops.set_math(old)
+        fn.render.set_compact(old_c)
+
+
+def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
+    """north_star's "PSNR within 0.1 dB at equal iteration count" as a PAIRED two-sample test at the BASELINE shape (100 cameras of
+    800 x 800, 64 + 128 samples, 200 iterations of 256 uniformly drawn rays): tests/golden/g22_psnr_cpu_ensemble.npz holds the CPU
+    oracle's PSNR for initialisation seeds 0 .. n-1 (oracle/make_golden_psnr_ensemble.py, ~2.3 minutes of 8 host cores per seed,
+    recorded once in the build container); here the GPU starts from the SAME weights (oracle/psnr_protocol.py init_weights), sees the
+    SAME batches / t_rand / u (generated on the CPU from seeds, digest checked) and the statistic is the mean over seeds of
+    PSNR_gpu(s) - PSNR_cpu(s) -- pairing removes the 3 dB that the initialisation moves a run's PSNR by; averaging each seed's GPU
+    value over 5 members (the un-jittered run + 4 whose weights carry a 1e-6 relative perturbation) removes most of the GPU side's
+    chaos.  Asserted: (a) POWER -- the standard error of the mean difference is below 0.09 dB, i.e. a 0.15 dB bias is visible at
+    >= 1.7 standard errors and a 0.25 dB bias at >= 2.8; (b) the mean difference is compatible with a bias below 0.05 dB:
+    |mean| < 0.05 + 2.6 SE (a true bias of 0.3 dB fails this with > 95 % probability); (c) runs that collapse to the empty scene
+    (PSNR < 15 dB) are the same seeds on both sides, up to two.  Both the headline arithmetic and the fp32 FMA-chain mode."""
+    import os
+    from oracle import psnr_protocol as P
+    path = os.path.join(golden_dir, 'g22_psnr_cpu_ensemble.npz')
+    z = np.load(path)
+    seeds = [int(s) for s in z['seeds']]
+    assert len(seeds) >= 24 and [int(x) for x in z['protocol']] == [P.ITERS, P.RAYS, P.HELD_OUT, P.WINDOW, P.N_SAMPLES, P.N_IMPORTANCE]
+    data = P.inputs(lambda o, d: fn.synthetic.render_rays(o, d, cutoff=0.0))
+    digest = [float(data['ro'].double().sum()), float(data['tgt'].double().sum()), float(data['u'].double().sum())]
+    assert np.allclose(digest, z['input_digest'], rtol=1e-12, atol=0), 'the inputs regenerated here are not the recorded run\'s'
+    dev = torch.device('cuda')
+    dd = {k: v.to(dev) for k, v in data.items()}
+    K = np.array([[P.FOCAL, 0, 0.5 * P.W], [0, P.FOCAL, 0.5 * P.H], [0, 0, 1]])
+    args = fn.run_nerf.make_args(N_importance=P.N_IMPORTANCE, N_samples=P.N_SAMPLES, perturb=1.0, white_bkgd=True, no_reload=True,
+                                 lrate=5e-4, lrate_decay=500)
+    old, old_c = fn.ops.get_math(), fn.render.get_compact()
+    members = 5
+
+    def gpu_run(seed, mode, member):
+        fn.ops.set_math(mode)
+        fn.render.set_compact('0')
+        ktr, kte, _, _, _, _ = fn.run_nerf.create_nerf(args, device=dev)
+        sdc, sdf = P.init_weights(seed)
+        ktr['network_fn'].load_state_dict(sdc)
+        ktr['network_fine'].load_state_dict(sdf)
+        tr = fn.run_nerf.Trainer(ktr, P.H, P.W, K, 2.0, 6.0, lrate=5e-4, lrate_decay=500)
+        if member:
+            g = torch.Generator(device=dev).manual_seed(7000 + 10 * seed + member)
+            with torch.no_grad():
+                tr.flat.mul_(1.0 + 1e-6 * torch.randn(tr.flat.shape, generator=g, device=dev))
+        tr.repack()
+        ls = []
+        for it in range(P.ITERS):
+            ls.append(tr.step(dd['ro'][it], dd['rd'][it], dd['tgt'][it], t_rand=dd['t_rand'][it], u=dd['u'][it])[0][0])
+        ls = torch.stack(ls).cpu().numpy()
+        with torch.no_grad():
+            rgb = fn.render.render(P.H, P.W, K, chunk=P.HELD_OUT, rays=(dd['ho_ro'], dd['ho_rd']), near=2.0, far=6.0, **kte)[0]
+            mse = float(torch.mean((rgb - dd['ho_tgt']) ** 2))
+        return P.psnr(np.mean(ls[-P.WINDOW:])), P.psnr(mse), float(ls[0])
+    try:
+        for mode in ('bf16x6', 'fp32'):
+            g_train, g_held = [], []
+            for i, seed in enumerate(seeds):
+                runs = [gpu_run(seed, mode, j) for j in range(members)]
+                assert abs(runs[0][2] - float(z['first_loss'][i])) < 2e-5 * float(z['first_loss'][i]) + 1e-7      # same weights, same batch
+                g_train.append([r[0] for r in runs]); g_held.append([r[1] for r in runs])
+            for name, gv, cv in (('train', np.array(g_train), z['train_psnr_db']), ('held-out', np.array(g_held), z['held_out_psnr_db'])):
+                alive_g, alive_c = gv[:, 0] > 15.0, cv > 15.0
+                assert int((alive_g != alive_c).sum()) <= 2, (mode, name, alive_g.tolist(), alive_c.tolist())
+                ok = alive_c & (gv > 15.0).all(1)
+                d = gv[ok].mean(1) - cv[ok]
+                se = float(np.std(d, ddof=1) / np.sqrt(len(d)))
+                print('G22 paired %s %s PSNR: %d of %d seeds train on both sides; CPU mean %.3f, GPU mean %.3f, mean difference %+.3f dB, per-seed std %.3f, '
+                      'standard error %.3f; within-seed GPU std %.3f' % (mode, name, len(d), len(seeds), cv[ok].mean(), gv[ok].mean(), d.mean(),
+                                                                         np.std(d, ddof=1), se, float(np.mean(np.std(gv[ok], axis=1, ddof=1)))))
+                assert len(d) >= 20 and se < 0.09, (mode, name, len(d), se)
+                assert abs(float(d.mean())) < 0.05 + 2.6 * se, (mode, name, float(d.mean()), se)
     finally:
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)

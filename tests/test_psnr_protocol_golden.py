@@ -1,0 +1,32 @@
+"""G22 (tests/golden/g22_psnr_cpu_ensemble.npz, the CPU oracle's PSNR ensemble of the paired equal-iterations protocol) is pinned to
+its generator: the inputs regenerate from their seeds to the recorded digest, and the first iteration of a recorded seed reproduces
+its first loss.  (The GPU side is tests/test_gpu_train.py::test_psnr_paired_with_the_cpu_ensemble_g22.)"""
+import importlib
+import os
+
+import numpy as np
+import torch
+
+from oracle import nerf_oracle as O
+from oracle import psnr_protocol as P
+
+
+def test_g22_inputs_and_first_loss(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'g22_psnr_cpu_ensemble.npz'))
+    assert [int(x) for x in z['protocol']] == [P.ITERS, P.RAYS, P.HELD_OUT, P.WINDOW, P.N_SAMPLES, P.N_IMPORTANCE]
+    synthetic = importlib.import_module('fast-learning-nerf_amd.synthetic')
+    data = P.inputs(lambda o, d: synthetic.render_rays(o, d, cutoff=0.0))
+    digest = [float(data['ro'].double().sum()), float(data['tgt'].double().sum()), float(data['u'].double().sum())]
+    assert np.allclose(digest, z['input_digest'], rtol=1e-12, atol=0)
+    seeds = [int(s) for s in z['seeds']]
+    assert len(seeds) >= 24 and len(set(seeds)) == len(seeds)
+    assert np.isfinite(z['train_psnr_db']).all() and np.isfinite(z['held_out_psnr_db']).all()
+    # the rays are unit-depth pinhole rays of the recorded cameras: origin on the radius-4 sphere, direction z-component -1 in camera space
+    assert np.allclose(data['ro'].norm(dim=-1).numpy(), 4.0, atol=1e-5)
+    i = len(seeds) // 2
+    sdc, sdf = P.init_weights(seeds[i])
+    opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    l1, _, _, _ = O.train_step(sdc, sdf, opt, O.make_ray_batch(data['ro'][0], data['rd'][0], 2.0, 6.0), data['tgt'][0], P.N_SAMPLES,
+                               P.N_IMPORTANCE, True, t_rand=data['t_rand'][0], u=data['u'][0])
+    assert abs(float(l1) - float(z['first_loss'][i])) < 1e-6 * float(z['first_loss'][i])
