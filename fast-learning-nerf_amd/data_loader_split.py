@@ -61,6 +61,11 @@ def shrink_linear(img, factor):
     OpenCV is not vendored or pinned by the reference: restated from its documented sampling rule, parity unpinned."""
     if factor == 1:
         return img
+    if img.shape[0] % factor or img.shape[1] % factor:
+        # the reference resizes to (W // lvl, H // lvl) with a NON-integer scale src / dst here (general bilinear sampling at
+        # (x + 0.5) * src / dst - 0.5); the block formulas below would silently crop instead and return other depths
+        raise NotImplementedError('shrink_linear: image size {}x{} is not a multiple of the resolution level {} (non-integer '
+                                  'INTER_LINEAR scales are not restated)'.format(img.shape[0], img.shape[1], factor))
     h, w = img.shape[0] // factor, img.shape[1] // factor
     c = (factor - 1) // 2
     if factor % 2:

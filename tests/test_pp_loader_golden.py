@@ -80,3 +80,8 @@ def test_min_depth_half_resolution_is_the_bilinear_sample_at_pixel_centres():
     assert np.array_equal(o3, img[1:9:3, 1:12:3])
     o4 = shrink_linear(rng.random((8, 8)).astype(np.float32), 4)
     assert o4.shape == (2, 2)
+    # a size that is not a multiple of the level means a non-integer INTER_LINEAR scale in the reference -- refused loudly,
+    # never cropped silently
+    import pytest
+    with pytest.raises(NotImplementedError):
+        shrink_linear(img[:9, :11], 2)
