@@ -761,10 +761,13 @@ __device__ __forceinline__ void h_cols(float* Hs, int wm, int wn, int lane, floa
 #define H_AT(colp, nt, mt, r) ((colp)[nt][((r) & 3) + 4 * (((r) >> 2) & 1)][((mt) * 32 + ((r) & 3) + 8 * ((r) >> 2)) * 256])
 
 // forward epilogue: + bias, optional ReLU, write H (LDS) and optionally the saved activation.
-// When `mask_out` is given (training, ReLU layers) the sign pattern of every accumulator register
-// is recorded as one 64-bit ballot; ballot i = (nt*2+mt)*16 + r is kept by lane i and the wave
-// stores its 64 words with one coalesced 512-byte access.  mlp_bwd_dx (same wave->tile mapping)
-// reads the words back instead of re-reading 1 KB/point/layer of activations.
+// When `mask_out` is given (training, ReLU layers) every lane records the sign pattern of ITS 64 accumulator values in one 64-bit word
+// -- value i = (nt*2+mt)*16 + r is bit 31 - (i & 31) of half i >> 5: `v_cmp_lt_f32 vcc, 0, v ; v_addc_co_u32 w, vcc, w, w, vcc` shifts the
+// word left and takes the compare as the new bit 0 (two instructions per value, no scalar round trip) -- and the wave stores its 64 words
+// with one coalesced 512-byte access.  mlp_bwd_dx (same wave -> tile mapping, same lane) reads its word back and masks a gradient with
+// `v_bfe_i32` + `v_and_b32`, instead of re-reading 1 KB/point/layer of activations.  (Round 3 kept wave BALLOTS, one per value, moved
+// into lane i with `s_nop 3` + two `v_writelane` and fetched in dX with two `v_readlane` + select + shift: 6 / 6 instructions per value
+// where this takes 5 / 2.)
 template <int NT>
 __device__ __forceinline__ void load_bias(float (&bv)[NT], const float* __restrict__ bias, int wn, int lane) {
 #pragma unroll
@@ -778,7 +781,7 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
                                              int wm, int wn, int lane, float* __restrict__ save, int ldsave,
                                              int valid, unsigned long long* __restrict__ mask_out = nullptr) {
   asm volatile("" : "+v"(lane));
-  int mlo = 0, mhi = 0;   // this lane's ballot word (v_writelane: no per-value branch, no select)
+  unsigned wlo = 0u, whi = 0u;   // this lane's sign word (see above)
   constexpr bool want_mask = RELU && NT == 2 && MASKS;
   float* colp[NT][8];
   h_cols<NT>(Hs, wm, wn, lane, colp);
@@ -792,26 +795,22 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
       for (int r = 0; r < 16; ++r) {
         const int m = wm * 64 + mt * 32 + crow(r, lane);
         float v = acc[mt][nt][r] + bv;
-        const bool pos = v > 0.f;
-        if (RELU && NT == 2) {
-          if (want_mask) {   // the compare's lane mask IS the ballot; lane (nt*2+mt)*16 + r keeps it
-            const unsigned long long bm = __ballot(pos);
-            // (s_nop: a v_writelane issued right behind the v_cmp that wrote its scalar source still reads the OLD value --
-            //  measured: the low words came out one value late; the hazard recogniser does not look inside inline asm)
-            asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                : "+v"(mlo), "+v"(mhi) : "s"((unsigned)bm), "s"((unsigned)(bm >> 32)), "n"((nt * 2 + mt) * 16 + r));
-          }
+        if (want_mask) {
+          // sign bit into the word, then ReLU: three instructions, vcc lives only inside the block
+          if ((nt * 2 + mt) * 16 + r < 32)
+            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_max_f32 %1, 0, %1" : "+v"(wlo), "+v"(v) : : "vcc");
+          else
+            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_max_f32 %1, 0, %1" : "+v"(whi), "+v"(v) : : "vcc");
+        } else if (RELU) {
+          v = v > 0.f ? v : 0.f;   // (one compare + select; fmaxf is two v_max: it canonicalises first)
         }
-        if (RELU) v = pos ? v : 0.f;   // (one select on the compare the mask needs anyway; fmaxf is two v_max: it canonicalises first)
         H_AT(colp, nt, mt, r) = v;
         if (save != nullptr && m < valid) save[(unsigned)(m * ldsave + n)] = v;
       }
       __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
     }
   }
-  if (RELU && NT == 2) {
-    if (want_mask) mask_out[lane] = ((unsigned long long)(unsigned)mhi << 32) | (unsigned long long)(unsigned)mlo;
-  }
+  if (want_mask) mask_out[lane] = ((unsigned long long)whi << 32) | (unsigned long long)wlo;
 }
 
 
@@ -1230,12 +1229,10 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[2][2], float* Hs
         const int m = wm * 64 + mt * 32 + crow(r, lane);
         float v = acc[mt][nt][r];
         if (RANK1) v = fmaf(Es_dalpha[m], wan, v);
-        if (MASK) {
+        if (MASK) {   // this lane's sign word of the forward (epilogue_fwd): value idx is bit 31 - (idx & 31) of half idx >> 5
           const int idx = (nt * 2 + mt) * 16 + r;
-          const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)mlo, idx);
-          const unsigned bhi = (unsigned)__builtin_amdgcn_readlane((int)mhi, idx);
-          const unsigned word = (lane & 32) ? bhi : blo;
-          v = ((word >> (lane & 31)) & 1u) ? v : 0.f;
+          const int keep = __builtin_amdgcn_sbfe(idx < 32 ? (int)mlo : (int)mhi, 31 - (idx & 31), 1);   // 0 or -1
+          v = __int_as_float(__float_as_int(v) & keep);
         }
         H_AT(colp, nt, mt, r) = v;
         if (dsave != nullptr && m < valid) dsave[(unsigned)(m * 256 + n)] = v;
