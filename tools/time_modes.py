@@ -15,7 +15,7 @@ pix = torch.stack([torch.randint(0, 100, (N,), generator=g), torch.randint(0, 80
 ro, rd = ops.gen_rays_pixels(pix.to(dev), poses, K)
 tgt = torch.rand(N, 3, generator=g).to(dev)
 args = fastnerf.run_nerf.make_args(N_importance=128, N_samples=64, perturb=1.0, white_bkgd=True, no_reload=True, lrate=5e-4, lrate_decay=500)
-fastnerf.render.set_compact('0')
+fastnerf.render.set_compact(os.environ.get('TM_COMPACT', '0'))
 for mode in modes:
     ops.set_math(mode)
     torch.manual_seed(0)
