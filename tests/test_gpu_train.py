@@ -225,7 +225,10 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
     assert len(seeds) >= 24 and [int(x) for x in z['protocol']] == [P.ITERS, P.RAYS, P.HELD_OUT, P.WINDOW, P.N_SAMPLES, P.N_IMPORTANCE]
     data = P.inputs(lambda o, d: fn.synthetic.render_rays(o, d, cutoff=0.0))
     digest = [float(data['ro'].double().sum()), float(data['tgt'].double().sum()), float(data['u'].double().sum())]
-    assert np.allclose(digest, z['input_digest'], rtol=1e-12, atol=0), 'the inputs regenerated here are not the recorded run\'s'
+    # rays and jitter streams regenerate bit for bit from their seeds; the targets go through exp / cumprod of the host's vector math
+    # library, which may differ in the last bit between CPU models (the per-seed first-loss check below bounds what that is worth)
+    assert np.allclose([digest[0], digest[2]], [z['input_digest'][0], z['input_digest'][2]], rtol=1e-12, atol=0) and \
+        abs(digest[1] - z['input_digest'][1]) < 1e-7 * abs(z['input_digest'][1]), 'the inputs regenerated here are not the recorded run\'s'
     dev = torch.device('cuda')
     dd = {k: v.to(dev) for k, v in data.items()}
     K = np.array([[P.FOCAL, 0, 0.5 * P.W], [0, P.FOCAL, 0.5 * P.H], [0, 0, 1]])
