@@ -550,13 +550,13 @@ __device__ __forceinline__ void split_one_pair(const float4 (&ar)[2][2], Pieces&
 #ifndef X6_PIPE_VP
 #define X6_PIPE_VP (X6_PIPE_DOT2 ? 8 : 11)
 #endif
-template <int I, int NM, int NVALU = 8 * X6_PIPE_VP>   // NM MFMAs with NVALU VALU instructions spread evenly between them
+template <int I, int NM, int NVALU = 8 * X6_PIPE_VP, int SYNC = 0>   // NM MFMAs with NVALU VALU instructions spread evenly between them
 __device__ __forceinline__ void interleave6() {
   if constexpr (I < NM) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, SYNC);
     constexpr int nv = ((I + 1) * NVALU) / NM - (I * NVALU) / NM;
-    if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
-    interleave6<I + 1, NM, NVALU>();
+    if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, SYNC);
+    interleave6<I + 1, NM, NVALU, SYNC>();
   }
 }
 // one k-step: the MFMAs on the pieces `pc` and the weight pieces `b`; between them the split of the raw fragments `ar` (the
@@ -1594,10 +1594,14 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
   static_assert(!(RANK1 && CTO2) && !(CTI2 && CTO2), "one second tensor per job");
   const float* tsrc[TPW];
   bool tisy[TPW], tis2[TPW];   // tis2: the tile comes from the second tensor of its side
+  // KNOWN: the wave count divides the number of dY tiles and there is no second tensor (the 256 x 256 jobs: 14 of a step's 22 launches):
+  // whether slot k holds a dY or an X tile is then the same for every wave and known at compile time -- no wave-uniform branch splits the
+  // main loop's body, which is what lets the split of k-step q + 1 be scheduled between the MFMAs of k-step q (X6_DW_PIPE below)
+  constexpr bool KNOWN = (CTO % NW == 0) && (NTILE % NW == 0) && CTO2 == 0 && CTI2 == 0;
 #pragma unroll
   for (int k = 0; k < TPW; ++k) {
     const int t = k * NW + wave;
-    tisy[k] = t < CTO;
+    tisy[k] = KNOWN ? (k * NW < CTO) : (t < CTO);
     tis2[k] = (CTI2 > 0 && t >= CTO + CTI1) || (CTO2 > 0 && t >= CTO1 && t < CTO);
     tsrc[k] = tisy[k] ? (tis2[k] ? dY2 + q0 * (16 * NO2) + (t - CTO1) * 32 : dY + q0 * (16 * NO1) + t * 32)
                       : (tis2[k] ? X2 + q0 * (16 * KI2) + (t - CTO - CTI1) * 32 : X + q0 * (16 * KI1) + (t - CTO) * 32);
@@ -1678,8 +1682,8 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
         split3_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
         uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
         d[0] = h; d[64] = m; d[128] = l;
-        if (BIAS && t < CTO1) ssum[k] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        if (RANK1 && t >= CTO) {
+        if (BIAS && (KNOWN ? (k * NW < CTO) : (t < CTO1))) ssum[k] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        if (RANK1 && (KNOWN ? (k * NW >= CTO) : (t >= CTO))) {
           const float4 d0 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8);
           const float4 d1 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8 + 4);
           const float da[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -1744,19 +1748,26 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
     split_store(r0, 0, 0, ANY);
     load_raw(r0, 2, ANY);
     publish();
-    // (pinning the split of k-step q + 1 between the MFMAs of k-step q with sched_group_barrier, as gemm_seg6p does, measured equal
-    //  here: 10.06 vs 10.09 ms of backward -- the compiler only interleaves the tail, and this kernel's split is done once per value
-    //  anyway; profiles/r04_power_limit.md)
+#ifndef X6_DW_PIPE
+#define X6_DW_PIPE 1   // the split of k-step q + 1 (it fills the OTHER buffer) spread between the MFMAs of k-step q, as in gemm_seg6p
+#endif
+    auto mix = [&](auto sync) __attribute__((always_inline)) {   // (one pipeline per half of the loop body: distinct sync ids)
+#if X6_DW_PIPE
+      if constexpr (KNOWN && !RANK1) interleave6<0, TO * TI * 6, TPW * 4 * (X6_DOT2 ? 8 : 11) + (BIAS ? 8 : 0), decltype(sync)::value>();
+#endif
+    };
     auto pair = [&](int d, auto whole) __attribute__((always_inline)) {
       const int st = 2 * d;
       if (da_lane) { DA[lane] = dr0; dr0 = draw[ix0 * 4 + 3]; ix0 = load_ix(st + 6); }
       multiply(0);
       split_store(r1, 1, st + 1, whole);
+      mix(std::integral_constant<int, 1>{});
       load_raw(r1, st + 3, whole);
       publish();
       if (da_lane) { DA[16 + lane] = dr1; dr1 = draw[ix1 * 4 + 3]; ix1 = load_ix(st + 7); }
       multiply(1);
       split_store(r0, 0, st + 2, whole);
+      mix(std::integral_constant<int, 2>{});
       load_raw(r0, st + 4, whole);
       publish();
     };

@@ -6,7 +6,7 @@ import fastnerf as fn
 from fastnerf import ops, nerfpp
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 dev = torch.device('cuda')
-for mode in ('fp32', 'bf16x3'):
+for mode in (sys.argv[2:] or ['fp32', 'bf16x3']):
     ops.set_math(mode)
     torch.manual_seed(0)
     nets = [nerfpp.NerfNet(device=dev) for _ in range(2)]
