@@ -60,7 +60,7 @@ int fastnerf_posenc(int64_t n, int L, const float* x, float* out, fn_stream_t st
 #define FASTNERF_PACKED_FWD 593920      /* floats: fragment-ordered forward weights  */
 #define FASTNERF_PACKED_BWD 557056      /* floats: fragment-ordered transposed weights */
 /* saved activations: n*S*FASTNERF_ACT_FLOATS + FASTNERF_ACT_SLACK floats
- * (per point pe64 + 8*h256 + feat256 + vpe32 + hv128 + 64 floats of ReLU ballot masks) */
+ * (per point pe64 + 8*h256 + feat256 + vpe32 + hv128 + 64 floats of ReLU sign words) */
 #define FASTNERF_ACT_FLOATS 2592
 #define FASTNERF_ACT_SLACK 8192   /* kind 0; in general use fastnerf_mlp_act_floats() */
 /* per-point pre-activation gradients (floats): 8*dY256 + dfeat256 + dYv128 */

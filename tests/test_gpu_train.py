@@ -146,16 +146,17 @@ def test_psnr_300_iterations_both_modes(fn):
 
 
 def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
-    """The metric's second half at BASELINE configs[1]'s shape: 100 cameras of 800 x 800, 64 + 128 samples, 512 uniformly drawn
-    rays per iteration, 200 iterations, identical batches / injected t_rand, u / initial weights on the GPU and on the CPU oracle
+    """The metric's second half at BASELINE configs[1]'s shape: 100 cameras of 800 x 800, 64 + 128 samples, 256 uniformly drawn
+    rays per iteration (bench.PSNR_RAYS), 200 iterations, identical batches / injected t_rand, u / initial weights on the GPU and on the CPU oracle
     (bench.py's `psnr_vs_cpu` leg: the same functions).  Three statements:
       1. LOCKSTEP -- the GPU step taken from the CPU run's state before every iteration gives the CPU's loss (median 1e-6) and hence its
          PSNR window to < 0.01 dB (north_star's 0.1 dB with an order of magnitude to spare), in every math mode: there is no bias;
       2. the first iterations of the FREE runs agree to 1e-4 (they decorrelate later: chaotic trajectories);
-      3. (reported, not asserted here) the free runs' PSNR at 200 iterations next to a 9-member ulp-jitter ensemble.  Round 4 showed
-         that such an ensemble is NOT a yardstick for another arithmetic: its members stay closer to each other than to the un-jittered
-         run (tools/psnr_jitter_study.py, profiles/r04_psnr_paired.md).  The falsifiable statement about free runs is the PAIRED test
-         over initialisation seeds against a committed CPU ensemble: test_psnr_paired_with_the_cpu_ensemble_g22.
+      3. (reported, not asserted here) the free runs' PSNR at 200 iterations.  Round 3 bounded the CPU's value by 6 sigma of a 9-member
+         ulp-jitter ensemble; round 4 showed that such an ensemble is NOT a yardstick for another arithmetic: its members stay closer to
+         each other than to the un-jittered run (tools/psnr_jitter_study.py, profiles/r04_psnr_paired.md).  The falsifiable statement
+         about free runs is the PAIRED test over initialisation seeds against a committed CPU ensemble:
+         test_psnr_paired_with_the_cpu_ensemble_g22.
     The CPU run takes ~5 minutes of host time (PSNR_TEST_ITERS shortens it for local runs); tests/conftest.py starts it when the
     collection is known, so it runs beside the rest of the suite."""
     import json
@@ -173,7 +174,6 @@ def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
         dd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
         modes = (B.MAIN_MODE, 'fp32', 'bf16x3')
         free = {m: B.psnr_gpu_free(fn, dd, new_trainer, K, m) for m in modes}
-        ens = [free[B.MAIN_MODE][0]] + [B.psnr_gpu_free(fn, dd, new_trainer, K, B.MAIN_MODE, jitter_ulp_seed=100 + j)[0] for j in range(8)]
         _, err = run['proc'].communicate()
         assert run['proc'].returncode == 0, err.decode()[-2000:]
         cpu = json.load(open(run['out']))
@@ -197,9 +197,7 @@ def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
             assert np.max(np.abs(g - c) / c) < 1e-4, (mode, g, c)
         # 3. (the free runs' PSNR at 200 iterations is a statement about distributions: test_psnr_paired_with_the_cpu_ensemble_g22)
         for key, cpu_v in (('train_psnr_db', cpu_train), ('held_out_psnr_db', cpu_held)):
-            v = np.array([e[key] for e in ens])
-            print('PSNR-vs-CPU free', key, 'cpu %.3f' % cpu_v, 'gpu %s ensemble mean %.3f std %.3f' % (B.MAIN_MODE, v.mean(), float(np.std(v, ddof=1))),
-                  'fp32 %.3f' % free['fp32'][0][key], 'bf16x3 %.3f' % free['bf16x3'][0][key])
+            print('PSNR-vs-CPU free', key, 'cpu %.3f' % cpu_v, ' '.join('%s %.3f' % (m, free[m][0][key]) for m in modes))
     finally:
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)
