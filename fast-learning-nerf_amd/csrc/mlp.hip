@@ -868,6 +868,13 @@ __device__ __forceinline__ int x2idx(int m, int k) { return m * 32 + ((((k >> 2)
 // BG == true : nerf++ background net: inverted-sphere points (4-D), samples in flipped order
 //              (ddp_model.py:118-124), 84 channels = 64 in E + 20 (padded to 32) in the X2 block that
 //              borrows the first 8 KiB of H while H is free (L0) or after it has been consumed (L5).
+#ifdef X6_ABL_NOPE   // timing-only ablation (wrong results): the positional encoding without its sines and cosines
+#define FN_SIN(a) (a)
+#define FN_COS(a) (a)
+#else
+#define FN_SIN(a) sinf(a)
+#define FN_COS(a) cosf(a)
+#endif
 template <bool SAVE, bool BG, int MM = MM_F32>
 __global__ void __launch_bounds__(NTHR, 2 * NTHR / 512 * WG_PER_CU)
 mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __restrict__ zv,
@@ -909,11 +916,11 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     float x4[4] = {0.f, 0.f, 0.f, 0.f};   // BG: kept live for the L5 re-encode of channels 64..83
     auto write_x2 = [&]() {               // channels 64..95 of the 4-D encoding, dimension pq of row pm
       const float xv = x4[pq];
-      X2[x2idx(pm, 0 + pq)] = cosf(fmul(xv, 128.0f));
-      X2[x2idx(pm, 4 + pq)] = sinf(fmul(xv, 256.0f));
-      X2[x2idx(pm, 8 + pq)] = cosf(fmul(xv, 256.0f));
-      X2[x2idx(pm, 12 + pq)] = sinf(fmul(xv, 512.0f));
-      X2[x2idx(pm, 16 + pq)] = cosf(fmul(xv, 512.0f));
+      X2[x2idx(pm, 0 + pq)] = FN_COS(fmul(xv, 128.0f));
+      X2[x2idx(pm, 4 + pq)] = FN_SIN(fmul(xv, 256.0f));
+      X2[x2idx(pm, 8 + pq)] = FN_COS(fmul(xv, 256.0f));
+      X2[x2idx(pm, 12 + pq)] = FN_SIN(fmul(xv, 512.0f));
+      X2[x2idx(pm, 16 + pq)] = FN_COS(fmul(xv, 512.0f));
       X2[x2idx(pm, 20 + pq)] = 0.f; X2[x2idx(pm, 24 + pq)] = 0.f; X2[x2idx(pm, 28 + pq)] = 0.f;
     };
     if (!BG) {
@@ -928,8 +935,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       for (int j = pq; j < 30; j += 4) {
         const int k = j / 3, dim = j - 3 * k;
         const float a = fmul(x[dim], (float)(1 << k));
-        Es[eidx(pm, 3 + 6 * k + dim)] = sinf(a);
-        Es[eidx(pm, 6 + 6 * k + dim)] = cosf(a);
+        Es[eidx(pm, 3 + 6 * k + dim)] = FN_SIN(a);
+        Es[eidx(pm, 6 + 6 * k + dim)] = FN_COS(a);
       }
     } else {
       const int sidx = (int)(pp - ray * S);
@@ -940,10 +947,10 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const float a = fmul(xv, (float)(1 << k));
-        Es[eidx(pm, 4 + 8 * k + pq)] = sinf(a);
-        Es[eidx(pm, 8 + 8 * k + pq)] = cosf(a);
+        Es[eidx(pm, 4 + 8 * k + pq)] = FN_SIN(a);
+        Es[eidx(pm, 8 + 8 * k + pq)] = FN_COS(a);
       }
-      Es[eidx(pm, 60 + pq)] = sinf(fmul(xv, 128.0f));
+      Es[eidx(pm, 60 + pq)] = FN_SIN(fmul(xv, 128.0f));
       write_x2();
     }
     __syncthreads();
@@ -1028,8 +1035,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       for (int j = pq; j < 12; j += 4) {
         const int k = j / 3, dim = j - 3 * k;
         const float a = fmul(v[dim], (float)(1 << k));
-        Es[eidx(pm, 3 + 6 * k + dim)] = sinf(a);
-        Es[eidx(pm, 6 + 6 * k + dim)] = cosf(a);
+        Es[eidx(pm, 3 + 6 * k + dim)] = FN_SIN(a);
+        Es[eidx(pm, 6 + 6 * k + dim)] = FN_COS(a);
       }
     }
     // FN_FWD_SKIP_DEAD_RGB (see mlp_bf16.hip): a tile without a live sample skips the feature / view / colour layers.  One word

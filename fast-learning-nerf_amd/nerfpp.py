@@ -100,13 +100,22 @@ class MLPNet(nn.Module):
         return OrderedDict([('rgb', rgb), ('sigma', sigma.squeeze(-1))])
 
 
-def _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save):
+def _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save, workspace=False):
+    """workspace=True (CascadeTrainer: the backward of a level follows its forward before anything else runs on the stream): the
+    saved activations live in the per-(device, stream) scratch of render._Workspace instead of two fresh multi-GB allocations per
+    level and step -- inside a long process the caching allocator otherwise ends up freeing and re-allocating them (bench.py's nerf++
+    leg measured 26 instead of 19 ms per batch behind the other legs)."""
     dev = rays11.device
     n, Sf = fg_z.shape
     Sb = bg_z.shape[1]
     pf, pb = net.fg_net.packed(), net.bg_net.packed()
-    act_f = torch.empty(ops.act_floats(n * Sf, 1), device=dev) if save else None
-    act_b = torch.empty(ops.act_floats(n * Sb, 2), device=dev) if save else None
+    act_f = act_b = None
+    if save and workspace:
+        act_f = _Workspace.get('pp_act_fg', dev, ops.act_floats(n * Sf, 1))
+        act_b = _Workspace.get('pp_act_bg', dev, ops.act_floats(n * Sb, 2))
+    elif save:
+        act_f = torch.empty(ops.act_floats(n * Sf, 1), device=dev)
+        act_b = torch.empty(ops.act_floats(n * Sb, 2), device=dev)
     raw_f = ops.mlp_fwd(rays11, fg_z, net.fg_net.flat, pf[0], act=act_f, kind=1)
     fg_rgb, fg_w, fg_depth, lam = ops.pp_composite_fwd(0, raw_f, fg_z, rays11, fg_far)
     raw_b = ops.mlp_fwd(rays11, bg_z, net.bg_net.flat, pb[0], act=act_b, kind=2)
@@ -333,7 +342,7 @@ class CascadeTrainer:
                 bg_z, _ = ops.pp_sample_pdf_merge(bg_z, ret[5], N, u=r.get('bg_u'), det=det and r.get('bg_u') is None,
                                                   seed=0 if det else _next_seed())
             self.last_depths.append((fg_z, bg_z))
-            outs, saved = _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save=True)
+            outs, saved = _nerfnet_forward(net, rays11, fg_far, fg_z, bg_z, save=True, workspace=True)
             fg_rgb, fg_w, fg_depth, lam, bg_rgb, bg_w, bg_depth = outs
             rgb = fg_rgb + lam[:, None] * bg_rgb
             last = m == len(self.nets) - 1
