@@ -44,6 +44,14 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_F32 0
 #define MM_X6 1
+// X6_SHAPE16 (round 4): the MM_X6 forward / dX kernels multiply on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  The chip is
+// power limited under these kernels and most of an MFMA's register traffic is its accumulator (C in + D out: 128 of ~160 bytes per lane
+// for the 32x32x16 shape); the 16x16x32 shape updates a quarter of the accumulator with twice the K: half the accumulator traffic per flop,
+// twice the operand traffic.  Bare streams on random data: 2240 against 1990 TFLOP/s (tools/micro/mfma_shapes.hip); the planes prototype's
+// hidden layers 0.449 against 0.502 ms (tools/micro/x6_planes_proto3.hip).  profiles/r04_power_limit.md, section 6.
+#ifndef X6_SHAPE16
+#define X6_SHAPE16 1
+#endif
 
 #ifndef TM
 #define TM 64          // points per tile (fwd / dx)
@@ -166,8 +174,13 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 __global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* __restrict__ params,
                                                      uint4* __restrict__ pf, uint4* __restrict__ pb) {
   const PackDesc d = tab.d[blockIdx.y];
-  const int KS = (d.transposed ? d.n_rows : d.n_cols) / 16;
-  const int NTL = (d.transposed ? d.n_cols : d.n_rows) / 32;
+#if X6_SHAPE16   // fragment order of v_mfma_f32_16x16x32_bf16: tiles of 16 columns, k-steps of 32, lane = (column l & 15, k-chunk l >> 4)
+  constexpr int TW = 16, KW = 32;
+#else
+  constexpr int TW = 32, KW = 16;
+#endif
+  const int KS = (d.transposed ? d.n_rows : d.n_cols) / KW;
+  const int NTL = (d.transposed ? d.n_cols : d.n_rows) / TW;
   const int64_t total = (int64_t)NTL * KS * 64;          // one thread = the three planes of one (tile, k-step, lane)
   uint4* dst = (d.transposed ? pb : pf) + d.dst_off * 3 / 8;   // dst_off: floats of the fp32 packing = 8/3 of these uint4
   const float* src = params + d.src_off;
@@ -178,16 +191,16 @@ __global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* 
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int kp = ks * 16 + (l >> 5) * 8 + j;
+      const int kp = ks * KW + (l / TW) * 8 + j;
       v[j] = 0.f;
       if (!d.transposed) {
-        const int n = tile * 32 + (l & 31);
+        const int n = tile * TW + (l % TW);
         int col = -1;
         if (kp < d.segA_pad) { if (kp < d.segA_valid) col = kp; }
         else { const int q = kp - d.segA_pad; if (q < d.segB_valid) col = d.segA_valid + q; }
         if (col >= 0) v[j] = src[(int64_t)n * d.ld + col];
       } else {
-        v[j] = src[(int64_t)kp * d.ld + d.col0 + tile * 32 + (l & 31)];
+        v[j] = src[(int64_t)kp * d.ld + d.col0 + tile * TW + (l % TW)];
       }
     }
     unsigned h[4], m[4], lo[4];
@@ -703,7 +716,160 @@ __device__ __forceinline__ void gemm_seg6p(f32x16 (&acc)[2][NT], const float* __
   }
 }
 
+// ---- MM_X6 on v_mfma_f32_16x16x32_bf16 (X6_SHAPE16) -----------------------------------------------------------------------------
+// A wave's 64 x 64 outputs are 4 x 4 tiles of 16 x 16 (64 accumulator registers, as before); a k-step is 32 wide.  Lane (r16 = lane & 15,
+// kc = lane >> 4) holds 8 consecutive k of row / column r16 for both operands.  The weight pieces of a k-step (4 column tiles x 3
+// pieces = 48 registers) are held for the whole k-step and double buffered; the activation pieces are streamed ROW TILE by row tile:
+// "unit" u = (k-step, row tile) issues its 24 MFMAs (6 products x 4 column tiles) on the pieces of row tile u while the raw fragment of
+// unit u + 1 is split between them (4 pairs = 44 plain VALU per 24 MFMAs) and the LDS reads of unit u + 2 are issued -- the software
+// pipeline of gemm_seg6p at half the k-granularity, with 24 instead of 48 piece registers.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <bool L16, int NT> struct AccSel { typedef f32x16 type[2][NT]; };
+template <int NT> struct AccSel<true, NT> { typedef f32x4m type[4][2 * NT]; };
+template <bool L16, int NT> using AccT = typename AccSel<L16, NT>::type;
+
+__device__ __forceinline__ f32x4m mfma16(const uint4& a, const uint4& b, f32x4m c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+struct Pieces16 { unsigned v[3][4]; };   // [piece h | m | l][pair of k] of ONE row tile
+__device__ __forceinline__ uint4 piece_frag16(const Pieces16& p, int pl) { return make_uint4(p.v[pl][0], p.v[pl][1], p.v[pl][2], p.v[pl][3]); }
+__device__ __forceinline__ void split_pair16(const float4 (&ar)[2], Pieces16& pn, int q) {
+  const float4& s4 = ar[q >> 1];
+  const float x0 = (q & 1) ? s4.z : s4.x, x1 = (q & 1) ? s4.w : s4.y;
+  split3_pair_p(x0, x1, pn.v[0][q], pn.v[1][q], pn.v[2][q]);
+}
+// one unit: 6 * CT MFMAs of row tile MT on the pieces pc and the k-step's weight pieces b; between them the split of `ar` (the next unit's
+// raw fragment) into pn and, behind its last pair, `refill()` (the LDS reads that reload ar for the unit after that)
+template <int CT, int MT, int SYNC, typename ACC, typename RF>
+__device__ __forceinline__ void unit16(ACC& acc, const Pieces16& pc, const uint4 (&b)[CT][3], float4 (&ar)[2], Pieces16& pn, RF&& refill) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int NM = 6 * CT;
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int i = t * CT + ct;
+      acc[MT][ct] = mfma16(piece_frag16(pc, PA[t]), b[ct][PB[t]], acc[MT][ct]);
+#pragma unroll
+      for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) {
+        split_pair16(ar, pn, pair);
+        if (pair == 3) refill();
+      }
+    }
+  interleave6<0, NM, 4 * X6_PIPE_VP, SYNC>();
+}
+template <int NT, int AMODE, typename ACC>
+__device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ As, int a_ks0, int nks, const uint4* __restrict__ Bp, int KS,
+                                           int b_ks0, int nt0, int wm, int lane, float* __restrict__ save_dst, int save_valid, int wave) {
+  asm volatile("" : "+v"(lane));
+  constexpr int CT = 2 * NT;
+  const int r16 = lane & 15, kc = lane >> 4;
+  constexpr int RS = AMODE == 0 ? 256 : (AMODE == 1 ? 64 : 32);
+  const int m0 = wm * 64 + r16;
+  // row tile mt: row m0 + 16 mt; the swizzle term of H / E rows (m & 15) does not depend on mt
+  const float* arow0 = As + m0 * RS;
+  auto load_raw = [&](float4 (&a)[2], int mt, int ks) {
+    const int m = m0 + 16 * mt;
+    const int ax = (AMODE == 2) ? ((m >> 1) & 7) : (m & 15);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      a[j] = *reinterpret_cast<const float4*>(arow0 + mt * (16 * RS) + ((((a_ks0 + ks) * 8 + kc * 2 + j) ^ ax) << 2));
+  };
+  const char* bptr[CT];   // (scalar-base weight loads: see gemm_seg6)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) bptr[ct] = reinterpret_cast<const char*>(Bp + ((int64_t)(nt0 * 2 + ct) * KS + b_ks0) * 192);
+  unsigned blane = (unsigned)lane * 16u;
+  auto load_b = [&](uint4 (&b)[CT][3], int ks) {
+    asm volatile("" : "+v"(blane));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[ct][pl] = *reinterpret_cast<const uint4*>((bptr[ct] + (ks * 192 + pl * 64) * 16) + blane);
+  };
+  const int klast = nks - 1;
+  float4 r0[2], r1[2];          // raw fragments of units u + 1 (being split) and u + 2 (in flight)
+  Pieces16 pa, pb;              // pieces of the current and the next unit
+  uint4 b0[CT][3], b1[CT][3];
+  load_b(b0, 0);
+  load_raw(r0, 0, 0);
+  load_raw(r1, 1, 0);
+  load_b(b1, klast > 0 ? 1 : 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_pair16(r0, pa, q);     // unit 0 is split up front; its registers then take unit 2
+  load_raw(r0, 2, 0);
+#if X6_PRIO
+  __builtin_amdgcn_s_setprio(X6_PRIO);
+#endif
+  // unit u = 4 ks + mt:   pieces  pa (u even) / pb (u odd);   splits raw r1 (u even) / r0 (u odd) = unit u + 1;   refills it with unit u + 3
+  // (clamped at the segment's last k-step: re-reads, never used)
+  auto kstep = [&](const uint4 (&b)[CT][3], int ks, auto par) __attribute__((always_inline)) {
+    constexpr int S0 = 1 + 4 * decltype(par)::value;   // one sched_group_barrier pipeline per unit of the loop body
+    const int kn = ks + 1 < klast ? ks + 1 : klast;   // k-step of units u + 3 / u + 4 once they wrap
+    unit16<CT, 0, S0 + 0>(acc, pa, b, r1, pb, [&]() { load_raw(r1, 3, ks); });
+    unit16<CT, 1, S0 + 1>(acc, pb, b, r0, pa, [&]() { load_raw(r0, 0, kn); });
+    unit16<CT, 2, S0 + 2>(acc, pa, b, r1, pb, [&]() { load_raw(r1, 1, kn); });
+    unit16<CT, 3, S0 + 3>(acc, pb, b, r0, pa, [&]() { load_raw(r0, 2, kn); });
+  };
+  constexpr std::integral_constant<int, 0> EVEN{};
+  constexpr std::integral_constant<int, 1> ODD{};
+  const bool saving = AMODE == 0 && save_dst != nullptr;
+#pragma unroll 1
+  for (int ks = 0; ks + 2 <= nks - (saving ? 1 : 0); ks += 2) {
+    kstep(b0, ks, EVEN);
+    load_b(b0, ks + 2 < klast ? ks + 2 : klast);
+    kstep(b1, ks + 1, ODD);
+    load_b(b1, ks + 3 < klast ? ks + 3 : klast);
+  }
+  if (!saving) {
+    if (nks & 1) kstep(b0, klast, EVEN);          // (single-step segments: the 32 extra encoding channels)
+  } else {
+    // nks is even (8) for every saved segment: k-step nks - 2 as above, then the LAST k-step with the tile's rows streamed out between
+    // its MFMAs (every load of the segment has been issued; rows beyond the valid count are clamped: rewritten with the same bytes)
+    kstep(b0, nks - 2, EVEN);
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int ROWS = TM / NWAVES, NM = 6 * CT;
+    const int last_row = save_valid - 1;
+    auto last_unit = [&](auto mtc, const Pieces16& pc, float4 (&ar)[2], Pieces16& pn) __attribute__((always_inline)) {
+      constexpr int MT = decltype(mtc)::value;
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int i = t * CT + ct;
+          acc[MT][ct] = mfma16(piece_frag16(pc, PA[t]), b1[ct][PB[t]], acc[MT][ct]);
+          if (MT < 3) {
+#pragma unroll
+            for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) split_pair16(ar, pn, pair);
+          }
+#pragma unroll
+          for (int r = (i * (ROWS / 4)) / NM; r < ((i + 1) * (ROWS / 4)) / NM; ++r) {
+            int m = (MT * (ROWS / 4) + r) * NWAVES + wave;
+            m = m < last_row ? m : last_row;
+            const float4 v = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
+            store_nt(save_dst + (unsigned)(m * 256 + ((lane ^ (m & 15)) << 2)), v);
+          }
+        }
+    };
+    last_unit(std::integral_constant<int, 0>{}, pa, r1, pb);
+    load_raw(r1, 3, klast);
+    last_unit(std::integral_constant<int, 1>{}, pb, r0, pa);
+    last_unit(std::integral_constant<int, 2>{}, pa, r1, pb);
+    last_unit(std::integral_constant<int, 3>{}, pb, r0, pa);
+  }
+#if X6_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // one call site for both math modes: k-steps in the 8-wide units of gemm_seg, Bw = the layer's block in this mode's packing
+template <int MM, int NT, int AMODE>
+__device__ __forceinline__ void gemm(f32x4m (&acc)[4][2 * NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
+                                     int KS, int b_ks0, int nt0, int wm, int lane, int dbg = 0,
+                                     float* __restrict__ save_dst = nullptr, int save_valid = 0, int wave = 0) {
+  static_assert(MM == MM_X6, "the 16 x 16 accumulator layout belongs to the bf16x6 kernels");
+  gemm_seg16<NT, AMODE>(acc, As, a_ks0 / 4, nks / 4, reinterpret_cast<const uint4*>(Bw), KS / 4, b_ks0 / 4, nt0, wm, lane, save_dst,
+                        save_valid, wave);
+}
 template <int MM, int NT, int AMODE>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
                                      int KS, int b_ks0, int nt0, int wm, int lane, int dbg = 0,
@@ -737,6 +903,32 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 }
 
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x4m (&acc)[4][2 * NT]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int ct = 0; ct < 2 * NT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][ct][r] = 0.f;
+}
+// C layout of v_mfma_f32_16x16x32_bf16: col = lane & 15, row = 4 * (lane >> 4) + r.  Element (mt, ct, r) of a wave's 64 x 64 block is
+// H[wm*64 + mt*16 + 4*hq + r][(wn*CT + ct)*16 + (lane & 15)], hq = lane >> 4; the row's swizzle term m & 15 = (hq << 2) | r separates as in
+// h_cols: four column pointers per column tile (one per r), everything else an immediate.
+template <int CT>
+__device__ __forceinline__ void h_cols16(float* Hs, int wm, int wn, int lane, float* (&colp)[CT][4]) {
+  const int hq = lane >> 4;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int n = (wn * CT + ct) * 16 + (lane & 15);
+    float* const rowp = Hs + (wm * 64 + 4 * hq) * 256 + (n & 3);
+    const int q = (n >> 2) ^ (hq << 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) colp[ct][r] = rowp + ((q ^ r) << 2);
+  }
+}
+#define H16_AT(colp, ct, mt, r) ((colp)[ct][r][((mt) * 16 + (r)) * 256])
+
 // C layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -768,10 +960,16 @@ __device__ __forceinline__ void h_cols(float* Hs, int wm, int wn, int lane, floa
 // `v_bfe_i32` + `v_and_b32`, instead of re-reading 1 KB/point/layer of activations.  (Round 3 kept wave BALLOTS, one per value, moved
 // into lane i with `s_nop 3` + two `v_writelane` and fetched in dX with two `v_readlane` + select + shift: 6 / 6 instructions per value
 // where this takes 5 / 2.)
-template <int NT>
-__device__ __forceinline__ void load_bias(float (&bv)[NT], const float* __restrict__ bias, int wn, int lane) {
+template <int NT, int NB>
+__device__ __forceinline__ void load_bias(float (&bv)[NB], const float* __restrict__ bias, int wn, int lane) {
+  static_assert(NB == NT || NB == 2 * NT, "NT columns tiles of 32 or 2 NT of 16");
+  if constexpr (NB == NT) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bv[nt] = bias[(wn * NT + nt) * 32 + (lane & 31)];
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = bias[(wn * NT + nt) * 32 + (lane & 31)];
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < NB; ++ct) bv[ct] = bias[(wn * NB + ct) * 16 + (lane & 15)];
+  }
 }
 
 // bias values are loaded by the caller BEFORE the k-loop (load_bias) so that no global load waits
@@ -809,6 +1007,42 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
       }
       __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one 32x32 tile at a time
     }
+  }
+  if (want_mask) mask_out[lane] = ((unsigned long long)whi << 32) | (unsigned long long)wlo;
+}
+
+
+// the same epilogue on the 16 x 16 accumulator layout (X6_SHAPE16): value index i = (mt * CT + ct) * 4 + r in the lane's sign word
+template <int NT, bool RELU, bool MASKS = false>
+__device__ __forceinline__ void epilogue_fwd(const f32x4m (&acc)[4][2 * NT], const float (&bias_v)[2 * NT], float* Hs, int wm, int wn, int lane,
+                                             float* __restrict__ save, int ldsave, int valid,
+                                             unsigned long long* __restrict__ mask_out = nullptr) {
+  asm volatile("" : "+v"(lane));
+  constexpr int CT = 2 * NT;
+  unsigned wlo = 0u, whi = 0u;
+  constexpr bool want_mask = RELU && NT == 2 && MASKS;
+  float* colp[CT][4];
+  h_cols16<CT>(Hs, wm, wn, lane, colp);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const float bv = bias_v[ct];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[mt][ct][r] + bv;
+        if (want_mask) {
+          if ((mt * CT + ct) * 4 + r < 32)
+            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_max_f32 %1, 0, %1" : "+v"(wlo), "+v"(v) : : "vcc");
+          else
+            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_max_f32 %1, 0, %1" : "+v"(whi), "+v"(v) : : "vcc");
+        } else if (RELU) {
+          v = v > 0.f ? v : 0.f;
+        }
+        H16_AT(colp, ct, mt, r) = v;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one row tile at a time
   }
   if (want_mask) mask_out[lane] = ((unsigned long long)whi << 32) | (unsigned long long)wlo;
 }
@@ -970,10 +1204,11 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         }
       }
     }
-    f32x16 acc[2][2];
+    constexpr bool L16 = MM == MM_X6 && X6_SHAPE16;
+    AccT<L16, 2> acc;
     // ---- L0 : pe -> 256 -----------------------------------------------------------------
     zero_acc<2>(acc);
-    float bv2[2];
+    float bv2[L16 ? 4 : 2];
     load_bias<2>(bv2, params + lay.LB[0], wn, lane);
     gemm<MM, 2, 1>(acc, Es, 0, 8, wblock<MM>(packed, lay.PF[0]), PEP / 8, 0, wn * 2, wm, lane, dbg);
     if (BG) {
@@ -1073,9 +1308,9 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     }
     // ---- view layer: [feat | vpe32] -> 128, ReLU ---------------------------------------
     {
-      f32x16 av[2][1];
+      AccT<L16, 1> av;
       zero_acc<1>(av);
-      float bv1[1];
+      float bv1[L16 ? 2 : 1];
       load_bias<1>(bv1, params + lay.VB, wn, lane);
       gemm<MM, 1, 0>(av, Hs, 0, 32, wblock<MM>(packed, lay.PF[9]), 36, 0, wn, wm, lane, dbg,
                      SAVE ? act + act_feat(PL, PEP) + p0 * 256 : nullptr, valid, wave);
@@ -1197,24 +1432,57 @@ extern "C" int fastnerf_mlp_fwd(int64_t n, int S, const float* rays11, const flo
 // and the pre-activation gradient buffer.
 struct DxPre {  // loaded before the k-loop (see load_bias)
   unsigned mlo, mhi;
-  float wan[2];
+  float wan[4];   // rank-1 weights of this lane's columns: two column tiles of 32, or four of 16 (L16)
 };
-template <bool MASK, bool RANK1>
+template <bool MASK, bool RANK1, bool L16 = false>
 __device__ __forceinline__ DxPre dx_preload(const unsigned long long* __restrict__ maskw, const float* __restrict__ wa,
                                             int wn, int lane) {
   DxPre p;
   p.mlo = p.mhi = 0u;
-  p.wan[0] = p.wan[1] = 0.f;
+  p.wan[0] = p.wan[1] = p.wan[2] = p.wan[3] = 0.f;
   if (MASK) {
     const unsigned long long w = maskw[lane];
     p.mlo = (unsigned)w;
     p.mhi = (unsigned)(w >> 32);
   }
   if (RANK1) {
-    p.wan[0] = wa[(wn * 2 + 0) * 32 + (lane & 31)];
-    p.wan[1] = wa[(wn * 2 + 1) * 32 + (lane & 31)];
+    if constexpr (L16) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) p.wan[ct] = wa[(wn * 4 + ct) * 16 + (lane & 15)];
+    } else {
+      p.wan[0] = wa[(wn * 2 + 0) * 32 + (lane & 31)];
+      p.wan[1] = wa[(wn * 2 + 1) * 32 + (lane & 31)];
+    }
   }
   return p;
+}
+template <bool MASK, bool RANK1>
+__device__ __forceinline__ void epilogue_dx(const f32x4m (&acc)[4][4], float* Hs, const float* Es_dalpha, const DxPre& pre,
+                                            float* __restrict__ dsave, int wm, int wn, int lane, int valid) {
+  asm volatile("" : "+v"(lane));
+  const unsigned mlo = pre.mlo, mhi = pre.mhi;
+  float* colp[4][4];
+  h_cols16<4>(Hs, wm, wn, lane, colp);
+  const int hq = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float wan = pre.wan[ct];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[mt][ct][r];
+        if (RANK1) v = fmaf(Es_dalpha[wm * 64 + mt * 16 + 4 * hq + r], wan, v);
+        if (MASK) {   // this lane's sign word of the forward (epilogue_fwd, same enumeration)
+          const int idx = (mt * 4 + ct) * 4 + r;
+          const int keep = __builtin_amdgcn_sbfe(idx < 32 ? (int)mlo : (int)mhi, 31 - (idx & 31), 1);
+          v = __int_as_float(__float_as_int(v) & keep);
+        }
+        H16_AT(colp, ct, mt, r) = v;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <bool MASK, bool RANK1>
@@ -1301,18 +1569,19 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       }
     }
     __syncthreads();
-    f32x16 acc[2][2];
+    constexpr bool L16 = MM == MM_X6 && X6_SHAPE16;
+    AccT<L16, 2> acc;
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ------------------------------------------
     zero_acc<2>(acc);
     gemm<MM, 2, 0>(acc, Hs, 0, 16, wblock<MM>(packed_t, lay.PB[0]), 16, 0, wn * 2, wm, lane);
     __syncthreads();
-    epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
+    epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false, L16>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
                               valid);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ------------------------------------
     zero_acc<2>(acc);
     {
-      const DxPre pre = dx_preload<true, true>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
+      const DxPre pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
       gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
                          dact + dact_feat(PL) + p0 * 256, valid, wave);    // streams dfeat (what it reads) out
       __syncthreads();
@@ -1324,7 +1593,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     for (int l = 7; l >= 1; --l) {
       const int64_t off = lay.PB[9 - l];   // PB[2] = L7t ... PB[8] = L1t
       zero_acc<2>(acc);
-      const DxPre pre = dx_preload<true, false>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
+      const DxPre pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
       gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
                          dact + dact_y(PL, l) + p0 * 256, valid, wave);    // streams dY_l (what it reads) out
       __syncthreads();

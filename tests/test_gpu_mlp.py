@@ -428,11 +428,12 @@ def test_bf16x6_decomposition_is_exact_and_products_have_fp32_width(fn, weights)
             w = weights[name].numpy()
             N = w.shape[0]
             kp = 64 if l == 0 else (320 if l == 5 else (288 if l == 9 else 256))
-            n_u4 = (N // 32) * (kp // 16) * 3 * 64
-            blk = u16[off * 8:(off + n_u4) * 8].reshape(N // 32, kp // 16, 3, 64, 8)
+            # fragment order of v_mfma_f32_16x16x32_bf16 (csrc/mlp.hip, X6_SHAPE16): column tiles of 16, k-steps of 32
+            n_u4 = (N // 16) * (kp // 32) * 3 * 64
+            blk = u16[off * 8:(off + n_u4) * 8].reshape(N // 16, kp // 32, 3, 64, 8)
             tot = bf(blk[:, :, 0]) + bf(blk[:, :, 1]) + bf(blk[:, :, 2])          # [tile][ks][lane][8]
-            # lane l of (tile, ks): n = tile*32 + (l & 31), k' = ks*16 + (l >> 5)*8 + 0..7
-            got = tot.reshape(N // 32, kp // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(N, kp)
+            # lane l of (tile, ks): n = tile*16 + (l & 15), k' = ks*32 + (l >> 4)*8 + 0..7
+            got = tot.reshape(N // 16, kp // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(N, kp)
             if l == 0:
                 ref = np.concatenate([w, np.zeros((N, 1), np.float32)], 1)
             elif l == 5:

@@ -256,6 +256,7 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
             rgb = fn.render.render(P.H, P.W, K, chunk=P.HELD_OUT, rays=(dd['ho_ro'], dd['ho_rd']), near=2.0, far=6.0, **kte)[0]
             mse = float(torch.mean((rgb - dd['ho_tgt']) ** 2))
         return P.psnr(np.mean(ls[-P.WINDOW:])), P.psnr(mse), float(ls[0])
+    checks = []
     try:
         for mode in ('bf16x6', 'fp32'):
             g_train, g_held = [], []
@@ -263,6 +264,9 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
                 runs = [gpu_run(seed, mode, j) for j in range(members)]
                 assert abs(runs[0][2] - float(z['first_loss'][i])) < 2e-5 * float(z['first_loss'][i]) + 1e-7      # same weights, same batch
                 g_train.append([r[0] for r in runs]); g_held.append([r[1] for r in runs])
+            out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+            if os.path.isdir(out_dir):      # (a record of the GPU side of the pairs for profiles/r04_psnr_paired.md; not part of the test)
+                np.savez(os.path.join(out_dir, 'g22_gpu_%s.npz' % mode), seeds=np.array(seeds), train=np.array(g_train), held=np.array(g_held))
             for name, gv, cv in (('train', np.array(g_train), z['train_psnr_db']), ('held-out', np.array(g_held), z['held_out_psnr_db'])):
                 alive_g, alive_c = gv[:, 0] > 15.0, cv > 15.0
                 assert int((alive_g != alive_c).sum()) <= 2, (mode, name, alive_g.tolist(), alive_c.tolist())
@@ -272,11 +276,12 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
                 print('G22 paired %s %s PSNR: %d of %d seeds train on both sides; CPU mean %.3f, GPU mean %.3f, mean difference %+.3f dB, per-seed std %.3f, '
                       'standard error %.3f; within-seed GPU std %.3f' % (mode, name, len(d), len(seeds), cv[ok].mean(), gv[ok].mean(), d.mean(),
                                                                          np.std(d, ddof=1), se, float(np.mean(np.std(gv[ok], axis=1, ddof=1)))))
-                assert len(d) >= 20 and se < 0.09, (mode, name, len(d), se)
-                assert abs(float(d.mean())) < 0.05 + 2.6 * se, (mode, name, float(d.mean()), se)
+                checks.append((len(d) >= 20 and se < 0.09, (mode, name, len(d), se)))
+                checks.append((abs(float(d.mean())) < 0.05 + 2.6 * se, (mode, name, float(d.mean()), se)))
     finally:
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)
+    assert all(ok for ok, _ in checks), [info for ok, info in checks if not ok]
 
 
 def test_train_driver_with_quadtree(fn):
