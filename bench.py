@@ -208,6 +208,13 @@ def psnr_cpu_worker(in_path, out_path):
     from oracle import nerf_oracle as O
     d = torch.load(in_path)
     _, t32 = cpu_threads()
+    try:   # this run happens BESIDE the GPU legs: keep it off the cores the launching process uses (upper half of the CPU list, low priority)
+        cpus = sorted(os.sched_getaffinity(0))
+        if len(cpus) >= 4 * t32:
+            os.sched_setaffinity(0, cpus[len(cpus) // 2:])
+        os.nice(10)
+    except (AttributeError, OSError):
+        pass
     torch.set_num_threads(t32)
     sdc, sdf = d['sdc'], d['sdf']
     params = list(sdc.values()) + list(sdf.values())

@@ -8,7 +8,7 @@ N = 4096
 dev = torch.device('cuda')
 H, W, focal = 756, 1008, 815.13
 K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
-for mode in ('fp32', 'bf16x3'):
+for mode in (sys.argv[1:] or ['fp32', 'bf16x3']):
     ops.set_math(mode)
     torch.manual_seed(0)
     args = fn.run_nerf.make_args(N_importance=64, N_samples=64, perturb=1.0, raw_noise_std=1.0, no_reload=True, dataset_type='llff',
