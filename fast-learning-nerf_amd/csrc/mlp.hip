@@ -48,7 +48,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // power limited under these kernels and most of an MFMA's register traffic is its accumulator (C in + D out: 128 of ~160 bytes per lane
 // for the 32x32x16 shape); the 16x16x32 shape updates a quarter of the accumulator with twice the K: half the accumulator traffic per flop,
 // twice the operand traffic.  Bare streams on random data: 2240 against 1990 TFLOP/s (tools/micro/mfma_shapes.hip); the planes prototype's
-// hidden layers 0.449 against 0.502 ms (tools/micro/x6_planes_proto3.hip).  profiles/r04_power_limit.md, section 6.
+// hidden layers 0.449 against 0.502 ms (tools/micro/x6_planes_proto3.hip).  profiles/r04_power_limit.md, section 5.
 #ifndef X6_SHAPE16
 #define X6_SHAPE16 1
 #endif

@@ -1,5 +1,5 @@
 // (-DSHAPE16=1: the same k-loop on v_mfma_f32_16x16x32_bf16 -- 48 MFMAs of 16 cycles per 32 channels of K instead of 2 x 12 of 32 cycles;
-//  timing only: the epilogue then runs on accumulators in another layout.  profiles/r04_power_limit.md, section 6.)
+//  timing only: the epilogue then runs on accumulators in another layout.  profiles/r04_power_limit.md, section 5.)
 // Prototype (timing study, not product code): what would a bf16x6 hidden layer cost if every activation were split ONCE -- in
 // the epilogue that produces it -- and kept in LDS as three bf16 planes, instead of fp32 in LDS split by each of the four waves
 // that multiply it (csrc/mlp.hip, gemm_seg6)?  VALU time does not hide under the partner wave's MFMAs on this chip
