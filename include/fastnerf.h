@@ -319,8 +319,8 @@ int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N
  * Same network functions and call protocol as fastnerf_mlp_pack_ex / fwd_ex / fwd_flags_ex / bwd_ex / fwd_live_ex / bwd_live_ex
  * (run_nerf.py:50-64 run_network -> model.py:37-63, autograd backward of the same).  Every fp32 operand is decomposed EXACTLY
  * into three bf16 pieces (8 + 8 + 8 significand bits) and a product is the sum of the six piece products whose weight is
- * >= 2^-16 of it, accumulated in fp32 on v_mfma_f32_32x32x16_bf16: the dropped terms are <= 2^-24 of the product, the rounding
- * fp32 itself applies to it.  Weights are packed as three bf16 planes (fastnerf_mlp_x6_packed_floats(kind, 1 | 2) floats);
+ * >= 2^-16 of it, accumulated in fp32 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16 in the forward / dX, v_mfma_f32_32x32x16_bf16 in dW): the dropped terms are <= 2^-24 of the product, the rounding
+ * fp32 itself applies to it.  Weights are packed as three bf16 planes in the MFMA's fragment order (opaque; fastnerf_mlp_x6_packed_floats(kind, 1 | 2) floats);
  * saved activations / gradient workspaces are those of the exact-fp32 kernels (fastnerf_mlp_act_floats,
  * n*S*FASTNERF_DACT_FLOATS, fastnerf_mlp_bwd_partial_floats).  fwd: act == NULL -> inference, flags as
  * fastnerf_mlp_fwd_flags_ex (ignored when act != NULL). */
