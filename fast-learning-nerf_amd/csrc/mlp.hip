@@ -73,6 +73,24 @@ static int num_cus() {
   return g_num_cus;
 }
 
+#ifdef X6_TIMING   // instrumented build (tools/x6_timing.py): where a wave of the forward spends its cycles; wrong for nothing, slower by the clock reads
+__device__ unsigned long long g_x6_timing[4096 * 8];   // per wave: k-loops | barrier 1 | epilogue | barrier 2 | layer iterations | tiles' cycles | gemm prologues | gemm calls
+#define X6_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define X6_TADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_x6_timing[((blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095) * 8 + (i)], (unsigned long long)(v)); } while (0)
+extern "C" int fastnerf_dbg_x6_timing(unsigned long long* out, int reset) {   // out[8]: sums over the waves
+  static unsigned long long h[4096 * 8];
+  if (out) {
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_x6_timing), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) { out[i] = 0; for (int w = 0; w < 4096; ++w) out[i] += h[w * 8 + i]; }
+  }
+  if (reset) { for (auto& v : h) v = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_x6_timing), h, sizeof(h)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define X6_T(var)
+#define X6_TADD(i, v)
+#endif
+
 // =========================================================================================
 // weight packing
 // =========================================================================================
@@ -784,12 +802,18 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[ct][pl] = *reinterpret_cast<const uint4*>((bptr[ct] + (ks * 192 + pl * 64) * 16) + blane);
+      for (int pl = 0; pl < 3; ++pl) {
+#ifdef X6_ABL_WPIECES   // timing-only ablation (wrong results): only the first X6_ABL_WPIECES weight pieces are loaded
+        if (pl >= X6_ABL_WPIECES) { b[ct][pl] = b[ct][0]; continue; }
+#endif
+        b[ct][pl] = *reinterpret_cast<const uint4*>((bptr[ct] + (ks * 192 + pl * 64) * 16) + blane);
+      }
   };
   const int klast = nks - 1;
   float4 r0[2], r1[2];          // raw fragments of units u + 1 (being split) and u + 2 (in flight)
   Pieces16 pa, pb;              // pieces of the current and the next unit
   uint4 b0[CT][3], b1[CT][3];
+  X6_T(tp0);
   load_b(b0, 0);
   load_raw(r0, 0, 0);
   load_raw(r1, 1, 0);
@@ -797,6 +821,11 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 #pragma unroll
   for (int q = 0; q < 4; ++q) split_pair16(r0, pa, q);     // unit 0 is split up front; its registers then take unit 2
   load_raw(r0, 2, 0);
+#ifdef X6_TIMING
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the instrumented build waits here for what the first unit needs anyway)
+  X6_T(tp1);
+  X6_TADD(6, tp1 - tp0); X6_TADD(7, 1);
+#endif
 #if X6_PRIO
   __builtin_amdgcn_s_setprio(X6_PRIO);
 #endif
@@ -1055,7 +1084,10 @@ __device__ __forceinline__ void epilogue_fwd(const f32x4m (&acc)[4][2 * NT], con
 // the other's MFMAs (measured: profiles/r01_summary.md).
 __device__ __forceinline__ void stagger_start() {
 #if TM == 64
-  const unsigned h = ((unsigned)blockIdx.x * 2654435761u) >> 28;  // 0..15
+#ifndef X6_STAGGER_SHIFT
+#define X6_STAGGER_SHIFT 28
+#endif
+  const unsigned h = X6_STAGGER_SHIFT >= 32 ? 0u : ((unsigned)blockIdx.x * 2654435761u) >> (X6_STAGGER_SHIFT & 31);  // 0..15
   for (unsigned i = 0; i < h; ++i) __builtin_amdgcn_s_sleep(16);    // 16 x 64 cycles
 #endif
 }
@@ -1137,6 +1169,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
 
   for (int64_t tile = blockIdx.x; tile < ntiles;) {
     const int64_t p0 = tile * TM;
+    X6_T(tt0);
     const int valid = (int)((P - p0) < TM ? (P - p0) : TM);
     unsigned long long* maskw =
         SAVE ? reinterpret_cast<unsigned long long*>(act + act_mask(PL, PEP)) + tile * (8 * NWAVES * 64) : nullptr;
@@ -1239,12 +1272,20 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
           gemm<MM, 2, 2>(acc, X2, 0, 4, B, KS5, 8, wn * 2, wm, lane, dbg);
         }
       } else {
+        X6_T(t0);
         gemm<MM, 2, 0>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
+        X6_T(t1);
+        X6_TADD(0, t1 - t0); X6_TADD(4, 1);
       }
+      X6_T(t2);
       __syncthreads();  // every wave has finished reading H
+      X6_T(t3);
       epilogue_fwd<2, true, SAVE>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
                                   SAVE ? maskw + (l * NWAVES + wave) * 64 : nullptr);
+      X6_T(t4);
       __syncthreads();
+      X6_T(t5);
+      X6_TADD(1, t3 - t2); X6_TADD(2, t4 - t3); X6_TADD(3, t5 - t4);
     }
     // ---- alpha head (VALU) + view-direction encoding -> Es ---------------------------
     float alpha_val = 0.f;
@@ -1353,6 +1394,8 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     }
     }   // !skip_tail
     tile = b_next_tile(sched, sched_word, tid);   // closing barrier inside: H / Es are rewritten by the next tile
+    X6_T(tt1);
+    X6_TADD(5, tt1 - tt0);
   }
   b_sched_exit(sched, tid);
 }
