@@ -776,9 +776,36 @@ __device__ __forceinline__ void unit16(ACC& acc, const Pieces16& pc, const uint4
     }
   interleave6<0, NM, 4 * X6_PIPE_VP, SYNC>();
 }
-template <int NT, int AMODE, typename ACC>
+// X6_CHAIN: the weight pieces of a segment's first k-step are loaded by the CALLER one layer ahead -- between the barrier that ends
+// the previous layer's k-loop and its epilogue -- into registers that are dead there (they are the k-loop's own double buffer): the
+// segment starts without waiting for L2 (tools/x6_timing.py: ~2 000 cycles per layer before the first MFMA otherwise).
+#ifndef X6_CHAIN
+#define X6_CHAIN 1
+#endif
+struct NoChain {};
+template <int CT> struct WRegs { uint4 b0[CT][3]; };   // k-step 0 (k-step 1 is not needed for ~3 000 cycles: the segment loads it itself)
+template <bool ON, int NT> struct WRegsSel { typedef NoChain type; };
+template <int NT> struct WRegsSel<true, NT> { typedef WRegs<2 * NT> type; };
+template <bool L16, int NT> using WRegsT = typename WRegsSel<L16 && X6_CHAIN, NT>::type;
+// arguments as gemm<>'s: KS, b_ks0, nks in the 8-wide k units of the call sites, nt0 = the wave's first 32-column tile
+template <int CT>
+__device__ __forceinline__ void wprefetch(WRegs<CT>& w, const void* Bw, int KS, int b_ks0, int /*nks*/, int nt0, int lane) {
+  const uint4* Bp = reinterpret_cast<const uint4*>(Bw);
+  unsigned blane = (unsigned)lane * 16u;
+  asm volatile("" : "+v"(blane));
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const char* p = reinterpret_cast<const char*>(Bp + ((int64_t)(nt0 * 2 + ct) * (KS / 4) + b_ks0 / 4) * 192);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) w.b0[ct][pl] = *reinterpret_cast<const uint4*>((p + (pl * 64) * 16) + blane);
+  }
+}
+__device__ __forceinline__ void wprefetch(NoChain&, const void*, int, int, int, int, int) {}
+
+template <int NT, int AMODE, bool PRE, typename ACC, typename W>
 __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ As, int a_ks0, int nks, const uint4* __restrict__ Bp, int KS,
-                                           int b_ks0, int nt0, int wm, int lane, float* __restrict__ save_dst, int save_valid, int wave) {
+                                           int b_ks0, int nt0, int wm, int lane, float* __restrict__ save_dst, int save_valid, int wave,
+                                           W& wext) {
   asm volatile("" : "+v"(lane));
   constexpr int CT = 2 * NT;
   const int r16 = lane & 15, kc = lane >> 4;
@@ -812,9 +839,14 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
   const int klast = nks - 1;
   float4 r0[2], r1[2];          // raw fragments of units u + 1 (being split) and u + 2 (in flight)
   Pieces16 pa, pb;              // pieces of the current and the next unit
-  uint4 b0[CT][3], b1[CT][3];
+  constexpr bool CHAINED = !std::is_same<W, NoChain>::value;
+  static_assert(CHAINED || !PRE, "preloaded weights come through a WRegs");
+  WRegs<CT> wloc_;
+  WRegs<CT>& wr_ = [&]() -> WRegs<CT>& { if constexpr (CHAINED) return wext; else return wloc_; }();
+  uint4 (&b0)[CT][3] = wr_.b0;
+  uint4 b1[CT][3];
   X6_T(tp0);
-  load_b(b0, 0);
+  if constexpr (!PRE) load_b(b0, 0);
   load_raw(r0, 0, 0);
   load_raw(r1, 1, 0);
   load_b(b1, klast > 0 ? 1 : 0);
@@ -891,13 +923,20 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 }
 
 // one call site for both math modes: k-steps in the 8-wide units of gemm_seg, Bw = the layer's block in this mode's packing
+template <int MM, int NT, int AMODE, bool PRE, typename W>
+__device__ __forceinline__ void gemm(f32x4m (&acc)[4][2 * NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
+                                     int KS, int b_ks0, int nt0, int wm, int lane, int dbg,
+                                     float* __restrict__ save_dst, int save_valid, int wave, W& w) {
+  static_assert(MM == MM_X6, "the 16 x 16 accumulator layout belongs to the bf16x6 kernels");
+  gemm_seg16<NT, AMODE, PRE>(acc, As, a_ks0 / 4, nks / 4, reinterpret_cast<const uint4*>(Bw), KS / 4, b_ks0 / 4, nt0, wm, lane, save_dst,
+                             save_valid, wave, w);
+}
 template <int MM, int NT, int AMODE>
 __device__ __forceinline__ void gemm(f32x4m (&acc)[4][2 * NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
                                      int KS, int b_ks0, int nt0, int wm, int lane, int dbg = 0,
                                      float* __restrict__ save_dst = nullptr, int save_valid = 0, int wave = 0) {
-  static_assert(MM == MM_X6, "the 16 x 16 accumulator layout belongs to the bf16x6 kernels");
-  gemm_seg16<NT, AMODE>(acc, As, a_ks0 / 4, nks / 4, reinterpret_cast<const uint4*>(Bw), KS / 4, b_ks0 / 4, nt0, wm, lane, save_dst,
-                        save_valid, wave);
+  NoChain nc;
+  gemm<MM, NT, AMODE, false>(acc, As, a_ks0, nks, Bw, KS, b_ks0, nt0, wm, lane, dbg, save_dst, save_valid, wave, nc);
 }
 template <int MM, int NT, int AMODE>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
@@ -914,6 +953,13 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restri
   else
     gemm_seg<NT, AMODE>(acc, As, a_ks0, nks, reinterpret_cast<const float4*>(Bw), KS, b_ks0, nt0, wm, lane, dbg, save_dst,
                         save_valid, wave);
+}
+template <int MM, int NT, int AMODE, bool PRE, typename W>   // (the 32 x 32 layouts take no preloaded weights: W is NoChain there)
+__device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
+                                     int KS, int b_ks0, int nt0, int wm, int lane, int dbg,
+                                     float* __restrict__ save_dst, int save_valid, int wave, W&) {
+  static_assert(std::is_same<W, NoChain>::value, "preloaded weights belong to the 16 x 16 path");
+  gemm<MM, NT, AMODE>(acc, As, a_ks0, nks, Bw, KS, b_ks0, nt0, wm, lane, dbg, save_dst, save_valid, wave);
 }
 // the block of a layer whose fp32 packing starts `off` floats into the packed buffer
 template <int MM>
@@ -940,6 +986,25 @@ __device__ __forceinline__ void zero_acc(f32x4m (&acc)[4][2 * NT]) {
     for (int ct = 0; ct < 2 * NT; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[mt][ct][r] = 0.f;
+}
+// X6_BIASFOLD: a layer's bias is the accumulators' initial value (the column is the same for a lane's four rows of every row tile) instead of 64
+// additions in the epilogue -- whose VALU instructions starve beside the partner wave's MFMA stream (tools/x6_timing.py: 14 cycles each)
+#ifndef X6_BIASFOLD
+#define X6_BIASFOLD 1
+#endif
+template <int NT>
+__device__ __forceinline__ void bias_acc(f32x4m (&acc)[4][2 * NT], const float (&bv)[2 * NT]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int ct = 0; ct < 2 * NT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][ct][r] = bv[ct];
+}
+template <int NT, bool FOLD, typename ACC, int NB>
+__device__ __forceinline__ void init_acc(ACC& acc, const float (&bv)[NB]) {
+  if constexpr (FOLD) bias_acc<NT>(acc, bv);
+  else zero_acc<NT>(acc);
 }
 // C layout of v_mfma_f32_16x16x32_bf16: col = lane & 15, row = 4 * (lane >> 4) + r.  Element (mt, ct, r) of a wave's 64 x 64 block is
 // H[wm*64 + mt*16 + 4*hq + r][(wn*CT + ct)*16 + (lane & 15)], hq = lane >> 4; the row's swizzle term m & 15 = (hq << 2) | r separates as in
@@ -1003,7 +1068,7 @@ __device__ __forceinline__ void load_bias(float (&bv)[NB], const float* __restri
 
 // bias values are loaded by the caller BEFORE the k-loop (load_bias) so that no global load waits
 // behind the activation stores issued at the end of the loop
-template <int NT, bool RELU, bool MASKS = false>
+template <int NT, bool RELU, bool MASKS = false, bool FOLDED = false>
 __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const float (&bias_v)[NT], float* Hs,
                                              int wm, int wn, int lane, float* __restrict__ save, int ldsave,
                                              int valid, unsigned long long* __restrict__ mask_out = nullptr) {
@@ -1042,7 +1107,7 @@ __device__ __forceinline__ void epilogue_fwd(const f32x16 (&acc)[2][NT], const f
 
 
 // the same epilogue on the 16 x 16 accumulator layout (X6_SHAPE16): value index i = (mt * CT + ct) * 4 + r in the lane's sign word
-template <int NT, bool RELU, bool MASKS = false>
+template <int NT, bool RELU, bool MASKS = false, bool FOLDED = false>
 __device__ __forceinline__ void epilogue_fwd(const f32x4m (&acc)[4][2 * NT], const float (&bias_v)[2 * NT], float* Hs, int wm, int wn, int lane,
                                              float* __restrict__ save, int ldsave, int valid,
                                              unsigned long long* __restrict__ mask_out = nullptr) {
@@ -1059,7 +1124,7 @@ __device__ __forceinline__ void epilogue_fwd(const f32x4m (&acc)[4][2 * NT], con
       const float bv = bias_v[ct];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[mt][ct][r] + bv;
+        float v = FOLDED ? acc[mt][ct][r] : acc[mt][ct][r] + bv;
         if (want_mask) {
           if ((mt * CT + ct) * 4 + r < 32)
             asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_max_f32 %1, 0, %1" : "+v"(wlo), "+v"(v) : : "vcc");
@@ -1238,28 +1303,36 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       }
     }
     constexpr bool L16 = MM == MM_X6 && X6_SHAPE16;
+    constexpr bool FOLD = L16 && X6_BIASFOLD;
+#ifndef X6_CHAIN_FWD
+#define X6_CHAIN_FWD 0   // the look-ahead load pays in dX (backward 9.26 -> 9.12 ms) and costs in the forward (3.99 -> 4.28 ms, before or behind the epilogue:
+#endif                   // gpurun_out/ab_chain2.log, ab_chain3.log); the forward keeps loading a segment's first weights in its prologue
+    constexpr bool CHAIN = L16 && X6_CHAIN && X6_CHAIN_FWD;   // the plain layers 1 .. 4, 6, 7 find their first weights loaded
     AccT<L16, 2> acc;
+    WRegsT<CHAIN, 2> wch;
+    constexpr int KS5 = (BG ? 96 + 256 : 64 + 256) / 8;
+    auto ahead = [&](int l) __attribute__((always_inline)) { wprefetch(wch, wblock<MM>(packed, lay.PF[l]), 32, 0, 32, wn * 2, lane); };
     // ---- L0 : pe -> 256 -----------------------------------------------------------------
-    zero_acc<2>(acc);
     float bv2[L16 ? 4 : 2];
     load_bias<2>(bv2, params + lay.LB[0], wn, lane);
+    init_acc<2, FOLD>(acc, bv2);
     gemm<MM, 2, 1>(acc, Es, 0, 8, wblock<MM>(packed, lay.PF[0]), PEP / 8, 0, wn * 2, wm, lane, dbg);
     if (BG) {
       gemm<MM, 2, 2>(acc, X2, 0, 4, wblock<MM>(packed, lay.PF[0]), PEP / 8, 8, wn * 2, wm, lane, dbg);
       __syncthreads();   // X2 lives in H: everyone must be done with it before H is written
     }
-    epilogue_fwd<2, true, SAVE>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
-                                SAVE ? maskw + (0 * NWAVES + wave) * 64 : nullptr);
+    ahead(1);
+    epilogue_fwd<2, true, SAVE, FOLD>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
+                                      SAVE ? maskw + (0 * NWAVES + wave) * 64 : nullptr);
     __syncthreads();
     // ---- L1..L7 -----------------------------------------------------------------------
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
-      zero_acc<2>(acc);
       const void* B = wblock<MM>(packed, lay.PF[l]);
       load_bias<2>(bv2, params + lay.LB[l], wn, lane);
+      init_acc<2, FOLD>(acc, bv2);
       float* sv = SAVE ? act + act_h(PL, PEP, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
       if (l == 5) {
-        const int KS5 = (PEP + 256) / 8;
         if (!BG) {
           gemm<MM, 2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
           gemm<MM, 2, 0>(acc, Hs, 0, 32, B, KS5, 8, wn * 2, wm, lane, dbg, sv, valid, wave);
@@ -1273,15 +1346,17 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         }
       } else {
         X6_T(t0);
-        gemm<MM, 2, 0>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave);
+        gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, B, 32, 0, wn * 2, wm, lane, dbg, sv, valid, wave, wch);
         X6_T(t1);
         X6_TADD(0, t1 - t0); X6_TADD(4, 1);
       }
       X6_T(t2);
       __syncthreads();  // every wave has finished reading H
       X6_T(t3);
-      epilogue_fwd<2, true, SAVE>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
-                                  SAVE ? maskw + (l * NWAVES + wave) * 64 : nullptr);
+      // (layer 5's two segments and the feature layer -- the alpha head and the direction encoding lie before it -- load their own)
+      if (l < 7 && l != 4) ahead(l + 1);
+      epilogue_fwd<2, true, SAVE, FOLD>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
+                                        SAVE ? maskw + (l * NWAVES + wave) * 64 : nullptr);
       X6_T(t4);
       __syncthreads();
       X6_T(t5);
@@ -1332,12 +1407,12 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       if (pq == 0 && pm < valid && raw) *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = make_float4(0.f, 0.f, 0.f, alpha_val);
     } else {
     // ---- feature layer (no ReLU) ------------------------------------------------------
-    zero_acc<2>(acc);
     load_bias<2>(bv2, params + lay.FB, wn, lane);
+    init_acc<2, FOLD>(acc, bv2);
     gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed, lay.PF[8]), 32, 0, wn * 2, wm, lane, dbg,
                    SAVE ? act + act_h(PL, PEP, 7) + p0 * 256 : nullptr, valid, wave);
     __syncthreads();
-    epilogue_fwd<2, false>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
+    epilogue_fwd<2, false, false, FOLD>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
     __syncthreads();
     if (SAVE) {
       float* avp = act + act_vpe(PL, PEP) + p0 * 32;
@@ -1350,14 +1425,14 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     // ---- view layer: [feat | vpe32] -> 128, ReLU ---------------------------------------
     {
       AccT<L16, 1> av;
-      zero_acc<1>(av);
       float bv1[L16 ? 2 : 1];
       load_bias<1>(bv1, params + lay.VB, wn, lane);
+      init_acc<1, FOLD>(av, bv1);
       gemm<MM, 1, 0>(av, Hs, 0, 32, wblock<MM>(packed, lay.PF[9]), 36, 0, wn, wm, lane, dbg,
                      SAVE ? act + act_feat(PL, PEP) + p0 * 256 : nullptr, valid, wave);
       gemm<MM, 1, 1>(av, Es, 0, 4, wblock<MM>(packed, lay.PF[9]), 36, 32, wn, wm, lane, dbg);
       __syncthreads();
-      epilogue_fwd<1, true>(av, bv1, Hs, wm, wn, lane, nullptr, 128, valid);
+      epilogue_fwd<1, true, false, FOLD>(av, bv1, Hs, wm, wn, lane, nullptr, 128, valid);
       __syncthreads();
       if (SAVE) {   // hv: 32 slots per row, whole 512-byte rows per half wave
         float* ahv = act + act_hv(PL, PEP) + p0 * 128;
@@ -1613,11 +1688,14 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     }
     __syncthreads();
     constexpr bool L16 = MM == MM_X6 && X6_SHAPE16;
+    constexpr bool CHAIN = L16 && X6_CHAIN;   // every 256 x 256 product after the first finds its first weights loaded (see mlp_fwd_kernel)
     AccT<L16, 2> acc;
+    WRegsT<L16, 2> wch;
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ------------------------------------------
     zero_acc<2>(acc);
     gemm<MM, 2, 0>(acc, Hs, 0, 16, wblock<MM>(packed_t, lay.PB[0]), 16, 0, wn * 2, wm, lane);
     __syncthreads();
+    wprefetch(wch, wblock<MM>(packed_t, lay.PB[1]), 32, 0, 32, wn * 2, lane);
     epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false, L16>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
                               valid);
     __syncthreads();
@@ -1625,9 +1703,10 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     zero_acc<2>(acc);
     {
       const DxPre pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
-      gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
-                         dact + dact_feat(PL) + p0 * 256, valid, wave);    // streams dfeat (what it reads) out
+      gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
+                            dact + dact_feat(PL) + p0 * 256, valid, wave, wch);    // streams dfeat (what it reads) out
       __syncthreads();
+      wprefetch(wch, wblock<MM>(packed_t, lay.PB[2]), 32, 0, 32, wn * 2, lane);
       epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
     }
     __syncthreads();
@@ -1637,9 +1716,10 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       const int64_t off = lay.PB[9 - l];   // PB[2] = L7t ... PB[8] = L1t
       zero_acc<2>(acc);
       const DxPre pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
-      gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
-                         dact + dact_y(PL, l) + p0 * 256, valid, wave);    // streams dY_l (what it reads) out
+      gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
+                            dact + dact_y(PL, l) + p0 * 256, valid, wave, wch);    // streams dY_l (what it reads) out
       __syncthreads();
+      wprefetch(wch, wblock<MM>(packed_t, lay.PB[l > 1 ? 10 - l : 8]), 32, 0, 32, wn * 2, lane);   // (l == 1: nobody's; a re-read)
       epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
       __syncthreads();
     }
