@@ -44,6 +44,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_F32 0
 #define MM_X6 1
+#define MM_H3 2   // "f16x3": MM_X6's kernels with the forward / dX products on two fp16 pieces (three products); dW as MM_X6
 // X6_SHAPE16 (round 4): the MM_X6 forward / dX kernels multiply on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  The chip is
 // power limited under these kernels and most of an MFMA's register traffic is its accumulator (C in + D out: 128 of ~160 bytes per lane
 // for the 32x32x16 shape); the 16x16x32 shape updates a quarter of the accumulator with twice the K: half the accumulator traffic per flop,
@@ -189,6 +190,27 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
   l = cvt_pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
 #endif
 }
+// MM_H3 ("f16x3", profiles/r04_f16x3_study.md): the forward / dX products of the MM_X6 kernels on TWO fp16 pieces with a scaled
+// residual -- x = h + 2^-12 l', h = fp16_rne(x), l' = fp16_rne((x - h) 2^12): |x - h - 2^-12 l'| <= 2^-23 |x| (rms 2^-24.4; three of four fp32
+// values are held exactly): ONE BIT short of fp32's 2^-24, below the fp32 accumulation error of this path's 128 ... 320-long sums --
+// and THREE products: Ah Wh into the layer's accumulators, Ah Wl' + Al' Wh into a second set that lives for one segment (gemm_seg16) and is
+// folded in (x 2^-12) at its end; the dropped Al' Wl' is 2^-24 relative (tests: logits vs fp64 as close as the fp32-MFMA kernels').  Same packed-weight layout as MM_X6 (planes h | l' | unused).
+// fp16's RANGE is the price: operands must stay below 65504 (activations and weights of this path do), and the dX kernel keeps its
+// gradients x 2^X6_H3_GSHIFT in LDS.  The dW kernel is MM_X6's (three bf16 pieces of the saved fp32 tensors: it has no room for a
+// second accumulator set).
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define X6_H3_SHIFT 12
+#define X6_H3_GSHIFT 14   // the dX kernel keeps its gradients x 2^14 in LDS (fp16's range: |dY| from 4e-9 normal, up to 4) and saves them unscaled
+__device__ __forceinline__ void split2h_pair(float x0, float x1, unsigned& h, unsigned& l) {
+  const f32x2v v = {x0, x1};
+  const f16x2v hv = __builtin_convertvector(v, f16x2v);
+  const f32x2v hf = __builtin_convertvector(hv, f32x2v);
+  const f32x2v rv = (v - hf) * (float)(1 << X6_H3_SHIFT);
+  h = __builtin_bit_cast(unsigned, hv);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, f16x2v));
+}
+template <bool H3>
 __global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* __restrict__ params,
                                                      uint4* __restrict__ pf, uint4* __restrict__ pb) {
   const PackDesc d = tab.d[blockIdx.y];
@@ -223,7 +245,10 @@ __global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* 
     }
     unsigned h[4], m[4], lo[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], lo[q]);
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (H3) { split2h_pair(v[2 * q], v[2 * q + 1], h[q], m[q]); lo[q] = 0u; }   // planes: h | l' | (unused)
+      else split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], lo[q]);
+    }
     uint4* o = dst + (blk * 3) * 64 + l;
     o[0] = make_uint4(h[0], h[1], h[2], h[3]);
     o[64] = make_uint4(m[0], m[1], m[2], m[3]);
@@ -292,12 +317,26 @@ extern "C" int64_t fastnerf_mlp_x6_packed_floats(int kind, int which) {
   const NetLayout& L = layout_of(kind);
   return (which == 1 ? L.pf_total : L.pb_total) * 3 / 2;
 }
+// The arithmetic behind the fastnerf_mlp_x6_* entry points (process-wide; the packed weights of one arithmetic are garbage to the other:
+// re-pack after a change).  0: bf16x6 (default) -- three bf16 pieces, six products everywhere.  1: f16x3 (MM_H3) -- forward and dX on two fp16
+// pieces with a scaled residual, three products; dW as bf16x6.  Returns the previous setting; any other argument only queries.
+static int g_x6_arith = 0;
+extern "C" int fastnerf_mlp_x6_arith(int arith) {
+  const int prev = g_x6_arith;
+  if (arith == 0 || arith == 1) g_x6_arith = arith;
+  return prev;
+}
+static int x6_mm() { return g_x6_arith ? MM_H3 : MM_X6; }
 extern "C" int fastnerf_mlp_x6_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream) {
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && params && packed_fwd && packed_bwd, "kind in 0..2, non-null pointers");
   static const PackTable T[3] = {make_pack_table(layout_of(0)), make_pack_table(layout_of(1)),
                                  make_pack_table(layout_of(2))};
-  hipLaunchKernelGGL(pack6_kernel, dim3(32, 19), dim3(256), 0, fn::S(stream), T[kind], params,
-                     reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
+  if (g_x6_arith)   // f16x3: planes h | l' | (zero); weights must be below fp16's 65504 in magnitude
+    hipLaunchKernelGGL(pack6_kernel<true>, dim3(32, 19), dim3(256), 0, fn::S(stream), T[kind], params,
+                       reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
+  else
+    hipLaunchKernelGGL(pack6_kernel<false>, dim3(32, 19), dim3(256), 0, fn::S(stream), T[kind], params,
+                       reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
   FN_LAUNCH_CHECK();
   return 0;
 }
@@ -746,35 +785,48 @@ template <bool L16, int NT> struct AccSel { typedef f32x16 type[2][NT]; };
 template <int NT> struct AccSel<true, NT> { typedef f32x4m type[4][2 * NT]; };
 template <bool L16, int NT> using AccT = typename AccSel<L16, NT>::type;
 
+template <bool H3>
 __device__ __forceinline__ f32x4m mfma16(const uint4& a, const uint4& b, f32x4m c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  if constexpr (H3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+template <bool H3> struct X6A {   // the arithmetic of a 16 x 16 x 32 tile product
+  static constexpr int NPL = H3 ? 2 : 3;               // weight / activation pieces
+  static constexpr int NPROD = H3 ? 3 : 6;             // MFMAs; H3: (l', h) and (h, l') into the segment's cross-term accumulators, (h, h) into the layer's
+  static constexpr int VP = H3 ? 7 : X6_PIPE_VP;       // VALU instructions of one pair's split (pin counts of the interleave)
+};
 struct Pieces16 { unsigned v[3][4]; };   // [piece h | m | l][pair of k] of ONE row tile
 __device__ __forceinline__ uint4 piece_frag16(const Pieces16& p, int pl) { return make_uint4(p.v[pl][0], p.v[pl][1], p.v[pl][2], p.v[pl][3]); }
+template <bool H3>
 __device__ __forceinline__ void split_pair16(const float4 (&ar)[2], Pieces16& pn, int q) {
   const float4& s4 = ar[q >> 1];
   const float x0 = (q & 1) ? s4.z : s4.x, x1 = (q & 1) ? s4.w : s4.y;
-  split3_pair_p(x0, x1, pn.v[0][q], pn.v[1][q], pn.v[2][q]);
+  if constexpr (H3) split2h_pair(x0, x1, pn.v[0][q], pn.v[1][q]);
+  else split3_pair_p(x0, x1, pn.v[0][q], pn.v[1][q], pn.v[2][q]);
 }
 // one unit: 6 * CT MFMAs of row tile MT on the pieces pc and the k-step's weight pieces b; between them the split of `ar` (the next unit's
 // raw fragment) into pn and, behind its last pair, `refill()` (the LDS reads that reload ar for the unit after that)
-template <int CT, int MT, int SYNC, typename ACC, typename RF>
-__device__ __forceinline__ void unit16(ACC& acc, const Pieces16& pc, const uint4 (&b)[CT][3], float4 (&ar)[2], Pieces16& pn, RF&& refill) {
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-  constexpr int NM = 6 * CT;
+#define X6_PA(H3) {(H3) ? 1 : 2, 0, (H3) ? 0 : 1, 1, 0, 0}   // piece of the activations / of the weights in product t
+#define X6_PB(H3) {0, (H3) ? 1 : 2, (H3) ? 0 : 1, 0, 1, 0}
+// (H3: the products t < NPROD - 1 are the cross terms and go to acc2, the segment's second accumulator set)
+template <bool H3, int CT, int MT, int SYNC, typename ACC, typename RF>
+__device__ __forceinline__ void unit16(ACC& acc, ACC& acc2, const Pieces16& pc, const uint4 (&b)[CT][3], float4 (&ar)[2], Pieces16& pn, RF&& refill) {
+  constexpr int PA[6] = X6_PA(H3), PB[6] = X6_PB(H3);
+  constexpr int NPROD = X6A<H3>::NPROD, NM = NPROD * CT;
 #pragma unroll
-  for (int t = 0; t < 6; ++t)
+  for (int t = 0; t < NPROD; ++t)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int i = t * CT + ct;
-      acc[MT][ct] = mfma16(piece_frag16(pc, PA[t]), b[ct][PB[t]], acc[MT][ct]);
+      if (H3 && t < NPROD - 1) acc2[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b[ct][PB[t]], acc2[MT][ct]);
+      else acc[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b[ct][PB[t]], acc[MT][ct]);
 #pragma unroll
       for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) {
-        split_pair16(ar, pn, pair);
+        split_pair16<H3>(ar, pn, pair);
         if (pair == 3) refill();
       }
     }
-  interleave6<0, NM, 4 * X6_PIPE_VP, SYNC>();
+  interleave6<0, NM, 4 * X6A<H3>::VP, SYNC>();
 }
 // X6_CHAIN: the weight pieces of a segment's first k-step are loaded by the CALLER one layer ahead -- between the barrier that ends
 // the previous layer's k-loop and its epilogue -- into registers that are dead there (they are the k-loop's own double buffer): the
@@ -783,12 +835,13 @@ __device__ __forceinline__ void unit16(ACC& acc, const Pieces16& pc, const uint4
 #define X6_CHAIN 1
 #endif
 struct NoChain {};
+struct NoChainGrad {};   // no preloaded weights either; marks the f16x3 dX kernel's calls (its LDS holds gradients x 2^X6_H3_GSHIFT)
 template <int CT> struct WRegs { uint4 b0[CT][3]; };   // k-step 0 (k-step 1 is not needed for ~3 000 cycles: the segment loads it itself)
 template <bool ON, int NT> struct WRegsSel { typedef NoChain type; };
 template <int NT> struct WRegsSel<true, NT> { typedef WRegs<2 * NT> type; };
 template <bool L16, int NT> using WRegsT = typename WRegsSel<L16 && X6_CHAIN, NT>::type;
 // arguments as gemm<>'s: KS, b_ks0, nks in the 8-wide k units of the call sites, nt0 = the wave's first 32-column tile
-template <int CT>
+template <bool H3, int CT>
 __device__ __forceinline__ void wprefetch(WRegs<CT>& w, const void* Bw, int KS, int b_ks0, int /*nks*/, int nt0, int lane) {
   const uint4* Bp = reinterpret_cast<const uint4*>(Bw);
   unsigned blane = (unsigned)lane * 16u;
@@ -797,12 +850,15 @@ __device__ __forceinline__ void wprefetch(WRegs<CT>& w, const void* Bw, int KS, 
   for (int ct = 0; ct < CT; ++ct) {
     const char* p = reinterpret_cast<const char*>(Bp + ((int64_t)(nt0 * 2 + ct) * (KS / 4) + b_ks0 / 4) * 192);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) w.b0[ct][pl] = *reinterpret_cast<const uint4*>((p + (pl * 64) * 16) + blane);
+    for (int pl = 0; pl < X6A<H3>::NPL; ++pl) w.b0[ct][pl] = *reinterpret_cast<const uint4*>((p + (pl * 64) * 16) + blane);
   }
 }
+template <bool H3>
 __device__ __forceinline__ void wprefetch(NoChain&, const void*, int, int, int, int, int) {}
+template <bool H3>
+__device__ __forceinline__ void wprefetch(NoChainGrad&, const void*, int, int, int, int, int) {}
 
-template <int NT, int AMODE, bool PRE, typename ACC, typename W>
+template <bool H3, int NT, int AMODE, bool PRE, typename ACC, typename W>
 __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ As, int a_ks0, int nks, const uint4* __restrict__ Bp, int KS,
                                            int b_ks0, int nt0, int wm, int lane, float* __restrict__ save_dst, int save_valid, int wave,
                                            W& wext) {
@@ -829,7 +885,7 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < X6A<H3>::NPL; ++pl) {
 #ifdef X6_ABL_WPIECES   // timing-only ablation (wrong results): only the first X6_ABL_WPIECES weight pieces are loaded
         if (pl >= X6_ABL_WPIECES) { b[ct][pl] = b[ct][0]; continue; }
 #endif
@@ -839,19 +895,27 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
   const int klast = nks - 1;
   float4 r0[2], r1[2];          // raw fragments of units u + 1 (being split) and u + 2 (in flight)
   Pieces16 pa, pb;              // pieces of the current and the next unit
-  constexpr bool CHAINED = !std::is_same<W, NoChain>::value;
+  constexpr bool CHAINED = !std::is_same<W, NoChain>::value && !std::is_same<W, NoChainGrad>::value;
+  constexpr bool GRADS = H3 && !std::is_same<W, NoChain>::value;   // the f16x3 dX kernel: rows saved from LDS are x 2^-X6_H3_GSHIFT
   static_assert(CHAINED || !PRE, "preloaded weights come through a WRegs");
   WRegs<CT> wloc_;
   WRegs<CT>& wr_ = [&]() -> WRegs<CT>& { if constexpr (CHAINED) return wext; else return wloc_; }();
   uint4 (&b0)[CT][3] = wr_.b0;
   uint4 b1[CT][3];
+  ACC acc2;                     // H3: cross terms of this segment (dead otherwise)
+  if constexpr (H3) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc2[mt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  }
   X6_T(tp0);
   if constexpr (!PRE) load_b(b0, 0);
   load_raw(r0, 0, 0);
   load_raw(r1, 1, 0);
   load_b(b1, klast > 0 ? 1 : 0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) split_pair16(r0, pa, q);     // unit 0 is split up front; its registers then take unit 2
+  for (int q = 0; q < 4; ++q) split_pair16<H3>(r0, pa, q);     // unit 0 is split up front; its registers then take unit 2
   load_raw(r0, 2, 0);
 #ifdef X6_TIMING
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the instrumented build waits here for what the first unit needs anyway)
@@ -866,10 +930,10 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
   auto kstep = [&](const uint4 (&b)[CT][3], int ks, auto par) __attribute__((always_inline)) {
     constexpr int S0 = 1 + 4 * decltype(par)::value;   // one sched_group_barrier pipeline per unit of the loop body
     const int kn = ks + 1 < klast ? ks + 1 : klast;   // k-step of units u + 3 / u + 4 once they wrap
-    unit16<CT, 0, S0 + 0>(acc, pa, b, r1, pb, [&]() { load_raw(r1, 3, ks); });
-    unit16<CT, 1, S0 + 1>(acc, pb, b, r0, pa, [&]() { load_raw(r0, 0, kn); });
-    unit16<CT, 2, S0 + 2>(acc, pa, b, r1, pb, [&]() { load_raw(r1, 1, kn); });
-    unit16<CT, 3, S0 + 3>(acc, pb, b, r0, pa, [&]() { load_raw(r0, 2, kn); });
+    unit16<H3, CT, 0, S0 + 0>(acc, acc2, pa, b, r1, pb, [&]() { load_raw(r1, 3, ks); });
+    unit16<H3, CT, 1, S0 + 1>(acc, acc2, pb, b, r0, pa, [&]() { load_raw(r0, 0, kn); });
+    unit16<H3, CT, 2, S0 + 2>(acc, acc2, pa, b, r1, pb, [&]() { load_raw(r1, 1, kn); });
+    unit16<H3, CT, 3, S0 + 3>(acc, acc2, pb, b, r0, pa, [&]() { load_raw(r0, 2, kn); });
   };
   constexpr std::integral_constant<int, 0> EVEN{};
   constexpr std::integral_constant<int, 1> ODD{};
@@ -887,26 +951,29 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
     // nks is even (8) for every saved segment: k-step nks - 2 as above, then the LAST k-step with the tile's rows streamed out between
     // its MFMAs (every load of the segment has been issued; rows beyond the valid count are clamped: rewritten with the same bytes)
     kstep(b0, nks - 2, EVEN);
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-    constexpr int ROWS = TM / NWAVES, NM = 6 * CT;
+    constexpr int PA[6] = X6_PA(H3), PB[6] = X6_PB(H3);
+    constexpr int NPROD = X6A<H3>::NPROD, ROWS = TM / NWAVES, NM = NPROD * CT;
     const int last_row = save_valid - 1;
     auto last_unit = [&](auto mtc, const Pieces16& pc, float4 (&ar)[2], Pieces16& pn) __attribute__((always_inline)) {
       constexpr int MT = decltype(mtc)::value;
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int i = t * CT + ct;
-          acc[MT][ct] = mfma16(piece_frag16(pc, PA[t]), b1[ct][PB[t]], acc[MT][ct]);
+          if (H3 && t < NPROD - 1) acc2[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b1[ct][PB[t]], acc2[MT][ct]);
+          else acc[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b1[ct][PB[t]], acc[MT][ct]);
           if (MT < 3) {
 #pragma unroll
-            for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) split_pair16(ar, pn, pair);
+            for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) split_pair16<H3>(ar, pn, pair);
           }
 #pragma unroll
           for (int r = (i * (ROWS / 4)) / NM; r < ((i + 1) * (ROWS / 4)) / NM; ++r) {
             int m = (MT * (ROWS / 4) + r) * NWAVES + wave;
             m = m < last_row ? m : last_row;
-            const float4 v = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
+            const float4 v0 = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
+            constexpr float ig = GRADS ? 1.f / (float)(1 << X6_H3_GSHIFT) : 1.f;
+            const float4 v = GRADS ? make_float4(v0.x * ig, v0.y * ig, v0.z * ig, v0.w * ig) : v0;
             store_nt(save_dst + (unsigned)(m * 256 + ((lane ^ (m & 15)) << 2)), v);
           }
         }
@@ -920,6 +987,12 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 #if X6_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
+  if constexpr (H3) {   // fold the segment's cross terms in
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[mt][ct] += acc2[mt][ct] * (1.f / (float)(1 << X6_H3_SHIFT));
+  }
 }
 
 // one call site for both math modes: k-steps in the 8-wide units of gemm_seg, Bw = the layer's block in this mode's packing
@@ -927,8 +1000,8 @@ template <int MM, int NT, int AMODE, bool PRE, typename W>
 __device__ __forceinline__ void gemm(f32x4m (&acc)[4][2 * NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
                                      int KS, int b_ks0, int nt0, int wm, int lane, int dbg,
                                      float* __restrict__ save_dst, int save_valid, int wave, W& w) {
-  static_assert(MM == MM_X6, "the 16 x 16 accumulator layout belongs to the bf16x6 kernels");
-  gemm_seg16<NT, AMODE, PRE>(acc, As, a_ks0 / 4, nks / 4, reinterpret_cast<const uint4*>(Bw), KS / 4, b_ks0 / 4, nt0, wm, lane, save_dst,
+  static_assert(MM != MM_F32, "the 16 x 16 accumulator layout belongs to the bf16x6 / f16x3 kernels");
+  gemm_seg16<MM == MM_H3, NT, AMODE, PRE>(acc, As, a_ks0 / 4, nks / 4, reinterpret_cast<const uint4*>(Bw), KS / 4, b_ks0 / 4, nt0, wm, lane, save_dst,
                              save_valid, wave, w);
 }
 template <int MM, int NT, int AMODE>
@@ -942,6 +1015,7 @@ template <int MM, int NT, int AMODE>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
                                      int KS, int b_ks0, int nt0, int wm, int lane, int dbg = 0,
                                      float* __restrict__ save_dst = nullptr, int save_valid = 0, int wave = 0) {
+  static_assert(MM != MM_H3, "f16x3 exists on the 16 x 16 x 32 shape only");
   if constexpr (MM == MM_X6)
 #if X6_PIPE
     gemm_seg6p<NT, AMODE>(acc, As, a_ks0 / 2, nks / 2, reinterpret_cast<const uint4*>(Bw), KS / 2, b_ks0 / 2, nt0, wm, lane,
@@ -964,7 +1038,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[2][NT], const float* __restri
 // the block of a layer whose fp32 packing starts `off` floats into the packed buffer
 template <int MM>
 __device__ __forceinline__ const void* wblock(const float* packed, int64_t off) {
-  if constexpr (MM == MM_X6) return reinterpret_cast<const uint4*>(packed) + off * 3 / 8;
+  if constexpr (MM != MM_F32) return reinterpret_cast<const uint4*>(packed) + off * 3 / 8;
   else return reinterpret_cast<const float4*>(packed) + off / 4;
 }
 
@@ -1302,7 +1376,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         }
       }
     }
-    constexpr bool L16 = MM == MM_X6 && X6_SHAPE16;
+    constexpr bool L16 = MM != MM_F32 && X6_SHAPE16;
     constexpr bool FOLD = L16 && X6_BIASFOLD;
 #ifndef X6_CHAIN_FWD
 #define X6_CHAIN_FWD 0   // the look-ahead load pays in dX (backward 9.26 -> 9.12 ms) and costs in the forward (3.99 -> 4.28 ms, before or behind the epilogue:
@@ -1311,7 +1385,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     AccT<L16, 2> acc;
     WRegsT<CHAIN, 2> wch;
     constexpr int KS5 = (BG ? 96 + 256 : 64 + 256) / 8;
-    auto ahead = [&](int l) __attribute__((always_inline)) { wprefetch(wch, wblock<MM>(packed, lay.PF[l]), 32, 0, 32, wn * 2, lane); };
+    auto ahead = [&](int l) __attribute__((always_inline)) { wprefetch<MM == MM_H3>(wch, wblock<MM>(packed, lay.PF[l]), 32, 0, 32, wn * 2, lane); };
     // ---- L0 : pe -> 256 -----------------------------------------------------------------
     float bv2[L16 ? 4 : 2];
     load_bias<2>(bv2, params + lay.LB[0], wn, lane);
@@ -1509,6 +1583,10 @@ static int fwd_launch(int kind, int64_t n, int S, const float* rays11, const flo
     if (kind == 2) return act ? FN_FWD(true, true, MM_X6) : FN_FWD(false, true, MM_X6);
     return act ? FN_FWD(true, false, MM_X6) : FN_FWD(false, false, MM_X6);
   }
+  if (mm == MM_H3) {
+    if (kind == 2) return act ? FN_FWD(true, true, MM_H3) : FN_FWD(false, true, MM_H3);
+    return act ? FN_FWD(true, false, MM_H3) : FN_FWD(false, false, MM_H3);
+  }
   if (kind == 2) return act ? FN_FWD(true, true, MM_F32) : FN_FWD(false, true, MM_F32);
   return act ? FN_FWD(true, false, MM_F32) : FN_FWD(false, false, MM_F32);
 #undef FN_FWD
@@ -1665,7 +1743,9 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       const bool ok = pm < valid;
       const int64_t pp = ok ? p0 + pm : P - 1;
       const float4 dr = *reinterpret_cast<const float4*>(draw + (live_idx ? (int64_t)live_idx[pp] : pp) * 4);
-      if (pq == 0) Es[pm] = ok ? dr.w : 0.f;
+      constexpr float GS = (float)(1 << X6_H3_GSHIFT);   // MM_H3: the tile's gradients live in LDS x GS (a power of two: exact)
+      if constexpr (MM == MM_H3) { if (pq == 0) Es[pm] = ok ? dr.w * GS : 0.f; }
+      else { if (pq == 0) Es[pm] = ok ? dr.w : 0.f; }
       const float* wr = params + lay.RW;
       const float* hv = act + act_hv(PL, lay.pe_pad) + pp * 128;
       float* dyv = dact + dact_yv(PL) + pp * 128;
@@ -1682,20 +1762,25 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
         o.z = (h.z > 0.f) ? fmaf(dr.z, w2.z, fmaf(dr.y, w1.z, dr.x * w0.z)) : 0.f;
         o.w = (h.w > 0.f) ? fmaf(dr.z, w2.w, fmaf(dr.y, w1.w, dr.x * w0.w)) : 0.f;
         if (!ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = o;
+        if constexpr (MM == MM_H3)
+          *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = make_float4(o.x * GS, o.y * GS, o.z * GS, o.w * GS);
+        else
+          *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = o;
         if (ok) store_nt(dyv + k, o);
       }
     }
     __syncthreads();
-    constexpr bool L16 = MM == MM_X6 && X6_SHAPE16;
-    constexpr bool CHAIN = L16 && X6_CHAIN;   // every 256 x 256 product after the first finds its first weights loaded (see mlp_fwd_kernel)
+    constexpr bool L16 = MM != MM_F32 && X6_SHAPE16;
+    // every 256 x 256 product after the first finds its first weights loaded (see mlp_fwd_kernel); not under MM_H3, whose second
+    // accumulator set leaves no registers for them (backward 8.84 -> 8.67 ms without)
+    constexpr bool CHAIN = L16 && X6_CHAIN && MM != MM_H3;
     AccT<L16, 2> acc;
-    WRegsT<L16, 2> wch;
+    typename std::conditional<MM == MM_H3, NoChainGrad, WRegsT<L16, 2>>::type wch;
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ------------------------------------------
     zero_acc<2>(acc);
     gemm<MM, 2, 0>(acc, Hs, 0, 16, wblock<MM>(packed_t, lay.PB[0]), 16, 0, wn * 2, wm, lane);
     __syncthreads();
-    wprefetch(wch, wblock<MM>(packed_t, lay.PB[1]), 32, 0, 32, wn * 2, lane);
+    wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[1]), 32, 0, 32, wn * 2, lane);
     epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false, L16>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
                               valid);
     __syncthreads();
@@ -1706,7 +1791,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
                             dact + dact_feat(PL) + p0 * 256, valid, wave, wch);    // streams dfeat (what it reads) out
       __syncthreads();
-      wprefetch(wch, wblock<MM>(packed_t, lay.PB[2]), 32, 0, 32, wn * 2, lane);
+      wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[2]), 32, 0, 32, wn * 2, lane);
       epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
     }
     __syncthreads();
@@ -1719,7 +1804,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
                             dact + dact_y(PL, l) + p0 * 256, valid, wave, wch);    // streams dY_l (what it reads) out
       __syncthreads();
-      wprefetch(wch, wblock<MM>(packed_t, lay.PB[l > 1 ? 10 - l : 8]), 32, 0, 32, wn * 2, lane);   // (l == 1: nobody's; a re-read)
+      wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[l > 1 ? 10 - l : 8]), 32, 0, 32, wn * 2, lane);   // (l == 1: nobody's; a re-read)
       epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
       __syncthreads();
     }
@@ -1727,8 +1812,17 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       float* d0 = dact + dact_y(PL, 0) + p0 * 256;
       for (int i = tid; i < TM * 64; i += NTHR) {
         const int m = i >> 6, sl = i & 63;
-        if (m < valid)
-          store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
+        if constexpr (MM == MM_H3) {
+          if (m < valid) {
+            float4 v = *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4);
+            constexpr float ig = 1.f / (float)(1 << X6_H3_GSHIFT);
+            v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
+            store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), v);
+          }
+        } else {
+          if (m < valid)
+            store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
+        }
       }
     }
     tile = b_next_tile(sched, sched_word, tid);   // closing barrier inside: H is rewritten by the next tile's phase A
@@ -2364,6 +2458,7 @@ template <int MM>
 static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                       const float* packed_bwd, float* dact, float* partial, float* grads, const int* live_idx,
                       const int* live_cnt, fn_stream_t stream) {
+  constexpr int MW = (MM == MM_H3) ? MM_X6 : MM;   // the dW jobs of f16x3 are bf16x6's (three bf16 pieces of the saved fp32 tensors)
   const NetLayout& L = layout_of(kind);
   const int PEP = L.pe_pad;
   hipStream_t st = fn::S(stream);
@@ -2402,48 +2497,48 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
   };
   // L0 (+ L5's pe part in the same job under MM_X6: one read and one split of the positional encoding for both;
   //     8 waves x (64 outputs x all pe tiles), partials [512][pe] + bias [256] across the neighbouring regions of jobs 0 and 8)
-  if constexpr (MM == MM_X6 && !X6_DW_SYNC) {
-    if (PEP == 64) rc = launch_dw<8, 1, 2, 2, true, false, MM, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
-    else rc = launch_dw<8, 1, 2, 3, true, false, MM, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
+  if constexpr (MW == MM_X6 && !X6_DW_SYNC) {
+    if (PEP == 64) rc = launch_dw<8, 1, 2, 2, true, false, MW, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
+    else rc = launch_dw<8, 1, 2, 3, true, false, MW, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
     if (rc) return rc;
     const int64_t b0 = dw_job_base(0, ncu, PEP);
     add_seg(T, b0, (int64_t)512 * PEP, nwg, 256, PEP, L.LW[0], L.in_pe, L.in_pe);
     add_seg(T, b0 + (int64_t)256 * PEP, (int64_t)512 * PEP, nwg, 256, PEP, L.LW[5], 256 + L.in_pe, L.in_pe);
     add_seg(T, b0 + (int64_t)nwg * 512 * PEP, 256, nwg, 1, 256, L.LB[0], 256, 256);
   } else {
-    if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
-    else rc = launch_dw<4, 1, 2, 3, true, false, MM>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
+    if (PEP == 64) rc = launch_dw<4, 1, 2, 2, true, false, MW>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt);
+    else rc = launch_dw<4, 1, 2, 3, true, false, MW>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt);
     if (rc) return rc;
     segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
   }
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
-    if ((rc = launch_dw<4, 2, 2, 4, true, false, MM>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
+    if ((rc = launch_dw<4, 2, 2, 4, true, false, MW>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
   }
   // L5 pe part (MM_X6: done with L0 above)
-  if constexpr (!(MM == MM_X6 && !X6_DW_SYNC)) {
-    if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
-    else rc = launch_dw<4, 1, 2, 3, false, false, MM>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
+  if constexpr (!(MW == MM_X6 && !X6_DW_SYNC)) {
+    if (PEP == 64) rc = launch_dw<4, 1, 2, 2, false, false, MW>(P, dact + dact_y(P, 5), 256, a_pe, 64, nullptr, region(8), nwg, st, live_idx, live_cnt);
+    else rc = launch_dw<4, 1, 2, 3, false, false, MW>(P, dact + dact_y(P, 5), 256, a_pe, 96, nullptr, region(8), nwg, st, live_idx, live_cnt);
     if (rc) return rc;
     segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
   }
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
-  if ((rc = launch_dw<4, 2, 2, 4, true, true, MM>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
+  if ((rc = launch_dw<4, 2, 2, 4, true, true, MW>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
   segs(9, L.FW, 256, 256, L.FB, L.AW);
   // view layer
-  if constexpr (MM == MM_X6 && !X6_DW_SYNC) {
+  if constexpr (MW == MM_X6 && !X6_DW_SYNC) {
     // one job for both inputs of the view layer (feature [P,256] | encoded direction [P,32]): dYv is read and split once; 12 waves,
     // partials [128][288] + bias [128] across the (adjacent) regions of jobs 10 and 11
-    if ((rc = launch_dw<4, 3, 1, 3, true, false, MM, 1>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st,
+    if ((rc = launch_dw<4, 3, 1, 3, true, false, MW, 1>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st,
                                                         live_idx, live_cnt, act + act_vpe(P, PEP)))) return rc;
     const int64_t b10 = dw_job_base(10, ncu, PEP);
     add_seg(T, b10, 128 * 288, nwg, 128, 288, L.VW, 283, 283);
     add_seg(T, b10 + (int64_t)nwg * 128 * 288, 128, nwg, 1, 128, L.VB, 128, 128);
   } else {
-    if ((rc = launch_dw<2, 4, 2, 2, true, false, MM>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st, live_idx, live_cnt))) return rc;
+    if ((rc = launch_dw<2, 4, 2, 2, true, false, MW>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st, live_idx, live_cnt))) return rc;
     segs(10, L.VW, 283, 256, L.VB, 0);
-    if ((rc = launch_dw<4, 1, 1, 1, false, false, MM>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
+    if ((rc = launch_dw<4, 1, 1, 1, false, false, MW>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
     segs(11, L.VW + 256, 283, 27, 0, 0);
   }
   // rgb head + alpha bias
@@ -2462,6 +2557,7 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
 static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                       const float* packed_bwd, float* dact, float* partial, float* grads, const int* live_idx,
                       const int* live_cnt, fn_stream_t stream, int mm = MM_F32) {
+  if (mm == MM_H3) return bwd_launch_t<MM_H3>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream);
   return mm == MM_X6 ? bwd_launch_t<MM_X6>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream)
                      : bwd_launch_t<MM_F32>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream);
 }
@@ -2494,13 +2590,13 @@ extern "C" int fastnerf_mlp_x6_fwd(int kind, int64_t n, int S, const float* rays
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
   FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
   if (n == 0) return 0;
-  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream, flags, MM_X6);
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream, flags, x6_mm());
 }
 extern "C" int fastnerf_mlp_x6_bwd(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                                    const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream) {
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads, "null pointer");
-  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, nullptr, nullptr, stream, MM_X6);
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, nullptr, nullptr, stream, x6_mm());
 }
 extern "C" int fastnerf_mlp_x6_fwd_live(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
                                         const float* packed_fwd, float* act, const int32_t* live_idx, const int32_t* live_cnt,
@@ -2508,12 +2604,12 @@ extern "C" int fastnerf_mlp_x6_fwd_live(int kind, int64_t n, int S, const float*
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(rays11 && z && params && packed_fwd && act && live_idx && live_cnt, "null pointer");
   FN_CHECK_ARG(n * (int64_t)S < ((int64_t)1 << 31), "live lists index points with int32");
-  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, nullptr, act, live_idx, live_cnt, stream, 0, MM_X6);
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, nullptr, act, live_idx, live_cnt, stream, 0, x6_mm());
 }
 extern "C" int fastnerf_mlp_x6_bwd_live(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                                         const float* packed_bwd, float* dact, float* partial, float* grads,
                                         const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream) {
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads && live_idx && live_cnt, "null pointer");
-  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream, MM_X6);
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream, x6_mm());
 }

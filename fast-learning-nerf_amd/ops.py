@@ -26,8 +26,13 @@ DACT_FLOATS = 2432
 #            packed weights (three bf16 planes)
 # 'bf16x3' : 3-term split-bf16 (two pieces, 16 significand bits) on the same instruction (csrc/mlp_bf16.hip): NARROWER than
 #            fp32 (products ~2^-17 relative), ~2.5x the rate of 'fp32'; rendered RGB still within 1e-6 of the fp32 kernels
+# 'f16x3'  : csrc/mlp.hip MM_H3 -- the forward and dX products of 'bf16x6' on TWO fp16 pieces with a scaled residual
+#            (x = h + 2^-12 l', both rounded to nearest: <= 2^-23 relative, rms 2^-24.4 -- one bit short of fp32) and THREE products with fp32
+#            accumulation; dW as 'bf16x6'.  Logits as close to fp64 as the 'fp32' kernels' (accumulation dominates) at half the matrix work (profiles/r04_f16x3_study.md);
+#            fp16's RANGE applies: weights and activations must stay below 65504 in magnitude (they do on this path)
 import os
-MATH_MODES = ('fp32', 'bf16x3', 'bf16x6')
+MATH_MODES = ('fp32', 'bf16x3', 'bf16x6', 'f16x3')
+_MODE_ID = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'f16x3': 2}   # 'f16x3' rides the bf16x6 entry points (fastnerf_mlp_x6_arith selects it)
 _MATH = os.environ.get('FASTNERF_MATH', 'bf16x6')   # default: the reference's arithmetic width
 assert _MATH in MATH_MODES, 'FASTNERF_MATH must be one of ' + ', '.join(MATH_MODES)
 
@@ -42,15 +47,23 @@ def set_math(mode):
     global _MATH
     assert mode in MATH_MODES
     _MATH = mode
+    _sync_arith()
+
+
+def _sync_arith():
+    """Point the fastnerf_mlp_x6_* entry points at the arithmetic of the current mode (process-wide switch in the library)."""
+    if _x6():
+        lib().fastnerf_mlp_x6_arith(1 if _MATH == 'f16x3' else 0)
 
 
 def mode_id():
     """math_mode argument of the fused C-ABI entry points (fastnerf_render_rays_*, fastnerf_train_step)."""
-    return MATH_MODES.index(_MATH)
+    _sync_arith()
+    return _MODE_ID[_MATH]
 
 
 def _x6():
-    return _MATH == 'bf16x6'
+    return _MATH in ('bf16x6', 'f16x3')
 
 
 # math mode a packed-weight buffer was produced under: a Python attribute on the tensor object AND a registry by storage
@@ -209,6 +222,7 @@ def mlp_pack(params, packed_fwd=None, packed_bwd=None, kind=0):
               'fastnerf_mlp_bf16_pack')
         return packed_fwd, packed_bwd
     if _x6():
+        _sync_arith()
         check(lib().fastnerf_mlp_x6_pack(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()), 'fastnerf_mlp_x6_pack')
         return packed_fwd, packed_bwd
     check(lib().fastnerf_mlp_pack_ex(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),

@@ -84,9 +84,9 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=['fp32', 'bf16x3', 'bf16x6'])
+@pytest.fixture(params=['fp32', 'bf16x3', 'bf16x6', 'f16x3'])
 def math_mode(request):
-    """Run a GPU test under both matrix-core math modes of the MLP kernels (ops.set_math)."""
+    """Run a GPU test under every matrix-core math mode of the MLP kernels (ops.set_math)."""
     import fastnerf
     old = fastnerf.ops.get_math()
     fastnerf.ops.set_math(request.param)

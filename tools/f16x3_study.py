@@ -2,7 +2,7 @@
 """CPU study (numpy, no GPU): would a TWO-piece fp16 operand split with a scaled residual -- three matrix products instead of the
 six of the bf16x6 mode -- still be fp32-wide?
 
-  x  =  h + l' * 2^-12 + e,     h = fp16_rne(x),   l' = fp16_rne((x - h) * 2^12),   |e| <= 2^-24 |x|   (two roundings to nearest:
+  x  =  h + l' * 2^-12 + e,     h = fp16_rne(x),   l' = fp16_rne((x - h) * 2^12),   |e| <= 2^-23 |x|   (two roundings to nearest:
                                                                                   11 + 11 bits and one bit from each sign)
   A W  ~=  Ah Wh  +  2^-12 (Ah Wl' + Al' Wh)          (two fp32 accumulators; the dropped Al' Wl' term is 2^-24 relative)
 
