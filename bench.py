@@ -17,6 +17,8 @@ test_bf16x6_decomposition_is_exact_and_products_have_fp32_width, profiles/r03_pr
 
 Everything else rides in the same JSON line as named sibling blocks and never feeds `value`:
   fp32_mfma_mode     the same protocol on v_mfma_f32_32x32x2_f32 (an fp32 FMA chain bit for bit; 157 TFLOP/s ceiling);
+  f16x3_mode         the same protocol with the forward / dX products on two fp16 pieces + scaled residual (three products; operands one bit
+                     short of fp32, logits vs fp64 as close as fp32's): the faster arithmetic, offered beside the headline, never `value`;
   split_bf16_mode    the same protocol in the split-bf16 mode (3 bf16 MFMA products per fp32 product, 16-bit operands: faster and
                      NARROWER than fp32, hence not the headline), plus that mode on a trained sparse scene with the exact
                      zero-gradient compaction (what a converged Lego-like field looks like to the backward);
@@ -60,6 +62,7 @@ PROFILE_ROUND = 'r04'
 MAIN_MODE = 'bf16x6'                        # the headline's arithmetic: fp32-width products on the bf16 matrix cores (docstring)
 MODE_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 1.0, 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'mlp_fwd_kernel', ', 0'),
              'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6.0, 6.0, 'dense bf16 MFMA 2500 TFLOP/s / 6 piece products per fp32 product', 'mlp_fwd_kernel', ', 1'),
+             'f16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 3.0, 'dense fp16 MFMA 2500 TFLOP/s / 3 piece products per fp32 product (forward and dX; the dW launches of this mode are bf16x6\'s)', 'mlp_fwd_kernel', ', 2'),
              'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 3.0, 'dense bf16 MFMA 2500 TFLOP/s / 3 split terms per product', 'mlp_fwd_bf16_kernel', '')}
 H = W = 800
 FOCAL = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
@@ -615,7 +618,7 @@ def main():
     # =====================================================================================================================
     # siblings (1 GPU, rank 0): never part of `value`
     # =====================================================================================================================
-    split_block = fp32_block = drop_in = infer = psnr_block = cfg_blocks = None
+    split_block = fp32_block = f16_block = drop_in = infer = psnr_block = cfg_blocks = None
     trb = kte_b = kte_32 = None
     if not a.no_siblings:
         # ---- the same protocol (random init, noise targets, plain backward) in the other two modes; every rank takes part -----
@@ -629,6 +632,20 @@ def main():
                                             step_frac_of_fp32_mfma_peak=n_step * 20 / t32_ * TRAIN_FLOP_PER_RAY / 1e12 / world / FP32_MFMA_PEAK_TFLOPS),
                           'roofline': mlp_roofline(tr32, 'fp32')}
         del tr32
+        # ---- f16x3: the headline's kernels with the forward / dX products on two fp16 pieces + scaled residual (three products) ----
+        ops.set_math('f16x3')
+        trh, _, _, _ = new_trainer()
+        th_, lh_, _ = timed(lambda i: step(trh, i)[0], 0, 3, 20)
+        if rank == 0:
+            f16_block = {'math_mode': 'f16x3',
+                         'dtype': 'f16x3: forward and dX products as Ah*Wh + 2^-12 (Ah*Wl + Al*Wh) on the fp16 matrix cores (v_mfma_f32_16x16x32_f16), '
+                                  'x = h + 2^-12 l with two roundings to nearest: operands to 2^-23 relative (ONE BIT short of fp32; rms 2^-24.4), fp32 '
+                                  'accumulation, cross terms in their own accumulators; dW as bf16x6.  Logits vs fp64 as close as the fp32-MFMA kernels\' '
+                                  '(tests/test_gpu_mlp.py), paired PSNR test G22 in this mode too -- a sibling because its operands are not bit-for-bit fp32-wide',
+                         'init_state': leg(th_, 20, warmup=3, backward='plain', final_loss=[float(x) for x in lh_.tolist()],
+                                           what='the headline protocol (random init, U[0,1) targets, plain backward) in this mode'),
+                         'roofline': mlp_roofline(trh, 'f16x3')}
+        del trh
         ops.set_math('bf16x3')
         trb, _, kte_b, _ = new_trainer()
         tb, lb, _ = timed(lambda i: step(trb, i)[0], 0, 3, 20)
@@ -797,6 +814,7 @@ def main():
             'roofline': roof,
             'psnr_vs_cpu': psnr_block,
             'fp32_mfma_mode': fp32_block,
+            'f16x3_mode': f16_block,
             'split_bf16_mode': split_block,
             'drop_in_route': drop_in,
             'other_configs': cfg_blocks,

@@ -224,7 +224,7 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
     chaos.  Asserted: (a) POWER -- the standard error of the mean difference is below 0.09 dB, i.e. a 0.15 dB bias is visible at
     >= 1.7 standard errors and a 0.25 dB bias at >= 2.8; (b) the mean difference is compatible with a bias below 0.05 dB:
     |mean| < 0.05 + 2.6 SE (a true bias of 0.3 dB fails this with > 95 % probability); (c) runs that collapse to the empty scene
-    (PSNR < 15 dB) are the same seeds on both sides, up to two.  Both the headline arithmetic and the fp32 FMA-chain mode."""
+    (PSNR < 15 dB) are the same seeds on both sides, up to two.  The headline arithmetic, the fp32 FMA-chain mode and f16x3."""
     import os
     from oracle import psnr_protocol as P
     path = os.path.join(golden_dir, 'g22_psnr_cpu_ensemble.npz')
@@ -268,7 +268,7 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
         return P.psnr(np.mean(ls[-P.WINDOW:])), P.psnr(mse), float(ls[0])
     checks = []
     try:
-        for mode in ('bf16x6', 'fp32'):
+        for mode in ('bf16x6', 'fp32', 'f16x3'):
             g_train, g_held = [], []
             for i, seed in enumerate(seeds):
                 runs = [gpu_run(seed, mode, j) for j in range(members)]
