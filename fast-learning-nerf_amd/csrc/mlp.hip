@@ -201,6 +201,12 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define X6_H3_SHIFT 12
+#ifndef X6_H3_DX_COPY
+#define X6_H3_DX_COPY 1
+#endif
+#ifndef X6_H3_PRE_LATE
+#define X6_H3_PRE_LATE 0   // 1: the f16x3 dX kernel fetches a layer's sign words behind its k-loop instead of ahead of it (A/B: 15.60 vs 15.72 ms step, no gain)
+#endif
 #define X6_H3_GSHIFT 14   // the dX kernel keeps its gradients x 2^14 in LDS (fp16's range: |dY| from 4e-9 normal, up to 4) and saves them unscaled
 __device__ __forceinline__ void split2h_pair(float x0, float x1, unsigned& h, unsigned& l) {
   const f32x2v v = {x0, x1};
@@ -993,7 +999,7 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[mt][ct] += acc2[mt][ct] * (1.f / (float)(1 << X6_H3_SHIFT));
+      for (int ct = 0; ct < CT; ++ct) acc[mt][ct] += acc2[mt][ct] * (1.f / (float)(1 << X6_H3_SHIFT));   // (as an explicit fma the saving forward spills 450 registers)
   }
 }
 
@@ -1773,6 +1779,20 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     }
     __syncthreads();
     constexpr bool L16 = MM != MM_F32 && X6_SHAPE16;
+    // MM_H3 (X6_H3_DX_COPY): a product's input tile (the gradient it multiplies, x 2^X6_H3_GSHIFT in LDS) is written out by the whole workgroup
+    // BEFORE its k-loop instead of being streamed between the MFMAs of its last k-step (where, with two accumulator sets live, the compiler
+    // spills accumulators around the stores)
+    auto copy_out = [&](float* __restrict__ dst) __attribute__((always_inline)) {
+      constexpr float ig = 1.f / (float)(1 << X6_H3_GSHIFT);
+      for (int i = tid; i < TM * 64; i += NTHR) {
+        const int m = i >> 6, sl = i & 63;
+        if (m < valid) {
+          float4 v = *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4);
+          v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
+          store_nt(dst + m * 256 + ((sl ^ (m & 15)) << 2), v);
+        }
+      }
+    };
     // every 256 x 256 product after the first finds its first weights loaded (see mlp_fwd_kernel); not under MM_H3, whose second
     // accumulator set leaves no registers for them (backward 8.84 -> 8.67 ms without)
     constexpr bool CHAIN = L16 && X6_CHAIN && MM != MM_H3;
@@ -1789,9 +1809,13 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ------------------------------------
     zero_acc<2>(acc);
     {
-      const DxPre pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
+      // (MM_H3: the sign words and rank-1 weights are fetched BEHIND the k-loop -- its two accumulator sets leave no registers to hold them)
+      DxPre pre;
+      if constexpr (!(MM == MM_H3 && X6_H3_PRE_LATE)) pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
+      if constexpr (MM == MM_H3 && X6_H3_DX_COPY) copy_out(dact + dact_feat(PL) + p0 * 256);
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
-                            dact + dact_feat(PL) + p0 * 256, valid, wave, wch);    // streams dfeat (what it reads) out
+                            (MM == MM_H3 && X6_H3_DX_COPY) ? nullptr : dact + dact_feat(PL) + p0 * 256, valid, wave, wch);    // streams dfeat (what it reads) out
+      if constexpr (MM == MM_H3 && X6_H3_PRE_LATE) pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
       __syncthreads();
       wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[2]), 32, 0, 32, wn * 2, lane);
       epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
@@ -1802,9 +1826,12 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     for (int l = 7; l >= 1; --l) {
       const int64_t off = lay.PB[9 - l];   // PB[2] = L7t ... PB[8] = L1t
       zero_acc<2>(acc);
-      const DxPre pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
+      DxPre pre;
+      if constexpr (!(MM == MM_H3 && X6_H3_PRE_LATE)) pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
+      if constexpr (MM == MM_H3 && X6_H3_DX_COPY) copy_out(dact + dact_y(PL, l) + p0 * 256);
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
-                            dact + dact_y(PL, l) + p0 * 256, valid, wave, wch);    // streams dY_l (what it reads) out
+                            (MM == MM_H3 && X6_H3_DX_COPY) ? nullptr : dact + dact_y(PL, l) + p0 * 256, valid, wave, wch);    // streams dY_l (what it reads) out
+      if constexpr (MM == MM_H3 && X6_H3_PRE_LATE) pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
       __syncthreads();
       wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[l > 1 ? 10 - l : 8]), 32, 0, 32, wn * 2, lane);   // (l == 1: nobody's; a re-read)
       epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
