@@ -201,6 +201,9 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define X6_H3_SHIFT 12
+#ifndef X6_H3_FWD_COPY
+#define X6_H3_FWD_COPY 0   // 1: the same for the saving forward (A/B: saving forward 3.46 -> 3.60 ms: worse; its in-loop stream does not spill)
+#endif
 #ifndef X6_H3_DX_COPY
 #define X6_H3_DX_COPY 1
 #endif
@@ -1394,6 +1397,13 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     WRegsT<CHAIN, 2> wch;
     constexpr int KS5 = (BG ? 96 + 256 : 64 + 256) / 8;
     auto ahead = [&](int l) __attribute__((always_inline)) { wprefetch<MM == MM_H3>(wch, wblock<MM>(packed, lay.PF[l]), 32, 0, 32, wn * 2, lane); };
+    // MM_H3 (X6_H3_FWD_COPY): the saved rows of a layer's input leave by a plain workgroup-wide copy before its k-loop (see mlp_bwd_dx_kernel)
+    auto copy_rows = [&](float* __restrict__ dst) __attribute__((always_inline)) {
+      for (int i = tid; i < TM * 64; i += NTHR) {
+        const int m = i >> 6, sl = i & 63;
+        if (m < valid) store_nt(dst + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
+      }
+    };
     // ---- L0 : pe -> 256 -----------------------------------------------------------------
     float bv2[L16 ? 4 : 2];
     load_bias<2>(bv2, params + lay.LB[0], wn, lane);
@@ -1414,6 +1424,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       load_bias<2>(bv2, params + lay.LB[l], wn, lane);
       init_acc<2, FOLD>(acc, bv2);
       float* sv = SAVE ? act + act_h(PL, PEP, l - 1) + p0 * 256 : nullptr;   // h_{l-1} is what this loop reads
+      if constexpr (SAVE && MM == MM_H3 && X6_H3_FWD_COPY) { copy_rows(sv); sv = nullptr; }
       if (l == 5) {
         if (!BG) {
           gemm<MM, 2, 1>(acc, Es, 0, 8, B, KS5, 0, wn * 2, wm, lane, dbg);
@@ -1491,8 +1502,9 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     // ---- feature layer (no ReLU) ------------------------------------------------------
     load_bias<2>(bv2, params + lay.FB, wn, lane);
     init_acc<2, FOLD>(acc, bv2);
+    if constexpr (SAVE && MM == MM_H3 && X6_H3_FWD_COPY) copy_rows(act + act_h(PL, PEP, 7) + p0 * 256);
     gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed, lay.PF[8]), 32, 0, wn * 2, wm, lane, dbg,
-                   SAVE ? act + act_h(PL, PEP, 7) + p0 * 256 : nullptr, valid, wave);
+                   (SAVE && !(MM == MM_H3 && X6_H3_FWD_COPY)) ? act + act_h(PL, PEP, 7) + p0 * 256 : nullptr, valid, wave);
     __syncthreads();
     epilogue_fwd<2, false, false, FOLD>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
     __syncthreads();
