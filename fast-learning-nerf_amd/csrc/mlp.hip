@@ -201,6 +201,9 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define X6_H3_SHIFT 12
+#ifndef X6_H3_PKMUL
+#define X6_H3_PKMUL 0   // 1: A/B 15.24 -> 15.36 ms step (packed fp32 VALU beside MFMAs is slower, as in the epilogues)
+#endif
 #ifndef X6_H3_FWD_COPY
 #define X6_H3_FWD_COPY 0   // 1: the same for the saving forward (A/B: saving forward 3.46 -> 3.60 ms: worse; its in-loop stream does not spill)
 #endif
@@ -217,7 +220,12 @@ __device__ __forceinline__ void split2h_pair(float x0, float x1, unsigned& h, un
   // (x - h) 2^12 as fma(h, -2^12, 2^12 x): every intermediate exact; the compiler reads the fp16 halves directly (v_fma_mix_f32):
   // v_cvt_pk_f16_f32, 2 v_mul_f32, 2 v_fma_mix_f32, v_cvt_pk_f16_f32 = 6 instructions per pair (8 with a conversion back and a subtraction)
   constexpr float SC = (float)(1 << X6_H3_SHIFT);
+#if X6_H3_PKMUL   // one v_pk_mul_f32 for both 2^12 x (the pair sits in adjacent registers: it comes out of a ds_read_b128): 5 instructions per pair
+  const f32x2v xs = v * SC;
+  const f32x2v rv = {__builtin_fmaf((float)hv.x, -SC, xs.x), __builtin_fmaf((float)hv.y, -SC, xs.y)};
+#else
   const f32x2v rv = {__builtin_fmaf((float)hv.x, -SC, x0 * SC), __builtin_fmaf((float)hv.y, -SC, x1 * SC)};
+#endif
   h = __builtin_bit_cast(unsigned, hv);
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, f16x2v));
 }
@@ -804,7 +812,7 @@ __device__ __forceinline__ f32x4m mfma16(const uint4& a, const uint4& b, f32x4m 
 template <bool H3> struct X6A {   // the arithmetic of a 16 x 16 x 32 tile product
   static constexpr int NPL = H3 ? 2 : 3;               // weight / activation pieces
   static constexpr int NPROD = H3 ? 3 : 6;             // MFMAs; H3: (l', h) and (h, l') into the segment's cross-term accumulators, (h, h) into the layer's
-  static constexpr int VP = H3 ? 6 : X6_PIPE_VP;       // VALU instructions of one pair's split (pin counts of the interleave)
+  static constexpr int VP = H3 ? (X6_H3_PKMUL ? 5 : 6) : X6_PIPE_VP;       // VALU instructions of one pair's split (pin counts of the interleave)
 };
 struct Pieces16 { unsigned v[3][4]; };   // [piece h | m | l][pair of k] of ONE row tile
 __device__ __forceinline__ uint4 piece_frag16(const Pieces16& p, int pl) { return make_uint4(p.v[pl][0], p.v[pl][1], p.v[pl][2], p.v[pl][3]); }
