@@ -2071,6 +2071,30 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// X6_DW_H3 (EXPERIMENT, timing + accuracy study for profiles/r04_f16x3_study.md section 4; default 0, not a product mode): the dW kernel on
+// TWO fp16 pieces and THREE products in its ONE accumulator set -- the residual is NOT scaled by 2^12 (that would need a second set);
+// instead each tensor is scaled by a power of two before it is split (X6_DW_H3_SX for activations, X6_DW_H3_SY for gradients: fixed here,
+// to be taken from the tensors' measured maxima in a real build) so that its entries of weight sit in fp16's normal range.
+#ifndef X6_DW_H3
+#define X6_DW_H3 0
+#endif
+#ifndef X6_DW_H3_SX
+#define X6_DW_H3_SX 512.f        // activations up to 127
+#endif
+#ifndef X6_DW_H3_SY
+#define X6_DW_H3_SY 1048576.f    // gradients up to 0.06
+#endif
+__device__ __forceinline__ void split2u_pair(float x0, float x1, float sc, unsigned& h, unsigned& l) {   // x sc = h + l (+ <= 2^-23), unscaled residual
+  const float y0 = x0 * sc, y1 = x1 * sc;
+  const f32x2v v = {y0, y1};
+  const f16x2v hv = __builtin_convertvector(v, f16x2v);
+  const f32x2v rv = {__builtin_fmaf((float)hv.x, -1.f, y0), __builtin_fmaf((float)hv.y, -1.f, y1)};
+  h = __builtin_bit_cast(unsigned, hv);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, f16x2v));
+}
+__device__ __forceinline__ f32x16 mfma_f16_32(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 // MM_X6 dW.  On this chip a SIMD issues NOTHING VALU-class while one of its waves streams v_mfma_f32_32x32x16_bf16 back to back
 // (tools/micro/coexec_split.hip, profiles/r03_mfma_valu_exclusion.md): the partner wave's VALU work does not hide under the MFMAs,
 // it adds to them; only LDS / memory latency overlaps.  The synchronous stage of mlp_bwd_dw_kernel (global -> registers -> fp32 LDS
@@ -2221,9 +2245,20 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
           for (int e = 0; e < 8; ++e) v[e] = e < nv ? v[e] : 0.f;
         }
         uint4 h, m, l;
+#if X6_DW_H3
+        {
+          const float sc = tisy[k] ? X6_DW_H3_SY : X6_DW_H3_SX;
+          split2u_pair(v[0], v[1], sc, h.x, m.x); split2u_pair(v[2], v[3], sc, h.y, m.y);
+          split2u_pair(v[4], v[5], sc, h.z, m.z); split2u_pair(v[6], v[7], sc, h.w, m.w);
+          l = h;
+        }
+        uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
+        d[0] = h; d[64] = m;
+#else
         split3_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
         uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
         d[0] = h; d[64] = m; d[128] = l;
+#endif
         if (BIAS && (KNOWN ? (k * NW < CTO) : (t < CTO1))) ssum[k] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         if (RANK1 && (KNOWN ? (k * NW >= CTO) : (t >= CTO))) {
           const float4 d0 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8);
@@ -2243,8 +2278,8 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 #pragma unroll
     for (int i = 0; i < TO; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) a[i][pl] = Sb[((wo * TO + i) * 3 + pl) * 64];
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      for (int pl = 0; pl < (X6_DW_H3 ? 2 : 3); ++pl) a[i][pl] = Sb[((wo * TO + i) * 3 + pl) * 64];
+    constexpr int PA[6] = {X6_DW_H3 ? 1 : 2, 0, X6_DW_H3 ? 0 : 1, 1, 0, 0}, PB[6] = {0, X6_DW_H3 ? 1 : 2, X6_DW_H3 ? 0 : 1, 0, 1, 0};
     constexpr int JP = TI >= 2 ? 2 : 1;
 #pragma unroll
     for (int j0 = 0; j0 < TI; j0 += JP) {
@@ -2252,15 +2287,21 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 #pragma unroll
       for (int jj = 0; jj < JP; ++jj)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < (X6_DW_H3 ? 2 : 3); ++pl)
           if (j0 + jj < TI) b[jj][pl] = Sb[((CTO + wi * TI + j0 + jj) * 3 + pl) * 64];
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < (X6_DW_H3 ? 3 : 6); ++t)
 #pragma unroll
         for (int jj = 0; jj < JP; ++jj)
 #pragma unroll
           for (int i = 0; i < TO; ++i)
-            if (j0 + jj < TI) acc[i][j0 + jj] = mfma_bf16(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
+            if (j0 + jj < TI) {
+#if X6_DW_H3
+              acc[i][j0 + jj] = mfma_f16_32(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
+#else
+              acc[i][j0 + jj] = mfma_bf16(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
+#endif
+            }
     }
   };
   auto publish = [&]() __attribute__((always_inline)) {   // S pieces written / fragments read: hand the buffers over
@@ -2295,7 +2336,7 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 #endif
     auto mix = [&](auto sync) __attribute__((always_inline)) {   // (one pipeline per half of the loop body: distinct sync ids)
 #if X6_DW_PIPE
-      if constexpr (KNOWN && !RANK1) interleave6<0, TO * TI * 6, TPW * 4 * (X6_DOT2 ? 8 : 11) + (BIAS ? 8 : 0), decltype(sync)::value>();
+      if constexpr (KNOWN && !RANK1) interleave6<0, TO * TI * (X6_DW_H3 ? 3 : 6), TPW * 4 * (X6_DW_H3 ? 8 : (X6_DOT2 ? 8 : 11)) + (BIAS ? 8 : 0), decltype(sync)::value>();
 #endif
     };
     auto pair = [&](int d, auto whole) __attribute__((always_inline)) {
@@ -2332,7 +2373,7 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
       for (int r = 0; r < 16; ++r) {
         const int o = (wo * TO + i) * 32 + crow(r, lane);
         const int c = (wi * TI + j) * 32 + (lane & 31);
-        pw[(int64_t)o * KI + c] = acc[i][j][r];
+        pw[(int64_t)o * KI + c] = X6_DW_H3 ? acc[i][j][r] * (1.f / (X6_DW_H3_SX * X6_DW_H3_SY)) : acc[i][j][r];
       }
   if (BIAS || RANK1) {
 #pragma unroll

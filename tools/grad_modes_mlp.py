@@ -31,7 +31,7 @@ z = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, -1).values.to(dev)
 cot = (torch.randn(n, S, 4, generator=gen) * 1e-3).to(dev)
 P = n * S
 res = {}
-MODES = ('fp32', 'bf16x6', 'bf16x3')
+MODES = ('fp32', 'bf16x6', 'f16x3', 'bf16x3')
 for mode in MODES:
     ops.set_math(mode)
     pf, pb = net.packed(refresh=True)
