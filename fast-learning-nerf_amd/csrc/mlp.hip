@@ -44,7 +44,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_F32 0
 #define MM_X6 1
-#define MM_H3 2   // "f16x3": MM_X6's kernels with the forward / dX products on two fp16 pieces (three products); dW as MM_X6
+#define MM_H3 2   // "f16x3": MM_X6's kernels with the forward / dX products on two fp16 pieces (three products); dW: X6_DW_H3 below, else as MM_X6
 // X6_SHAPE16 (round 4): the MM_X6 forward / dX kernels multiply on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  The chip is
 // power limited under these kernels and most of an MFMA's register traffic is its accumulator (C in + D out: 128 of ~160 bytes per lane
 // for the 32x32x16 shape); the 16x16x32 shape updates a quarter of the accumulator with twice the K: half the accumulator traffic per flop,
@@ -196,8 +196,33 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 // and THREE products: Ah Wh into the layer's accumulators, Ah Wl' + Al' Wh into a second set that lives for one segment (gemm_seg16) and is
 // folded in (x 2^-12) at its end; the dropped Al' Wl' is 2^-24 relative (tests: logits vs fp64 as close as the fp32-MFMA kernels').  Same packed-weight layout as MM_X6 (planes h | l' | unused).
 // fp16's RANGE is the price: operands must stay below 65504 (activations and weights of this path do), and the dX kernel keeps its
-// gradients x 2^X6_H3_GSHIFT in LDS.  The dW kernel is MM_X6's (three bf16 pieces of the saved fp32 tensors: it has no room for a
-// second accumulator set).
+// gradients x 2^X6_H3_GSHIFT in LDS.  The dW kernel has no room for a second accumulator set: see X6_DW_H3 for what it does instead.
+// X6_DW_H3 (profiles/r04_f16x3_study.md section 4; 0 = the dW jobs of f16x3 stay bf16x6's -- the default: a scale taken from a tensor's maximum
+// makes the gradient depend, in its last bits, on points whose own gradient is exactly zero, which breaks the bit-exact "dead points contribute
+// nothing / live-list backward == plain backward" contract of DESIGN 4a that tests/test_gpu_compact.py pins): under MM_H3 the dW jobs of the plain (kind 0, no
+// live list) backward run on TWO fp16 pieces and THREE products in their ONE accumulator set.  The residual is not scaled by 2^12 (that
+// would need a second set); instead each tensor is scaled by a power of two before it is split, x s = h + l, with s = 2^(14 - exponent of the
+// tensor's measured maximum): the saving forward records max |.| of pe, h0 .. h7 and feat behind the pass's saved activations (act_xmax), the dX
+// kernel those of dYv, dfeat, dY7 .. dY0 in g_h3_ymax (it runs right before the dW jobs on the same stream), one atomic per wave and tile.
+#ifndef X6_DW_H3
+#define X6_DW_H3 0   // measured: step 15.5 -> 14.7 ms, 324 of 330 GPU tests; the 6 that fail are the compaction contract (see below): off in the product build
+#endif
+__device__ unsigned g_h3_ymax[16];   // dY0 .. dY7 | dfeat | dYv  (float bits of non-negative maxima: ordered as unsigned)
+__device__ unsigned g_h3_xmax[16];   // the pass's act_xmax block, copied here by the launcher: pe | h0 .. h7 | feat | 1.0 (direction encoding)
+__device__ __forceinline__ void h3_wave_max(float m, unsigned* slot) {   // m >= 0; every LANE checks for itself
+  // A plain read first: after the first tiles a lane's maximum almost never exceeds the recorded one (a stale read only costs a redundant
+  // atomic).  Measured: unconditional atomics (4 per tile and layer from 256 CUs on ONE address) cost the saving forward 2.4 ms, a wave
+  // reduction by six ds_bpermute ahead of one conditional atomic 0.34 ms.
+  if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(m));
+}
+__device__ __forceinline__ float h3_scale(unsigned maxbits, float& inv) {   // s = 2^(14 - e), max s in [2^14, 2^15); inv = 1 / s (both exact)
+  int e = (int)((maxbits >> 23) & 0xffu);
+  if (e == 0) e = 127 + 14;                  // an all-zero (or subnormal) tensor: s = 1
+  int se = 127 + 14 - (e - 127);
+  se = se < 1 ? 1 : (se > 253 ? 253 : se);
+  inv = __uint_as_float((unsigned)(254 - se) << 23);
+  return __uint_as_float((unsigned)se << 23);
+}
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define X6_H3_SHIFT 12
@@ -338,7 +363,7 @@ extern "C" int64_t fastnerf_mlp_x6_packed_floats(int kind, int which) {
 }
 // The arithmetic behind the fastnerf_mlp_x6_* entry points (process-wide; the packed weights of one arithmetic are garbage to the other:
 // re-pack after a change).  0: bf16x6 (default) -- three bf16 pieces, six products everywhere.  1: f16x3 (MM_H3) -- forward and dX on two fp16
-// pieces with a scaled residual, three products; dW as bf16x6.  Returns the previous setting; any other argument only queries.
+// pieces with a scaled residual, three products; dW as bf16x6 (X6_DW_H3 builds: on two fp16 pieces with measured per-tensor scales).  Returns the previous setting; any other argument only queries.
 static int g_x6_arith = 0;
 extern "C" int fastnerf_mlp_x6_arith(int arith) {
   const int prev = g_x6_arith;
@@ -808,6 +833,17 @@ template <bool H3>
 __device__ __forceinline__ f32x4m mfma16(const uint4& a, const uint4& b, f32x4m c) {
   if constexpr (H3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <typename ACC>
+__device__ __forceinline__ void h3_track_acc(const ACC& acc, unsigned* slot, bool relu) {   // max of what the epilogue is about to write (bias folded in)
+  float m = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, relu ? acc[mt][ct][r] : fabsf(acc[mt][ct][r]));
+  h3_wave_max(m, slot);
 }
 template <bool H3> struct X6A {   // the arithmetic of a 16 x 16 x 32 tile product
   static constexpr int NPL = H3 ? 2 : 3;               // weight / activation pieces
@@ -1363,6 +1399,11 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         Es[eidx(pm, 3 + 6 * k + dim)] = FN_SIN(a);
         Es[eidx(pm, 6 + 6 * k + dim)] = FN_COS(a);
       }
+      if constexpr (X6_DW_H3 && SAVE && MM == MM_H3) {   // maxima of the encoding tile (raw coordinates; sin / cos <= 1) and of the direction encoding (1)
+        unsigned* xm = reinterpret_cast<unsigned*>(act + act_xmax(PL, lay.pe_pad));
+        h3_wave_max(fmaxf(1.f, fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2])))), xm);
+        if (tid == 0) atomicMax(xm + 10, 0x3f800000u);
+      }
     } else {
       const int sidx = (int)(pp - ray * S);
       const float zz = zv[ray * S + (S - 1 - sidx)];   // flipped sample order
@@ -1422,6 +1463,10 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       __syncthreads();   // X2 lives in H: everyone must be done with it before H is written
     }
     ahead(1);
+    constexpr bool TRACKX = X6_DW_H3 && SAVE && !BG && MM == MM_H3;   // maxima of the saved tensors for the f16 dW jobs (act_xmax)
+    static_assert(!TRACKX || FOLD, "the tracked accumulators hold the bias");
+    unsigned* const xmx = TRACKX ? reinterpret_cast<unsigned*>(act + act_xmax(PL, lay.pe_pad)) : nullptr;
+    if constexpr (TRACKX) h3_track_acc(acc, xmx + 1, true);
     epilogue_fwd<2, true, SAVE, FOLD>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
                                       SAVE ? maskw + (0 * NWAVES + wave) * 64 : nullptr);
     __syncthreads();
@@ -1456,6 +1501,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
       X6_T(t3);
       // (layer 5's two segments and the feature layer -- the alpha head and the direction encoding lie before it -- load their own)
       if (l < 7 && l != 4) ahead(l + 1);
+      if constexpr (TRACKX) h3_track_acc(acc, xmx + 1 + l, true);
       epilogue_fwd<2, true, SAVE, FOLD>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid,
                                         SAVE ? maskw + (l * NWAVES + wave) * 64 : nullptr);
       X6_T(t4);
@@ -1514,6 +1560,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
     gemm<MM, 2, 0>(acc, Hs, 0, 32, wblock<MM>(packed, lay.PF[8]), 32, 0, wn * 2, wm, lane, dbg,
                    (SAVE && !(MM == MM_H3 && X6_H3_FWD_COPY)) ? act + act_h(PL, PEP, 7) + p0 * 256 : nullptr, valid, wave);
     __syncthreads();
+    if constexpr (TRACKX) h3_track_acc(acc, xmx + 9, false);
     epilogue_fwd<2, false, false, FOLD>(acc, bv2, Hs, wm, wn, lane, nullptr, 256, valid);
     __syncthreads();
     if (SAVE) {
@@ -1612,6 +1659,9 @@ static int fwd_launch(int kind, int64_t n, int S, const float* rays11, const flo
     return act ? FN_FWD(true, false, MM_X6) : FN_FWD(false, false, MM_X6);
   }
   if (mm == MM_H3) {
+#if X6_DW_H3
+    if (act && kind != 2) FN_HIP(hipMemsetAsync(act + act_xmax(P, lay.pe_pad), 0, 128, st));   // maxima of the saved tensors (f16 dW jobs)
+#endif
     if (kind == 2) return act ? FN_FWD(true, true, MM_H3) : FN_FWD(false, true, MM_H3);
     return act ? FN_FWD(true, false, MM_H3) : FN_FWD(false, false, MM_H3);
   }
@@ -1772,6 +1822,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       const int64_t pp = ok ? p0 + pm : P - 1;
       const float4 dr = *reinterpret_cast<const float4*>(draw + (live_idx ? (int64_t)live_idx[pp] : pp) * 4);
       constexpr float GS = (float)(1 << X6_H3_GSHIFT);   // MM_H3: the tile's gradients live in LDS x GS (a power of two: exact)
+      float ymax_v = 0.f;
       if constexpr (MM == MM_H3) { if (pq == 0) Es[pm] = ok ? dr.w * GS : 0.f; }
       else { if (pq == 0) Es[pm] = ok ? dr.w : 0.f; }
       const float* wr = params + lay.RW;
@@ -1790,28 +1841,33 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
         o.z = (h.z > 0.f) ? fmaf(dr.z, w2.z, fmaf(dr.y, w1.z, dr.x * w0.z)) : 0.f;
         o.w = (h.w > 0.f) ? fmaf(dr.z, w2.w, fmaf(dr.y, w1.w, dr.x * w0.w)) : 0.f;
         if (!ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (X6_DW_H3 && MM == MM_H3) ymax_v = fmaxf(fmaxf(ymax_v, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         if constexpr (MM == MM_H3)
           *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = make_float4(o.x * GS, o.y * GS, o.z * GS, o.w * GS);
         else
           *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = o;
         if (ok) store_nt(dyv + k, o);
       }
+      if constexpr (X6_DW_H3 && MM == MM_H3) h3_wave_max(ymax_v, g_h3_ymax + 9);
     }
     __syncthreads();
     constexpr bool L16 = MM != MM_F32 && X6_SHAPE16;
     // MM_H3 (X6_H3_DX_COPY): a product's input tile (the gradient it multiplies, x 2^X6_H3_GSHIFT in LDS) is written out by the whole workgroup
     // BEFORE its k-loop instead of being streamed between the MFMAs of its last k-step (where, with two accumulator sets live, the compiler
     // spills accumulators around the stores)
-    auto copy_out = [&](float* __restrict__ dst) __attribute__((always_inline)) {
+    auto copy_out = [&](float* __restrict__ dst, int yslot) __attribute__((always_inline)) {
       constexpr float ig = 1.f / (float)(1 << X6_H3_GSHIFT);
+      float mx = 0.f;
       for (int i = tid; i < TM * 64; i += NTHR) {
         const int m = i >> 6, sl = i & 63;
         if (m < valid) {
           float4 v = *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4);
           v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
+          if constexpr (X6_DW_H3) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
           store_nt(dst + m * 256 + ((sl ^ (m & 15)) << 2), v);
         }
       }
+      if constexpr (X6_DW_H3) h3_wave_max(mx, g_h3_ymax + yslot);   // the gradient's maximum for the f16 dW job that multiplies it
     };
     // every 256 x 256 product after the first finds its first weights loaded (see mlp_fwd_kernel); not under MM_H3, whose second
     // accumulator set leaves no registers for them (backward 8.84 -> 8.67 ms without)
@@ -1832,7 +1888,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       // (MM_H3: the sign words and rank-1 weights are fetched BEHIND the k-loop -- its two accumulator sets leave no registers to hold them)
       DxPre pre;
       if constexpr (!(MM == MM_H3 && X6_H3_PRE_LATE)) pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
-      if constexpr (MM == MM_H3 && X6_H3_DX_COPY) copy_out(dact + dact_feat(PL) + p0 * 256);
+      if constexpr (MM == MM_H3 && X6_H3_DX_COPY) copy_out(dact + dact_feat(PL) + p0 * 256, 8);
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
                             (MM == MM_H3 && X6_H3_DX_COPY) ? nullptr : dact + dact_feat(PL) + p0 * 256, valid, wave, wch);    // streams dfeat (what it reads) out
       if constexpr (MM == MM_H3 && X6_H3_PRE_LATE) pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
@@ -1848,7 +1904,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       zero_acc<2>(acc);
       DxPre pre;
       if constexpr (!(MM == MM_H3 && X6_H3_PRE_LATE)) pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
-      if constexpr (MM == MM_H3 && X6_H3_DX_COPY) copy_out(dact + dact_y(PL, l) + p0 * 256);
+      if constexpr (MM == MM_H3 && X6_H3_DX_COPY) copy_out(dact + dact_y(PL, l) + p0 * 256, l);
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
                             (MM == MM_H3 && X6_H3_DX_COPY) ? nullptr : dact + dact_y(PL, l) + p0 * 256, valid, wave, wch);    // streams dY_l (what it reads) out
       if constexpr (MM == MM_H3 && X6_H3_PRE_LATE) pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
@@ -1859,6 +1915,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     }
     {   // dY0 has no consumer loop: copy it out row-wise
       float* d0 = dact + dact_y(PL, 0) + p0 * 256;
+      float y0max = 0.f;
       for (int i = tid; i < TM * 64; i += NTHR) {
         const int m = i >> 6, sl = i & 63;
         if constexpr (MM == MM_H3) {
@@ -1866,6 +1923,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
             float4 v = *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4);
             constexpr float ig = 1.f / (float)(1 << X6_H3_GSHIFT);
             v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
+            if constexpr (X6_DW_H3) y0max = fmaxf(fmaxf(y0max, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), v);
           }
         } else {
@@ -1873,6 +1931,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
             store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
         }
       }
+      if constexpr (X6_DW_H3 && MM == MM_H3) h3_wave_max(y0max, g_h3_ymax + 0);
     }
     tile = b_next_tile(sched, sched_word, tid);   // closing barrier inside: H is rewritten by the next tile's phase A
   }
@@ -2071,19 +2130,6 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// X6_DW_H3 (EXPERIMENT, timing + accuracy study for profiles/r04_f16x3_study.md section 4; default 0, not a product mode): the dW kernel on
-// TWO fp16 pieces and THREE products in its ONE accumulator set -- the residual is NOT scaled by 2^12 (that would need a second set);
-// instead each tensor is scaled by a power of two before it is split (X6_DW_H3_SX for activations, X6_DW_H3_SY for gradients: fixed here,
-// to be taken from the tensors' measured maxima in a real build) so that its entries of weight sit in fp16's normal range.
-#ifndef X6_DW_H3
-#define X6_DW_H3 0
-#endif
-#ifndef X6_DW_H3_SX
-#define X6_DW_H3_SX 512.f        // activations up to 127
-#endif
-#ifndef X6_DW_H3_SY
-#define X6_DW_H3_SY 1048576.f    // gradients up to 0.06
-#endif
 __device__ __forceinline__ void split2u_pair(float x0, float x1, float sc, unsigned& h, unsigned& l) {   // x sc = h + l (+ <= 2^-23), unscaled residual
   const float y0 = x0 * sc, y1 = x1 * sc;
   const f32x2v v = {y0, y1};
@@ -2115,12 +2161,18 @@ __device__ __forceinline__ f32x16 mfma_f16_32(const uint4& a, const uint4& b, f3
 // feature and encoded direction, ride in ONE job: their common dY is read and split once).
 // CTO2 > 0: the last CTO2 of the WO * TO output tiles come from a second gradient tensor dY2 of width 32 * CTO2 (layers 0 and 5 both
 // multiply the positional encoding: it is read and split once); bias sums are taken over dY only.
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int CTI2 = 0, int CTO2 = 0>
+// DWH3 (X6_DW_H3 builds, MM_H3): two fp16 pieces, three products; h3slots = slot of X | X2 << 8 | dY << 16 | dY2 << 24 in g_h3_xmax / g_h3_ymax
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int CTI2 = 0, int CTO2 = 0, bool DWH3 = false>
 __global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restrict__ X,
                    const float* __restrict__ draw, float* __restrict__ partial_w, float* __restrict__ partial_b,
                    float* __restrict__ partial_r, const int* __restrict__ live_idx, const int* __restrict__ live_cnt,
-                   const float* __restrict__ X2 = nullptr, const float* __restrict__ dY2 = nullptr) {
+                   const float* __restrict__ X2 = nullptr, const float* __restrict__ dY2 = nullptr, int h3slots = 0) {
+  float h3s[4] = {1.f, 1.f, 1.f, 1.f}, h3i[4] = {1.f, 1.f, 1.f, 1.f};   // scale and 1 / scale of X, X2, dY, dY2
+  if constexpr (DWH3) {
+    h3s[0] = h3_scale(g_h3_xmax[h3slots & 255], h3i[0]); h3s[1] = h3_scale(g_h3_xmax[(h3slots >> 8) & 255], h3i[1]);
+    h3s[2] = h3_scale(g_h3_ymax[(h3slots >> 16) & 255], h3i[2]); h3s[3] = h3_scale(g_h3_ymax[(h3slots >> 24) & 255], h3i[3]);
+  }
   if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int CTO = WO * TO, CTI = WI * TI, NTILE = CTO + CTI;
@@ -2245,20 +2297,16 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
           for (int e = 0; e < 8; ++e) v[e] = e < nv ? v[e] : 0.f;
         }
         uint4 h, m, l;
-#if X6_DW_H3
-        {
-          const float sc = tisy[k] ? X6_DW_H3_SY : X6_DW_H3_SX;
+        uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
+        if constexpr (DWH3) {
+          const float sc = tisy[k] ? (tis2[k] ? h3s[3] : h3s[2]) : (tis2[k] ? h3s[1] : h3s[0]);
           split2u_pair(v[0], v[1], sc, h.x, m.x); split2u_pair(v[2], v[3], sc, h.y, m.y);
           split2u_pair(v[4], v[5], sc, h.z, m.z); split2u_pair(v[6], v[7], sc, h.w, m.w);
-          l = h;
+          d[0] = h; d[64] = m;
+        } else {
+          split3_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
+          d[0] = h; d[64] = m; d[128] = l;
         }
-        uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
-        d[0] = h; d[64] = m;
-#else
-        split3_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
-        uint4* d = S6 + ((buf * NTILE + t) * 3) * 64 + lane;
-        d[0] = h; d[64] = m; d[128] = l;
-#endif
         if (BIAS && (KNOWN ? (k * NW < CTO) : (t < CTO1))) ssum[k] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         if (RANK1 && (KNOWN ? (k * NW >= CTO) : (t >= CTO))) {
           const float4 d0 = *reinterpret_cast<const float4*>(DA + (st & 1) * 16 + half8);
@@ -2278,8 +2326,8 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 #pragma unroll
     for (int i = 0; i < TO; ++i)
 #pragma unroll
-      for (int pl = 0; pl < (X6_DW_H3 ? 2 : 3); ++pl) a[i][pl] = Sb[((wo * TO + i) * 3 + pl) * 64];
-    constexpr int PA[6] = {X6_DW_H3 ? 1 : 2, 0, X6_DW_H3 ? 0 : 1, 1, 0, 0}, PB[6] = {0, X6_DW_H3 ? 1 : 2, X6_DW_H3 ? 0 : 1, 0, 1, 0};
+      for (int pl = 0; pl < (DWH3 ? 2 : 3); ++pl) a[i][pl] = Sb[((wo * TO + i) * 3 + pl) * 64];
+    constexpr int PA[6] = {DWH3 ? 1 : 2, 0, DWH3 ? 0 : 1, 1, 0, 0}, PB[6] = {0, DWH3 ? 1 : 2, DWH3 ? 0 : 1, 0, 1, 0};
     constexpr int JP = TI >= 2 ? 2 : 1;
 #pragma unroll
     for (int j0 = 0; j0 < TI; j0 += JP) {
@@ -2287,20 +2335,17 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 #pragma unroll
       for (int jj = 0; jj < JP; ++jj)
 #pragma unroll
-        for (int pl = 0; pl < (X6_DW_H3 ? 2 : 3); ++pl)
+        for (int pl = 0; pl < (DWH3 ? 2 : 3); ++pl)
           if (j0 + jj < TI) b[jj][pl] = Sb[((CTO + wi * TI + j0 + jj) * 3 + pl) * 64];
 #pragma unroll
-      for (int t = 0; t < (X6_DW_H3 ? 3 : 6); ++t)
+      for (int t = 0; t < (DWH3 ? 3 : 6); ++t)
 #pragma unroll
         for (int jj = 0; jj < JP; ++jj)
 #pragma unroll
           for (int i = 0; i < TO; ++i)
             if (j0 + jj < TI) {
-#if X6_DW_H3
-              acc[i][j0 + jj] = mfma_f16_32(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
-#else
-              acc[i][j0 + jj] = mfma_bf16(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
-#endif
+              if constexpr (DWH3) acc[i][j0 + jj] = mfma_f16_32(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
+              else acc[i][j0 + jj] = mfma_bf16(a[i][PA[t]], b[jj][PB[t]], acc[i][j0 + jj]);
             }
     }
   };
@@ -2336,7 +2381,7 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 #endif
     auto mix = [&](auto sync) __attribute__((always_inline)) {   // (one pipeline per half of the loop body: distinct sync ids)
 #if X6_DW_PIPE
-      if constexpr (KNOWN && !RANK1) interleave6<0, TO * TI * (X6_DW_H3 ? 3 : 6), TPW * 4 * (X6_DW_H3 ? 8 : (X6_DOT2 ? 8 : 11)) + (BIAS ? 8 : 0), decltype(sync)::value>();
+      if constexpr (KNOWN && !RANK1) interleave6<0, TO * TI * (DWH3 ? 3 : 6), TPW * 4 * (DWH3 ? 8 : (X6_DOT2 ? 8 : 11)) + (BIAS ? 8 : 0), decltype(sync)::value>();
 #endif
     };
     auto pair = [&](int d, auto whole) __attribute__((always_inline)) {
@@ -2373,7 +2418,12 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
       for (int r = 0; r < 16; ++r) {
         const int o = (wo * TO + i) * 32 + crow(r, lane);
         const int c = (wi * TI + j) * 32 + (lane & 31);
-        pw[(int64_t)o * KI + c] = X6_DW_H3 ? acc[i][j][r] * (1.f / (X6_DW_H3_SX * X6_DW_H3_SY)) : acc[i][j][r];
+        if constexpr (DWH3) {   // un-scale: rows of dY / dY2, columns of X / X2
+          const float un = ((CTO2 > 0 && wo * TO + i >= CTO1) ? h3i[3] : h3i[2]) * ((CTI2 > 0 && wi * TI + j >= CTI1) ? h3i[1] : h3i[0]);
+          pw[(int64_t)o * KI + c] = acc[i][j][r] * un;
+        } else {
+          pw[(int64_t)o * KI + c] = acc[i][j][r];
+        }
       }
   if (BIAS || RANK1) {
 #pragma unroll
@@ -2498,10 +2548,10 @@ extern "C" int64_t fastnerf_mlp_bwd_partial_floats(void) {
 #ifndef X6_DW_SYNC
 #define X6_DW_SYNC 0
 #endif
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32, int CTI2 = 0, int CTO2 = 0>
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int MM = MM_F32, int CTI2 = 0, int CTO2 = 0, bool DWH3 = false>
 static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ldx, const float* draw, float* base,
                      int nwg, hipStream_t st, const int* live_idx = nullptr, const int* live_cnt = nullptr,
-                     const float* X2 = nullptr, const float* dY2 = nullptr) {
+                     const float* X2 = nullptr, const float* dY2 = nullptr, int h3slots = 0) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   float* pw = base;
   float* pb = base + (int64_t)nwg * NO * KI;
@@ -2512,17 +2562,17 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
       return -1;
     }
     constexpr int lds6 = 2 * (WO * TO + WI * TI) * 3 * 1024 + 128;
-    auto kern6 = mlp_bwd_dw6_kernel<WO, WI, TO, TI, BIAS, RANK1, CTI2, CTO2>;
+    auto kern6 = mlp_bwd_dw6_kernel<WO, WI, TO, TI, BIAS, RANK1, CTI2, CTO2, DWH3>;
     static bool attr6 = false;
     if (!attr6) {
       FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern6), hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
       attr6 = true;
     }
-    hipLaunchKernelGGL(kern6, dim3(nwg), dim3(WO * WI * 64), lds6, st, P, dY, X, draw, pw, pb, pr, live_idx, live_cnt, X2, dY2);
+    hipLaunchKernelGGL(kern6, dim3(nwg), dim3(WO * WI * 64), lds6, st, P, dY, X, draw, pw, pb, pr, live_idx, live_cnt, X2, dY2, h3slots);
     FN_LAUNCH_CHECK();
     return 0;
   } else {   // MM_F32 (and, in -DX6_DW_SYNC=1 builds, MM_X6 on the synchronous-stage kernel for A/B timing)
-    static_assert(CTI2 == 0 && CTO2 == 0, "two-tensor jobs exist for the bf16x6 dW kernel only");
+    static_assert(CTI2 == 0 && CTO2 == 0 && !DWH3, "two-tensor / f16 jobs exist for the bf16x6 dW kernel only");
     constexpr int STAGE = DW_MT * (NO + KI) + DW_MT;
     const size_t lds = 2 * STAGE * sizeof(float);
     auto kern = mlp_bwd_dw_kernel<WO, WI, TO, TI, BIAS, RANK1, MM>;
@@ -2565,6 +2615,13 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
   }
   unsigned* sched = b_sched_pair();
   FN_CHECK_ARG(sched != nullptr, "scheduler counters (hipMalloc failed?)");
+  constexpr bool H3C = X6_DW_H3 && MM == MM_H3 && !X6_DW_SYNC;   // f16 dW jobs exist in this build ...
+  const bool h3dw = H3C && kind == 0 && live_idx == nullptr;    // ... and this backward has the maxima they need (forward + dX of the plain route)
+  if constexpr (H3C) {
+    static void* ym = nullptr;
+    if (!ym) FN_HIP(hipGetSymbolAddress(&ym, HIP_SYMBOL(g_h3_ymax)));
+    FN_HIP(hipMemsetAsync(ym, 0, 64, st));
+  }
   hipLaunchKernelGGL(mlp_bwd_dx_kernel<MM>, dim3(grid), dim3(NTHR), LDS_BYTES, st, P, draw, act, params, packed_bwd, dact, L, sched, live_idx, live_cnt);
   FN_LAUNCH_CHECK();
 
@@ -2585,11 +2642,14 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     if (d.bias) { add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO); o += (int64_t)nwg * d.NO; }
     if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
   };
+  // (the dW jobs as a generic lambda: D = the f16 variant of the bf16x6 dW kernel, X6_DW_H3 builds only)
+  auto dw_jobs = [&](auto h3tag) -> int {
+    constexpr bool D = decltype(h3tag)::value && MW == MM_X6 && !X6_DW_SYNC;
   // L0 (+ L5's pe part in the same job under MM_X6: one read and one split of the positional encoding for both;
   //     8 waves x (64 outputs x all pe tiles), partials [512][pe] + bias [256] across the neighbouring regions of jobs 0 and 8)
   if constexpr (MW == MM_X6 && !X6_DW_SYNC) {
-    if (PEP == 64) rc = launch_dw<8, 1, 2, 2, true, false, MW, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
-    else rc = launch_dw<8, 1, 2, 3, true, false, MW, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
+    if (PEP == 64) rc = launch_dw<8, 1, 2, 2, true, false, MW, 0, 8, D>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5), 5 << 24);
+    else rc = launch_dw<8, 1, 2, 3, true, false, MW, 0, 8, D>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5), 5 << 24);
     if (rc) return rc;
     const int64_t b0 = dw_job_base(0, ncu, PEP);
     add_seg(T, b0, (int64_t)512 * PEP, nwg, 256, PEP, L.LW[0], L.in_pe, L.in_pe);
@@ -2603,7 +2663,7 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
   }
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
-    if ((rc = launch_dw<4, 2, 2, 4, true, false, MW>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
+    if ((rc = launch_dw<4, 2, 2, 4, true, false, MW, 0, 0, D>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt, nullptr, nullptr, l | (l << 16)))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
   }
   // L5 pe part (MM_X6: done with L0 above)
@@ -2614,14 +2674,14 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
   }
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
-  if ((rc = launch_dw<4, 2, 2, 4, true, true, MW>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
+  if ((rc = launch_dw<4, 2, 2, 4, true, true, MW, 0, 0, D>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt, nullptr, nullptr, 8 | (8 << 16)))) return rc;
   segs(9, L.FW, 256, 256, L.FB, L.AW);
   // view layer
   if constexpr (MW == MM_X6 && !X6_DW_SYNC) {
     // one job for both inputs of the view layer (feature [P,256] | encoded direction [P,32]): dYv is read and split once; 12 waves,
     // partials [128][288] + bias [128] across the (adjacent) regions of jobs 10 and 11
-    if ((rc = launch_dw<4, 3, 1, 3, true, false, MW, 1>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st,
-                                                        live_idx, live_cnt, act + act_vpe(P, PEP)))) return rc;
+    if ((rc = launch_dw<4, 3, 1, 3, true, false, MW, 1, 0, D>(P, dact + dact_yv(P), 128, act + act_feat(P, PEP), 256, nullptr, region(10), nwg, st,
+                                                        live_idx, live_cnt, act + act_vpe(P, PEP), nullptr, 9 | (10 << 8) | (9 << 16)))) return rc;
     const int64_t b10 = dw_job_base(10, ncu, PEP);
     add_seg(T, b10, 128 * 288, nwg, 128, 288, L.VW, 283, 283);
     add_seg(T, b10 + (int64_t)nwg * 128 * 288, 128, nwg, 1, 128, L.VB, 128, 128);
@@ -2630,6 +2690,18 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     segs(10, L.VW, 283, 256, L.VB, 0);
     if ((rc = launch_dw<4, 1, 1, 1, false, false, MW>(P, dact + dact_yv(P), 128, act + act_vpe(P, PEP), 32, nullptr, region(11), nwg, st, live_idx, live_cnt))) return rc;
     segs(11, L.VW + 256, 283, 27, 0, 0);
+  }
+    return 0;
+  };
+  if constexpr (H3C) {
+    if (h3dw) {   // the pass's saved-tensor maxima next to the gradient maxima
+      static void* xm = nullptr;
+      if (!xm) FN_HIP(hipGetSymbolAddress(&xm, HIP_SYMBOL(g_h3_xmax)));
+      FN_HIP(hipMemcpyAsync(xm, act + act_xmax(P, PEP), 64, hipMemcpyDeviceToDevice, st));
+      if ((rc = dw_jobs(std::true_type{}))) return rc;
+    } else if ((rc = dw_jobs(std::false_type{}))) return rc;
+  } else {
+    if ((rc = dw_jobs(std::false_type{}))) return rc;
   }
   // rgb head + alpha bias
   {

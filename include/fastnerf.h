@@ -327,7 +327,7 @@ int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N
 /* The arithmetic behind the fastnerf_mlp_x6_* entry points (and math_mode 2 of the fused ones), process-wide.  0 (default): bf16x6 as
  * described above.  1: "f16x3" (csrc/mlp.hip, MM_H3) -- the forward and dX products on TWO fp16 pieces with a scaled residual,
  * x = h + 2^-12 l' with h = fp16(x), l' = fp16((x - h) 2^12), both rounded to nearest (|x - h - 2^-12 l'| <= 2^-23 |x|, rms 2^-24.4: one bit short of fp32), THREE products with fp32
- * accumulation (the cross terms in their own accumulators); dW unchanged.  Measured against fp64 the logits are as close as the exact-fp32 kernels' (fp32 accumulation dominates) at half the matrix work; fp16's
+ * accumulation (the cross terms in their own accumulators); dW unchanged (a build with -DX6_DW_H3=1 runs the dW jobs of the plain kind-0 backward on two fp16 pieces as well, each tensor scaled by a power of two taken from its measured maximum: faster, but the gradient then depends in its last bits on points whose own gradient is zero -- off by default).  Measured against fp64 the logits are as close as the exact-fp32 kernels' (fp32 accumulation dominates) at half the matrix work; fp16's
  * range applies: |weights|, |activations| < 65504.  Same buffer sizes; weights packed under one arithmetic are garbage to the other --
  * call fastnerf_mlp_x6_pack again after a change.  Returns the previous setting; any other argument only queries.  Replaces nothing in
  * the reference (which has one arithmetic, torch fp32: nerf-ours/model.py:38-63). */
