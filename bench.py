@@ -31,8 +31,14 @@ Everything else rides in the same JSON line as named sibling blocks and never fe
   inference          render()-style rays/s;   cpu_baseline   the CPU oracle timed on this box's host cores.
 
   python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
-Rank 0 prints ONE JSON line.  The GPU legs import nothing from oracle/; only the CPU legs (cpu_baseline, psnr_vs_cpu.cpu) do.
+  N>1: either under the launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...) or BARE
+  (python bench.py --gpus N ...): without WORLD_SIZE in the environment the script re-executes itself under that launcher.
+
+OUTPUT CONTRACT.  Rank 0 prints exactly ONE line on stdout, LAST: the headline record (headline_record(): <= 4 KB -- metric, value, unit,
+n_gpus, steps, warmup, ms_per_step, dtype, config, roofline, cpu_baseline, psnr, a few scalars of the siblings).  The full record with
+every sibling block is written to bench_full.json (--full-out; also copied under gpurun_out/ when that directory exists) BEFORE that
+line, never to stdout / stderr (a harness that keeps only a tail window of the combined output must still find the headline).
+The GPU legs import nothing from oracle/; only the CPU legs (cpu_baseline, psnr_vs_cpu.cpu) do.
 """
 import argparse
 import json
@@ -42,6 +48,7 @@ import subprocess
 import sys
 import tempfile
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -58,7 +65,7 @@ BWD_FLOP_PER_POINT = 2 * (2 * MAC_PER_POINT - 35712)   # dX (without the input-s
 TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + S1)  # 893.2 MFLOP
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 matrix peak
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 MAIN_MODE = 'bf16x6'                        # the headline's arithmetic: fp32-width products on the bf16 matrix cores (docstring)
 MODE_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 1.0, 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'mlp_fwd_kernel', ', 0'),
              'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6.0, 6.0, 'dense bf16 MFMA 2500 TFLOP/s / 6 piece products per fp32 product', 'mlp_fwd_kernel', ', 1'),
@@ -71,6 +78,95 @@ MAC_PER_POINT_BG = MAC_PER_POINT + 2 * 21 * 256   # nerf++ background MLPNet: 84
 # measured ceiling of a bare v_mfma_f32_32x32x16_bf16 stream on uniform(-1, 1) data (tools/micro/mfma_power.hip, gap_probe.hip:
 # 1848 - 1871 TFLOP/s issued at the 1.79 GHz the power management grants it) -- a REPO CONSTANT from earlier runs, not measured here
 BF16_MFMA_REAL_DATA_TFLOPS = 1871.0
+PAIRED_PSNR_NOTE = 'tests/test_gpu_train.py::test_psnr_paired_with_the_cpu_ensemble_g22 (profiles/r05_psnr_paired.md)'
+
+
+HEADLINE_MAX_BYTES = 4096
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + '...'
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d[k] for k in keys if k in d}
+
+
+def headline_record(out):
+    """The ONE line of stdout: the contract's keys + roofline + cpu_baseline + psnr + one scalar per sibling, cut from the full
+    record `out` (pure function of it; tests/test_bench_output.py holds it to HEADLINE_MAX_BYTES on a worst-case record)."""
+    roof, cpu, cfg = out.get('roofline'), out.get('cpu_baseline'), out['config']
+    h = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                             'vs_baseline', 'dtype')}
+    h['data'] = _short(out['data'], 160)
+    h['config'] = {'workload': _short(cfg['workload'], 330), 'rays_per_gpu_per_step': cfg['rays_per_gpu_per_step'],
+                   'rays_per_step': cfg['rays_per_step'], 'parallelism': cfg['parallelism'], 'math_mode': out['math_mode'].split(':')[0],
+                   'backward': out['backward']}
+    if roof is not None:
+        r = _pick(roof, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'flop_per_launch'))
+        r['kernel'] = _short(roof['kernel'], 120)
+        r['peak_note'] = _short(roof.get('peak_note', ''), 80)
+        r['traffic_source'] = _short(roof.get('traffic_source', ''), 110)
+        if roof.get('step_traffic'):
+            r['step_hbm_bytes'] = roof['step_traffic'].get('hbm_bytes_per_step')
+        for k in ('frac_of_measured_peak',):
+            if k in roof:
+                r[k] = roof[k]
+        r['launches_ms'] = {_short(x['kernel'], 40): round(x['avg_launch_ms'], 4) for x in roof.get('launches', [])[:3]}
+        h['roofline'] = r
+    else:
+        h['roofline'] = None
+    if cpu is not None:
+        c = _pick(cpu, ('value', 'unit', 'cores', 'kind', 'cpu', 'cores_available', 'rays_per_s_n4096'))
+        c['sample'] = _short(cpu.get('sample', ''), 200)
+        h['cpu_baseline'] = c
+        h['vs_cpu_baseline'] = out['value'] / cpu['value'] if cpu.get('value') else None
+    else:
+        h['cpu_baseline'] = None
+    h['psnr'] = out.get('psnr')
+    h.update({k: out.get(k) for k in ('final_loss', 'per_rank_ms_per_step', 'allreduce_ms', 'collective', 'step_tflops_per_gpu',
+                                      'step_frac_of_peak')})
+    if out.get('sustained'):
+        h['sustained_ms_per_step'] = out['sustained']['ms_per_step']
+    h['siblings'] = out.get('siblings_summary')
+    h['errors'] = [_short(e, 160) for e in out.get('errors', [])][:4] or None
+    h['full_record'] = out.get('full_record')
+    line = json.dumps(h)
+    if len(line) > HEADLINE_MAX_BYTES:      # never let an over-long optional field break the contract: drop optional blocks, largest first
+        for k in ('siblings', 'allreduce_ms', 'per_rank_ms_per_step', 'errors', 'psnr'):
+            h[k] = None
+            line = json.dumps(h)
+            if len(line) <= HEADLINE_MAX_BYTES:
+                break
+    return h
+
+
+def relaunch_under_torchrun(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run (one rank per GPU, 127.0.0.1
+    rendezvous, a free port) -- the command the contract names; stdout / stderr are inherited, so rank 0's single line is this
+    process's single line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def write_full_record(out, path):
+    """bench_full.json (every sibling block), plus a copy under gpurun_out/ so that it comes back from a GPU box."""
+    written = []
+    for pth in [path] + ([os.path.join(ROOT, 'gpurun_out', os.path.basename(path))] if os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else []):
+        try:
+            with open(pth, 'w') as f:
+                json.dump(out, f, indent=1)
+            written.append(os.path.relpath(pth, ROOT))
+        except OSError:
+            pass
+    return written
 
 
 def cpu_model():
@@ -347,9 +443,13 @@ def main():
     ap.add_argument('--cpu-protocol', choices=['full', 'short'], default='full')
     ap.add_argument('--psnr-iters', type=int, default=PSNR_ITERS)
     ap.add_argument('--psnr-cpu-worker', nargs=2, metavar=('IN', 'OUT'), help=argparse.SUPPRESS)
+    ap.add_argument('--full-out', default=os.path.join(ROOT, 'bench_full.json'), help='where the full record (all sibling blocks) goes')
     a = ap.parse_args()
     if a.psnr_cpu_worker:
         return psnr_cpu_worker(*a.psnr_cpu_worker)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        relaunch_under_torchrun(a.gpus, sys.argv[1:])
+    warnings.filterwarnings('ignore')     # stderr shares the harness's tail window with the headline line: keep it empty
 
     import fastnerf
     from fastnerf import ops, parallel, synthetic
@@ -362,6 +462,7 @@ def main():
     n_local = N_RAYS if a.scaling == 'weak' else N_RAYS // world      # rays per rank per step
     n_step = n_local * world                                          # rays per step, whole job
     siblings = rank == 0 and world == 1 and not a.no_siblings
+    psnr_leg = rank == 0 and world == 1 and a.psnr_iters > 0
 
     args = fastnerf.run_nerf.make_args(N_importance=N_IMPORTANCE, N_samples=N_SAMPLES, perturb=1.0, white_bkgd=True,
                                        no_reload=True, lrate=5e-4, lrate_decay=500, N_rand=n_local)
@@ -376,7 +477,7 @@ def main():
     # ---- PSNR protocol inputs first, so that the CPU side can start right away and run beside the GPU legs ----------------
     psnr_proc = psnr_in = psnr_out = None
     psnr_data = None
-    if siblings and a.psnr_iters > 0:
+    if psnr_leg:
         psnr_data = psnr_inputs(fastnerf, dev, a.psnr_iters, args, poses, K, draw_pixels)
         if not a.no_cpu_baseline:
             tmp = tempfile.mkdtemp(prefix='fastnerf_psnr_')
@@ -464,18 +565,21 @@ def main():
             r['frac'] = r['achieved'] / peak
         dom = rows[0]    # the single launch the plain step spends the most time in (the backward row is 15 launches)
         traffic = step_traffic = None
-        try:   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles_r03.sh)
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_pmc_traffic.json')))
-            traffic = pmc[mode]['kernels'][dom['kernel']]['hbm_bytes']
-            step_traffic = pmc[mode]['step_traffic']
-        except Exception:
-            pass
+        pmc_file = None
+        for rnd in (PROFILE_ROUND, 'r04'):   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles_*.sh)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd + '_pmc_traffic.json')))
+                traffic = pmc[mode]['kernels'][dom['kernel']]['hbm_bytes']
+                step_traffic = pmc[mode]['step_traffic']
+                pmc_file = 'profiles/%s_pmc_traffic.json' % rnd
+                break
+            except Exception:
+                pass
         roof = {'bound': 'mfma', 'kernel': dom['kernel'] + ' (fine pass; ' + dom['what'] + ')', 'achieved': dom['achieved'],
                 'peak': peak, 'unit': 'TFLOP/s', 'frac': dom['frac'],
                 'peak_note': peak_note, 'measured_in_this_run': ['achieved', 'frac', 'avg_launch_ms', 'launches'],
-                'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/%s_pmc_traffic.json)' % PROFILE_ROUND,
-                'traffic_source': 'REPO CONSTANT: read from the committed PMC passes (separate rocprofv3 --pmc runs of the same workload), '
-                                  'not collected in this run',
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, %s)' % pmc_file,
+                'traffic_source': 'REPO CONSTANT from %s (separate rocprofv3 --pmc passes of this workload), not collected in this run' % pmc_file,
                 'step_traffic': step_traffic, 'avg_launch_ms': dom['avg_launch_ms'], 'flop_per_launch': dom['flop_per_launch'],
                 'mfma_tflops_issued': n_prod * dom['achieved'], 'launches': rows}
         if mode != 'fp32':
@@ -616,48 +720,34 @@ def main():
     step_tflops = n_step * a.steps / dt * TRAIN_FLOP_PER_RAY / 1e12 / world
 
     # =====================================================================================================================
-    # siblings (1 GPU, rank 0): never part of `value`
+    # siblings (1 GPU, rank 0): never part of `value`; each leg guarded -- a failing sibling is recorded, the headline still prints
     # =====================================================================================================================
-    split_block = fp32_block = f16_block = drop_in = infer = psnr_block = cfg_blocks = None
-    trb = kte_b = kte_32 = None
-    if not a.no_siblings:
-        # ---- the same protocol (random init, noise targets, plain backward) in the other two modes; every rank takes part -----
-        ops.set_math('fp32')
-        tr32, _, kte_32, _ = new_trainer()
-        t32_, l32_, _ = timed(lambda i: step(tr32, i)[0], 0, 3, 20)
-        if rank == 0:
-            fp32_block = {'math_mode': 'fp32', 'dtype': 'f32: v_mfma_f32_32x32x2_f32, an fp32 FMA chain (157.3 TFLOP/s ceiling)',
-                          'init_state': leg(t32_, 20, warmup=3, backward='plain', final_loss=[float(x) for x in l32_.tolist()],
-                                            what='the headline protocol on the fp32 matrix instruction',
-                                            step_frac_of_fp32_mfma_peak=n_step * 20 / t32_ * TRAIN_FLOP_PER_RAY / 1e12 / world / FP32_MFMA_PEAK_TFLOPS),
-                          'roofline': mlp_roofline(tr32, 'fp32')}
-        del tr32
-        # ---- f16x3: the headline's kernels with the forward / dX products on two fp16 pieces + scaled residual (three products) ----
-        ops.set_math('f16x3')
-        trh, _, _, _ = new_trainer()
-        th_, lh_, _ = timed(lambda i: step(trh, i)[0], 0, 3, 20)
-        if rank == 0:
-            f16_block = {'math_mode': 'f16x3',
-                         'dtype': 'f16x3: forward and dX products as Ah*Wh + 2^-12 (Ah*Wl + Al*Wh) on the fp16 matrix cores (v_mfma_f32_16x16x32_f16), '
-                                  'x = h + 2^-12 l with two roundings to nearest: operands to 2^-23 relative (ONE BIT short of fp32; rms 2^-24.4), fp32 '
-                                  'accumulation, cross terms in their own accumulators; dW as bf16x6.  Logits vs fp64 as close as the fp32-MFMA kernels\' '
-                                  '(tests/test_gpu_mlp.py), paired PSNR test G22 in this mode too -- a sibling because its operands are not bit-for-bit fp32-wide',
-                         'init_state': leg(th_, 20, warmup=3, backward='plain', final_loss=[float(x) for x in lh_.tolist()],
-                                           what='the headline protocol (random init, U[0,1) targets, plain backward) in this mode'),
-                         'roofline': mlp_roofline(trh, 'f16x3')}
-        del trh
-        ops.set_math('bf16x3')
-        trb, _, kte_b, _ = new_trainer()
-        tb, lb, _ = timed(lambda i: step(trb, i)[0], 0, 3, 20)
-        if rank == 0:
-            split_block = {'math_mode': 'bf16x3', 'dtype': 'split-bf16 x3: every fp32 product as hi*hi + hi*lo + lo*hi on the bf16 '
-                           'matrix cores with fp32 accumulation; operands carry 16 significand bits -- NARROWER than fp32, hence a sibling',
-                           'init_state': leg(tb, 20, warmup=3, backward='plain', final_loss=[float(x) for x in lb.tolist()],
-                                             what='the headline protocol (random init, U[0,1) targets, plain backward) in this mode',
-                                             step_frac_of_bf16_mfma_peak_x3=3.0 * n_step * 20 / tb * TRAIN_FLOP_PER_RAY / 1e12 / world / BF16_MFMA_PEAK_TFLOPS),
-                           'roofline': mlp_roofline(trb, 'bf16x3')}
-    if siblings:
-        # ---- split-bf16 on a trained sparse scene, compacted backward (round 2's headline, now a named sibling) -------------
+    errors = []
+
+    def guarded(name, fn_):
+        try:
+            return fn_()
+        except Exception as e:     # noqa: BLE001  (recorded in the record, never swallowed silently)
+            import traceback
+            errors.append('%s: %s: %s | %s' % (name, type(e).__name__, e, traceback.format_exc().strip().splitlines()[-2].strip()))
+            return None
+
+    def mode_leg(mode, **kw):
+        """The headline protocol (random init, U[0,1) targets, plain backward) in another arithmetic."""
+        ops.set_math(mode)
+        fastnerf.render.set_compact('0')
+        trm, _, ktm, _ = new_trainer()
+        tm_, lm_, _ = timed(lambda i: step(trm, i)[0], 0, 3, 20)
+        blk = {'math_mode': mode, 'init_state': leg(tm_, 20, warmup=3, backward='plain', final_loss=[float(x) for x in lm_.tolist()],
+                                                    what='the headline protocol in this mode'),
+               'roofline': mlp_roofline(trm, mode)}
+        blk.update(kw)
+        return blk, trm, ktm
+
+    def sparse_scene_leg(mode):
+        """`mode` on a trained sparse scene with the exact zero-gradient compaction (what loss.backward() sees after the first epochs,
+        run_nerf.py:493), and the plain backward on the same weights."""
+        ops.set_math(mode)
         fastnerf.render.set_compact('auto')
         trs, _, _, _ = new_trainer()
         for i in range(a.scene_steps):
@@ -669,83 +759,48 @@ def main():
             live_frac = {'fine': c[0] / max(1, c[1]), 'coarse': c[2] / max(1, c[3])}
         fastnerf.render.set_compact('0')
         tpl, _, _ = timed(lambda i: step(trs, i, 'solid')[0], 7, 6, 20)
-        split_block['sparse_scene'] = leg(
-            tsol, 20, warmup=3, backward='compacted' if was_live else 'plain', live_fraction=live_frac,
+        return leg(
+            tsol, 20, warmup=3, math_mode=mode, backward='compacted' if was_live else 'plain', live_fraction=live_frac,
             after_optimisation_steps=a.scene_steps + 3, final_loss=[float(x) for x in lsol.tolist()],
             what='three solid analytic bodies on white (density exactly zero beyond %.1f sigma, ~27 %% of the pixels covered): nets '
                  'trained inside the run, backward over the samples with a non-zero gradient only (exact; DESIGN 4a).  Scene and '
                  'trajectory dependent: a field without exactly-empty space runs at `same_state_plain_backward`' % SCENE_CUTOFF,
             same_state_plain_backward=leg(tpl, 20, warmup=6))
-        del trs
 
-        # ---- INTEGRATION option A: the reference's own loop on the drop-in surface (run_nerf.py:479-508) ----------------------
-        def drop_in_leg(mode):
-            ops.set_math(mode)
-            fastnerf.render.set_compact('0')
-            torch.manual_seed(0)
-            k_train, _, _, _, grad_vars, optimizer = fastnerf.run_nerf.create_nerf(args, device=dev)
-            k_train.update(near=2.0, far=6.0)
-            state = {'it': 0}
+    def drop_in_leg(mode):
+        """INTEGRATION option A: the reference's own loop on the drop-in surface (run_nerf.py:479-508)."""
+        ops.set_math(mode)
+        fastnerf.render.set_compact('0')
+        torch.manual_seed(0)
+        k_train, _, _, _, grad_vars, optimizer = fastnerf.run_nerf.create_nerf(args, device=dev)
+        k_train.update(near=2.0, far=6.0)
+        state = {'it': 0}
 
-            def one(i):
-                ro, rd, tgts, _ = batches[i % n_batches]
-                rgb, disp, acc, extras = fastnerf.render.render(H, W, K, chunk=args.chunk, rays=(ro, rd), retraw=True, **k_train)
-                optimizer.zero_grad()
-                img_loss = fastnerf.run_nerf_helpers.img2mse(rgb, tgts['noise'])
-                loss = img_loss + fastnerf.run_nerf_helpers.img2mse(extras['rgb0'], tgts['noise'])
-                loss.backward()
-                optimizer.step()
-                new_lrate = 5e-4 * (0.1 ** (state['it'] / (500 * 1000)))
-                for pg in optimizer.param_groups:
-                    pg['lr'] = new_lrate
-                state['it'] += 1
-                return img_loss.detach()
-            td, ld, _ = timed(one, 0, 3, 20)
-            return leg(td, 20, warmup=3, final_img_loss=float(ld))
-        dmain = drop_in_leg(MAIN_MODE)
-        d32 = drop_in_leg('fp32')
-        d16 = drop_in_leg('bf16x3')
-        drop_in = {'what': 'the reference\'s loop verbatim on the drop-in surface: render(retraw=True) -> img2mse x 2 -> loss.backward() -> '
-                           'torch.optim.Adam(48 tensors).step() -> lr rule; same protocol and batches as `value`',
-                   MAIN_MODE: dmain, 'fp32': d32, 'bf16x3': d16,
-                   'fraction_of_fused_trainer': {MAIN_MODE: dmain['value'] / (n_step * a.steps / dt),
-                                                 'fp32': d32['value'] / fp32_block['init_state']['value'],
-                                                 'bf16x3': d16['value'] / split_block['init_state']['value']}}
+        def one(i):
+            ro, rd, tgts, _ = batches[i % n_batches]
+            rgb, disp, acc, extras = fastnerf.render.render(H, W, K, chunk=args.chunk, rays=(ro, rd), retraw=True, **k_train)
+            optimizer.zero_grad()
+            img_loss = fastnerf.run_nerf_helpers.img2mse(rgb, tgts['noise'])
+            loss = img_loss + fastnerf.run_nerf_helpers.img2mse(extras['rgb0'], tgts['noise'])
+            loss.backward()
+            optimizer.step()
+            new_lrate = 5e-4 * (0.1 ** (state['it'] / (500 * 1000)))
+            for pg in optimizer.param_groups:
+                pg['lr'] = new_lrate
+            state['it'] += 1
+            return img_loss.detach()
+        td, ld, _ = timed(one, 0, 3, 20)
+        return leg(td, 20, warmup=3, final_img_loss=float(ld))
 
-        # ---- PSNR at equal iterations: GPU side (both modes, free runs + a 1-ulp ensemble) on the inputs the CPU worker got ---
-        if psnr_data is not None:
-            psnr_block = {'iters': psnr_data['iters'], 'rays_per_iter': PSNR_RAYS, 'samples': '64+128', 'cameras': '100 x 800x800',
-                          'scene': 'three analytic Gaussian density blobs on white (fastnerf.synthetic), identical batches, injected '
-                                   't_rand / u (seed 2) and initial weights (seed 0) on both sides',
-                          'train_psnr_window': 20, 'held_out_rays': PSNR_HELD_OUT, 'gpu': {}}
-            dd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in psnr_data.items()}
-            for mode in (MAIN_MODE, 'fp32', 'bf16x3'):
-                psnr_block['gpu'][mode] = psnr_gpu_free(fastnerf, dd, new_trainer, K, mode)[0]
-            psnr_block['free_runs_note'] = (
-                'single free runs from one initialisation: trajectories are chaotic, and the level reached after 200 iterations depends on the '
-                'initial weights by ~3 dB; the falsifiable free-run statement is the PAIRED test over 40+ initialisation seeds against the committed '
-                'CPU ensemble G22 (tests/test_gpu_train.py::test_psnr_paired_with_the_cpu_ensemble_g22, profiles/r04_psnr_paired.md); the per-step '
-                'statement is `lockstep` below')
-
-        # ---- the other BASELINE configs at the headline arithmetic --------------------------------------------------------------
-        # (these loops have host work in their timed regions: the CPU PSNR worker -- our own child process -- is paused for their ~30 s; on boxes with
-        #  fewer than 128 CPUs it cannot be kept off the launching process's cores, and the nerf++ batch then measured 30 instead of 18.4 ms)
-        import signal
-        if psnr_proc is not None and psnr_proc.poll() is None:
-            psnr_proc.send_signal(signal.SIGSTOP)
-        try:
-            cfg_blocks = {'configs[2]_quadtree': config2_quadtree(), 'configs[3]_llff_ndc': config3_llff(), 'configs[4]_nerfpp': config4_nerfpp()}
-        finally:
-            if psnr_proc is not None and psnr_proc.poll() is None:
-                psnr_proc.send_signal(signal.SIGCONT)
-
-        # ---- inference rays/s (render_path-style, perturb=0, no saved activations) -------------------------------
-        ops.set_math(MAIN_MODE)
+    def inference_leg(test_kwargs):
+        """render_path-style, perturb=0, no saved activations."""
         n_inf = 32768
         pix = draw_pixels(torch.Generator().manual_seed(7), n_inf).to(dev)
         ro_i, rd_i = ops.gen_rays_pixels(pix, poses, K)
-        infer = {'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), random-init nets, 1 GPU'}
-        for mode, kt in ((MAIN_MODE, kte), ('fp32', kte_32), ('bf16x3', kte_b)):
+        inf = {'what': 'render() of 32768 rays, 64+128 samples, perturb=0 (render_kwargs_test), random-init nets, 1 GPU'}
+        for mode, kt in test_kwargs.items():
+            if kt is None:
+                continue
             ops.set_math(mode)
             with torch.no_grad():
                 for _ in range(2):
@@ -756,50 +811,161 @@ def main():
                     fastnerf.render.render(H, W, K, chunk=n_inf, rays=(ro_i, rd_i), near=2.0, far=6.0, **kt)
                 torch.cuda.synchronize()
                 dt_i = (time.perf_counter() - t1) / 5
-            infer[mode] = {'value': n_inf / dt_i, 'unit': 'rays/s', 'ms_per_call': 1e3 * dt_i}
+            inf[mode] = {'value': n_inf / dt_i, 'unit': 'rays/s', 'ms_per_call': 1e3 * dt_i}
+        return inf
+
+    split_block = fp32_block = f16_block = drop_in = infer = psnr_block = cfg_blocks = main_sparse = None
+    kte_b = kte_32 = None
+    dd = None
+    if siblings:
+        r_ = guarded('fp32_mfma_mode', lambda: mode_leg(
+            'fp32', dtype='f32: v_mfma_f32_32x32x2_f32, an fp32 FMA chain (157.3 TFLOP/s ceiling)'))
+        if r_ is not None:
+            fp32_block, _, kte_32 = r_
+            fp32_block['init_state']['step_frac_of_fp32_mfma_peak'] = (fp32_block['init_state']['value'] * TRAIN_FLOP_PER_RAY / 1e12
+                                                                       / FP32_MFMA_PEAK_TFLOPS)
+        r_ = guarded('f16x3_mode', lambda: mode_leg(
+            'f16x3', dtype='f16x3: forward and dX products as Ah*Wh + 2^-12 (Ah*Wl + Al*Wh) on the fp16 matrix cores (v_mfma_f32_16x16x32_f16), '
+                           'x = h + 2^-12 l with two roundings to nearest: operands to 2^-23 relative (ONE BIT short of fp32), fp32 accumulation; '
+                           'dW as bf16x6.  A sibling because its operands are not bit-for-bit fp32-wide and fp16 has a range limit (guarded: '
+                           'DESIGN 4)'))
+        if r_ is not None:
+            f16_block = r_[0]
+        r_ = guarded('split_bf16_mode', lambda: mode_leg(
+            'bf16x3', dtype='split-bf16 x3: every fp32 product as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation; '
+                            'operands carry 16 significand bits -- NARROWER than fp32, hence a sibling'))
+        if r_ is not None:
+            split_block, _, kte_b = r_
+            split_block['init_state']['step_frac_of_bf16_mfma_peak_x3'] = (3.0 * split_block['init_state']['value'] * TRAIN_FLOP_PER_RAY / 1e12
+                                                                           / BF16_MFMA_PEAK_TFLOPS)
+            split_block['sparse_scene'] = guarded('split_bf16_mode.sparse_scene', lambda: sparse_scene_leg('bf16x3'))
+        # ---- the headline arithmetic on the trained sparse scene: the step loss.backward() sees after the first epochs ------------
+        main_sparse = guarded(MAIN_MODE + '.sparse_scene', lambda: sparse_scene_leg(MAIN_MODE))
+
+        def all_drop_in():
+            dmain, d32, d16 = drop_in_leg(MAIN_MODE), drop_in_leg('fp32'), drop_in_leg('bf16x3')
+            frac = {MAIN_MODE: dmain['value'] / (n_step * a.steps / dt)}
+            if fp32_block is not None:
+                frac['fp32'] = d32['value'] / fp32_block['init_state']['value']
+            if split_block is not None:
+                frac['bf16x3'] = d16['value'] / split_block['init_state']['value']
+            return {'what': 'the reference\'s loop verbatim on the drop-in surface: render(retraw=True) -> img2mse x 2 -> loss.backward() -> '
+                            'torch.optim.Adam(48 tensors).step() -> lr rule; same protocol and batches as `value`',
+                    MAIN_MODE: dmain, 'fp32': d32, 'bf16x3': d16, 'fraction_of_fused_trainer': frac}
+        drop_in = guarded('drop_in_route', all_drop_in)
+
+    # ---- PSNR at equal iterations: GPU side (free runs) on the inputs the CPU worker got -------------------------------------------
+    psnr_modes = (MAIN_MODE, 'fp32', 'bf16x3') if siblings else (MAIN_MODE,)
+    if psnr_data is not None:
+        def psnr_gpu():
+            blk = {'iters': psnr_data['iters'], 'rays_per_iter': PSNR_RAYS, 'samples': '64+128', 'cameras': '100 x 800x800',
+                   'scene': 'three analytic Gaussian density blobs on white (fastnerf.synthetic), identical batches, injected '
+                            't_rand / u (seed 2) and initial weights (seed 0) on both sides',
+                   'train_psnr_window': 20, 'held_out_rays': PSNR_HELD_OUT, 'gpu': {}}
+            for mode in psnr_modes:
+                blk['gpu'][mode] = psnr_gpu_free(fastnerf, dd, new_trainer, K, mode)[0]
+            blk['free_runs_note'] = (
+                'single free runs from one initialisation: trajectories are chaotic, and the level reached after 200 iterations depends on the '
+                'initial weights by ~3 dB; the falsifiable free-run statement is the PAIRED test over the initialisation seeds of the committed '
+                'CPU ensemble G22 (tests/test_gpu_train.py::test_psnr_paired_with_the_cpu_ensemble_g22); the per-step statement is `lockstep`')
+            return blk
+        dd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in psnr_data.items()}
+        psnr_block = guarded('psnr_vs_cpu.gpu', psnr_gpu)
+
+    if siblings:
+        # ---- the other BASELINE configs at the headline arithmetic --------------------------------------------------------------
+        # (these loops have host work in their timed regions: the CPU PSNR worker -- our own child process -- is paused for their ~30 s; on boxes with
+        #  fewer than 128 CPUs it cannot be kept off the launching process's cores, and the nerf++ batch then measured 30 instead of 18.4 ms)
+        import signal
+        if psnr_proc is not None and psnr_proc.poll() is None:
+            psnr_proc.send_signal(signal.SIGSTOP)
+        try:
+            cfg_blocks = {k: v for k, v in (('configs[2]_quadtree', guarded('configs[2]', config2_quadtree)),
+                                            ('configs[3]_llff_ndc', guarded('configs[3]', config3_llff)),
+                                            ('configs[4]_nerfpp', guarded('configs[4]', config4_nerfpp))) if v is not None}
+        finally:
+            if psnr_proc is not None and psnr_proc.poll() is None:
+                psnr_proc.send_signal(signal.SIGCONT)
+        infer = guarded('inference', lambda: inference_leg({MAIN_MODE: kte, 'fp32': kte_32, 'bf16x3': kte_b}))
     ops.set_math(main_mode)
     fastnerf.render.set_compact(main_compact)
 
     if rank == 0:
         # ---- CPU legs: wait for the PSNR worker (it ran beside the GPU legs), then time the step alone ----------------------
         cpu = None
-        if siblings and not a.no_cpu_baseline:
-            if psnr_proc is not None:
-                _, err = psnr_proc.communicate()
-                if psnr_proc.returncode == 0:
-                    r = json.load(open(psnr_out))
-                    psnr_block['cpu'] = {'train_psnr_db': psnr_of(r['losses'], 20), 'held_out_psnr_db': -10.0 * math.log10(r['held_out_mse']),
-                                         'first_loss': r['losses'][0], 'last_loss': r['losses'][-1], 'threads': r['threads'],
-                                         'rays_per_s_while_gpu_legs_ran': r['rays_per_s'],
-                                         'what': 'oracle/nerf_oracle.py train_step / render_rays (torch CPU fp32), the same inputs'}
-                    psnr_block['delta_db'] = {m: {k: psnr_block['gpu'][m][k] - psnr_block['cpu'][k] for k in ('train_psnr_db', 'held_out_psnr_db')}
-                                              for m in psnr_block['gpu']}
-                    states = np.load(psnr_out + '.states', mmap_mode='r')
-                    psnr_block['lockstep'] = {
-                        'what': 'the GPU step taken from the CPU run\'s state before every iteration (weights + Adam moments): the same PSNR '
-                                'window without trajectory divergence; delta_db = GPU - CPU'}
-                    for mode in (MAIN_MODE, 'fp32', 'bf16x3'):
-                        r_ = psnr_gpu_lockstep(fastnerf, dd, new_trainer, states, r['losses'], mode)
-                        r_['delta_db'] = r_['train_psnr_db'] - psnr_block['cpu']['train_psnr_db']
-                        psnr_block['lockstep'][mode] = r_
-                    del states
-                    ops.set_math(main_mode)
-                    fastnerf.render.set_compact(main_compact)
-                else:
-                    psnr_block['cpu'] = {'error': err.decode()[-400:]}
-                for p in (psnr_in, psnr_out, psnr_out + '.states'):
-                    if p and os.path.exists(p):
-                        os.remove(p)
-            cpu = cpu_baseline(a.cpu_protocol)
-            if cfg_blocks is not None:
-                cfg_blocks['configs[2]_quadtree']['cpu_baseline'] = dict(
-                    cpu, note='the step of configs[2] is configs[1]\'s (the quadtree only chooses the rays): the same CPU figure; the reference\'s '
-                              'host-side quadtree work is not timed on top')
-                cfg_blocks['configs[3]_llff_ndc']['cpu_baseline'] = cpu_baseline_llff()
-                cfg_blocks['configs[4]_nerfpp']['cpu_baseline'] = cpu_baseline_nerfpp()
-                for b in cfg_blocks.values():
-                    b['vs_cpu_baseline'] = b['value'] / b['cpu_baseline']['value']
+        psnr_head = None
+
+        def psnr_cpu_side():
+            _, err = psnr_proc.communicate()
+            if psnr_proc.returncode != 0:
+                psnr_block['cpu'] = {'error': err.decode()[-400:]}
+                return
+            r = json.load(open(psnr_out))
+            psnr_block['cpu'] = {'train_psnr_db': psnr_of(r['losses'], 20), 'held_out_psnr_db': -10.0 * math.log10(r['held_out_mse']),
+                                 'first_loss': r['losses'][0], 'last_loss': r['losses'][-1], 'threads': r['threads'],
+                                 'rays_per_s_while_gpu_legs_ran': r['rays_per_s'],
+                                 'what': 'oracle/nerf_oracle.py train_step / render_rays (torch CPU fp32), the same inputs'}
+            psnr_block['delta_db'] = {m: {k: psnr_block['gpu'][m][k] - psnr_block['cpu'][k] for k in ('train_psnr_db', 'held_out_psnr_db')}
+                                      for m in psnr_block['gpu']}
+            states = np.load(psnr_out + '.states', mmap_mode='r')
+            psnr_block['lockstep'] = {
+                'what': 'the GPU step taken from the CPU run\'s state before every iteration (weights + Adam moments): the same PSNR '
+                        'window without trajectory divergence; delta_db = GPU - CPU'}
+            for mode in psnr_modes:
+                r_ = psnr_gpu_lockstep(fastnerf, dd, new_trainer, states, r['losses'], mode)
+                r_['delta_db'] = r_['train_psnr_db'] - psnr_block['cpu']['train_psnr_db']
+                psnr_block['lockstep'][mode] = r_
+            del states
+        if psnr_proc is not None:
+            if psnr_block is not None:
+                guarded('psnr_vs_cpu.cpu', psnr_cpu_side)
+            elif psnr_proc.poll() is None:
+                psnr_proc.kill()
+            ops.set_math(main_mode)
+            fastnerf.render.set_compact(main_compact)
+            for p in (psnr_in, psnr_out, psnr_out + '.states'):
+                if p and os.path.exists(p):
+                    os.remove(p)
+        if psnr_block is not None:    # the compact block of the headline line
+            g_ = psnr_block['gpu'].get(MAIN_MODE, {})
+            psnr_head = {'iters': psnr_block['iters'], 'rays_per_iter': PSNR_RAYS, 'gpu_train_db': g_.get('train_psnr_db'),
+                         'gpu_held_out_db': g_.get('held_out_psnr_db')}
+            if 'train_psnr_db' in psnr_block.get('cpu', {}):
+                psnr_head.update(cpu_train_db=psnr_block['cpu']['train_psnr_db'], cpu_held_out_db=psnr_block['cpu']['held_out_psnr_db'],
+                                 lockstep_delta_db=psnr_block['lockstep'][MAIN_MODE]['delta_db'],
+                                 lockstep_max_rel_loss_diff=psnr_block['lockstep'][MAIN_MODE]['max_rel_loss_diff'])
+            psnr_head['paired_ensemble'] = PAIRED_PSNR_NOTE
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = guarded('cpu_baseline', lambda: cpu_baseline(a.cpu_protocol))
+            if cpu is not None and cfg_blocks:
+                def cfg_cpu():
+                    if 'configs[2]_quadtree' in cfg_blocks:
+                        cfg_blocks['configs[2]_quadtree']['cpu_baseline'] = dict(
+                            cpu, note='the step of configs[2] is configs[1]\'s (the quadtree only chooses the rays): the same CPU figure; the '
+                                      'reference\'s host-side quadtree work at the shipped scale is timed by tools/bench_quadtree_full.py '
+                                      '(profiles/%s_quadtree_full.json)' % PROFILE_ROUND)
+                    if 'configs[3]_llff_ndc' in cfg_blocks:
+                        cfg_blocks['configs[3]_llff_ndc']['cpu_baseline'] = cpu_baseline_llff()
+                    if 'configs[4]_nerfpp' in cfg_blocks:
+                        cfg_blocks['configs[4]_nerfpp']['cpu_baseline'] = cpu_baseline_nerfpp()
+                    for b in cfg_blocks.values():
+                        if 'cpu_baseline' in b:
+                            b['vs_cpu_baseline'] = b['value'] / b['cpu_baseline']['value']
+                guarded('other_configs.cpu_baseline', cfg_cpu)
         rays_per_s = n_step * a.steps / dt
+
+        def ms_of(blk):
+            return None if blk is None else round(blk['init_state']['ms_per_step'], 3)
+        summary = None
+        if siblings:
+            summary = {'ms_per_step': {'fp32': ms_of(fp32_block), 'f16x3': ms_of(f16_block), 'bf16x3': ms_of(split_block),
+                                       'drop_in_' + MAIN_MODE: None if drop_in is None else round(drop_in[MAIN_MODE]['ms_per_step'], 3)},
+                       'sparse_scene_' + MAIN_MODE: None if main_sparse is None else {
+                           'ms_per_step': round(main_sparse['ms_per_step'], 3), 'rays_per_s': round(main_sparse['value']),
+                           'live_fine': None if not main_sparse['live_fraction'] else round(main_sparse['live_fraction']['fine'], 4),
+                           'plain_ms': round(main_sparse['same_state_plain_backward']['ms_per_step'], 3)},
+                       'configs_rays_per_s': None if not cfg_blocks else {k.split('_')[0]: round(v['value']) for k, v in cfg_blocks.items()},
+                       'inference_rays_per_s': None if infer is None or MAIN_MODE not in infer else round(infer[MAIN_MODE]['value'])}
         out = {
             'metric': 'training rays/sec (Lego-like 800x800, 64+128 samples) + PSNR@N-iters', 'value': rays_per_s, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
@@ -821,16 +987,22 @@ def main():
                                 '%.1f k rays/s/GPU' % (FP32_MFMA_PEAK_TFLOPS * 1e12 / TRAIN_FLOP_PER_RAY / 1e3),
             'sustained': sustained,
             'roofline': roof,
+            'psnr': psnr_head,
             'psnr_vs_cpu': psnr_block,
             'fp32_mfma_mode': fp32_block,
             'f16x3_mode': f16_block,
             'split_bf16_mode': split_block,
+            MAIN_MODE + '_sparse_scene': main_sparse,
             'drop_in_route': drop_in,
             'other_configs': cfg_blocks,
             'inference': infer,
             'cpu_baseline': cpu,
+            'siblings_summary': summary,
+            'errors': errors,
         }
-        print(json.dumps(out))
+        out['full_record'] = write_full_record(out, a.full_out)
+        sys.stderr.flush()
+        print(json.dumps(headline_record(out)), flush=True)      # the ONE stdout line, last
     if world > 1:
         parallel.barrier()
         torch.distributed.destroy_process_group()

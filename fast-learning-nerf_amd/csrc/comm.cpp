@@ -40,14 +40,31 @@ bool sym(void* h, const char* name, F& f) {
 }
 // an RCCL that is ALREADY in the process but not in the global symbol scope (PyTorch loads its bundled torch/lib/librccl.so as an
 // RTLD_LOCAL dependency of libtorch_hip.so): found by walking the loaded objects, re-opened with RTLD_NOLOAD -- the same copy,
-// never a second one next to it
-int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+// never a second one next to it.  The callback ONLY COPIES NAMES: glibc holds its loader lock for the whole walk, and a dlopen from
+// inside it orders the loader's locks opposite to a concurrent dlopen on another thread (torch and HIP load code objects lazily).
+struct LoadedNames {
+  static constexpr int kMax = 8;
+  char path[kMax][1024];
+  int n = 0;
+};
+int collect_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  auto* names = static_cast<LoadedNames*>(out);
   const char* name = info->dlpi_name;
-  if (name && std::strstr(name, "librccl")) {
-    void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
-    if (h && dlsym(h, "ncclCommInitRank")) { *static_cast<void**>(out) = h; return 1; }
+  if (name && std::strstr(name, "librccl") && names->n < LoadedNames::kMax && std::strlen(name) < sizeof(names->path[0])) {
+    std::strcpy(names->path[names->n++], name);
   }
   return 0;
+}
+void* open_loaded_rccl() {
+  LoadedNames names;
+  dl_iterate_phdr(collect_loaded_rccl, &names);
+  for (int i = 0; i < names.n; ++i) {      // after the walk, outside the loader lock
+    void* h = dlopen(names.path[i], RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+    if (h == nullptr) continue;
+    if (dlsym(h, "ncclCommInitRank")) return h;
+    dlclose(h);                            // (RTLD_NOLOAD took a reference: give it back for an object that is not an RCCL)
+  }
+  return nullptr;
 }
 // Resolution order: (1) FASTNERF_RCCL_LIB=<path> if set; (2) the global symbol scope; (3) a librccl already loaded in the process
 // (RTLD_NOLOAD); (4) only then the system librccl.so.1 -- a SECOND RCCL beside PyTorch's would come from another ROCm build than the
@@ -56,7 +73,7 @@ void load_rccl() {
   void* h = nullptr;
   if (const char* p = getenv("FASTNERF_RCCL_LIB")) h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
   if (h == nullptr && dlsym(RTLD_DEFAULT, "ncclCommInitRank") != nullptr) h = RTLD_DEFAULT;
-  if (h == nullptr) dl_iterate_phdr(find_loaded_rccl, &h);
+  if (h == nullptr) h = open_loaded_rccl();
   if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (h == nullptr) return;

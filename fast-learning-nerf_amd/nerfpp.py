@@ -313,7 +313,10 @@ class CascadeTrainer:
         from . import parallel
         n = ray_o.shape[0]
         dist = parallel.world_size() > 1
-        if n == 0:
+        if n == 0 and not dist:        # an empty batch of a single process is a no-op: no Adam step on a zero gradient (moments would decay,
+            self.last_depths = []      # t advance and the parameters drift by momentum)
+            return torch.zeros(len(self.nets), device=self.nets[0].flat.device), target.new_zeros((0, 3))
+        if n == 0:                     # an empty SHARD of a non-empty global batch: join every collective, take the common update
             for m, net in enumerate(self.nets):
                 net.flat_grad.zero_()
                 if dist:

@@ -58,7 +58,9 @@ class CabiComm:
     def all_reduce_sum(self, flat, scale=1.0, stream=None):
         L = self._lib
         L.require_gpu(flat)
-        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        if flat.dtype != torch.float32 or not flat.is_contiguous():      # (an assert would vanish under python -O and reduce garbage)
+            raise TypeError('fastnerf_allreduce_grads takes a contiguous float32 buffer, got %s%s' % (
+                flat.dtype, '' if flat.is_contiguous() else ' (non-contiguous)'))
         st = L.stream() if stream is None else stream.cuda_stream
         L.check(L.lib().fastnerf_allreduce_grads(self._h, L.ptr(flat), flat.numel(), float(scale), st), 'fastnerf_allreduce_grads')
         return flat
@@ -165,9 +167,15 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _cabi_takes(flat):
+    """The C-ABI collective is the gradient exchange: contiguous fp32 device buffers.  Anything else (the fp64 scalar of a logged
+    mse, a CPU tensor) goes through torch.distributed, which is initialised in every multi-rank run."""
+    return _CABI is not None and flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+
+
 def all_reduce_sum(flat):
     if world_size() > 1:
-        if _CABI is not None and flat.is_cuda:
+        if _cabi_takes(flat):
             return _CABI.all_reduce_sum(flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
@@ -178,7 +186,7 @@ def all_reduce_sum_async(flat):
     the collective runs on the process group's own stream behind everything enqueued on the current stream so far, beside
     whatever the caller enqueues next; `wait_all` orders the current stream behind it."""
     if world_size() > 1:
-        if _CABI is not None and flat.is_cuda:
+        if _cabi_takes(flat):
             return _CABI.all_reduce_sum_async(flat)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     return None

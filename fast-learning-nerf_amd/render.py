@@ -22,8 +22,13 @@ _SEED_GEN = torch.Generator()
 
 
 def _next_seed():
-    # device-side Philox streams are keyed from torch's global CPU RNG so torch.manual_seed governs them
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    """Key of a device-side Philox stream, drawn from torch's global CPU RNG so that torch.manual_seed governs it.  In a sharded run
+    every rank draws the SAME value (parallel.sync_seed keeps the host streams in step, which the redundantly drawn pixel picks need) and
+    folds its rank in: rows r::world of different ranks must not carry identical jitter patterns.  Rank 0 / a single process: unchanged."""
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    from . import parallel
+    rk = parallel.rank()
+    return seed if rk == 0 else (seed ^ ((rk * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)))
 
 
 def _pytest_rand(shape, device):

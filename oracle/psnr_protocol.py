@@ -42,10 +42,14 @@ def draw_pixels(gen, n):
                         torch.randint(0, W, (n,), generator=gen)], 1)
 
 
-def inputs(scene_fn):
+LONG_ITERS = 1000        # the longer horizon (G23): the same protocol with 1000 iterations, batch seed 3
+
+
+def inputs(scene_fn, iters=None, batch_seed=2):
     """scene_fn(rays_o, rays_d) -> colours (fastnerf.synthetic.render_rays with cutoff 0, on CPU tensors)."""
+    ITERS = globals()['ITERS'] if iters is None else int(iters)
     poses = cameras()
-    g = torch.Generator().manual_seed(2)
+    g = torch.Generator().manual_seed(batch_seed)
     ro, rd, tgt = [], [], []
     for _ in range(ITERS):
         o, d = rays_of(draw_pixels(g, RAYS), poses)
@@ -67,7 +71,9 @@ def psnr(mse):
 
 
 def cpu_run(seed, data):
-    """One free run of the CPU oracle -> (train PSNR over the last WINDOW iterations, held-out PSNR, first loss)."""
+    """One free run of the CPU oracle over all iterations `data` holds -> (train PSNR over the last WINDOW iterations, held-out PSNR,
+    first loss)."""
+    ITERS = data['ro'].shape[0]
     sdc, sdf = init_weights(seed)
     opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
     losses = []

@@ -1,5 +1,5 @@
-"""The N>1 path of bench.py end to end on the GPU: two ranks launched exactly as the driver launches them (torch.distributed.run,
-127.0.0.1 rendezvous), sharded rays, gradient all-reduce, barrier-bracketed timing, rank-0 JSON.  On a 1-GPU box the two
+"""The N>1 path of bench.py end to end on the GPU: two ranks under the contract's launcher command (torch.distributed.run, 127.0.0.1
+rendezvous) AND from the bare `python bench.py --gpus N` (which re-executes itself under that launcher), sharded rays, gradient all-reduce, barrier-bracketed timing, rank-0 JSON.  On a 1-GPU box the two
 ranks share the device and the collective backend is gloo (FASTNERF_DIST_BACKEND); on a multi-GPU box this is RCCL."""
 import json
 import os
@@ -14,26 +14,35 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(backend, port, scaling='weak'):
-    env = dict(os.environ)
+def _run(backend, port, scaling, full_out, launcher=True):
+    """launcher=True: under torch.distributed.run, the contract's N>1 command; False: the BARE `python bench.py --gpus 2 ...` (the way the
+    N=1 command is started) -- bench.py must re-execute itself under the launcher instead of asserting on WORLD_SIZE."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     if backend:
         env['FASTNERF_DIST_BACKEND'] = backend
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--sustained-steps', '5',
-           '--scaling', scaling]
+    args = ['--gpus', '2', '--steps', '3', '--warmup', '1', '--sustained-steps', '5', '--scaling', scaling, '--full-out', full_out]
+    if launcher:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize('scaling', ['weak', 'strong'])
-def test_bench_two_ranks(scaling):
+@pytest.mark.parametrize('scaling,launcher', [('weak', True), ('strong', True), ('weak', False)])
+def test_bench_two_ranks(scaling, launcher, tmp_path):
     # two or more GPUs: the collective MUST be RCCL over xGMI -- a failure there is a failure (no gloo retry);
     # a 1-GPU box can only exercise the plumbing (both ranks on one device, gloo)
     port = 29533 if scaling == 'weak' else 29535
-    out = _run(None, port, scaling) if torch.cuda.device_count() >= 2 else _run('gloo', port, scaling)
+    full_out = str(tmp_path / 'full.json')
+    out = _run(None if torch.cuda.device_count() >= 2 else 'gloo', port, scaling, full_out, launcher)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(lines) == 1, out.stdout[-2000:]          # exactly one JSON line, from rank 0
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]   # exactly ONE stdout line, the headline, from rank 0
+    assert len(lines[0]) <= 4096
     j = json.loads(lines[0])
+    full = json.load(open(full_out))
+    assert full['value'] == j['value'] and full['sustained']['steps'] == 5 and j['sustained_ms_per_step'] > 0
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == scaling and j['value'] > 0 and j['dtype'] == 'f32'
     per_gpu = 4096 if scaling == 'weak' else 2048        # weak: per-GPU work fixed; strong: 4096 rays per step split over the ranks
     assert j['config']['parallelism'] == 'dp2' and j['config']['rays_per_gpu_per_step'] == per_gpu and j['cpu_baseline'] is None
@@ -42,14 +51,14 @@ def test_bench_two_ranks(scaling):
     assert len(j['per_rank_ms_per_step']) == 2 and all(x > 0 for x in j['per_rank_ms_per_step'])
     ar = j['allreduce_ms']
     assert ar['fine_half'] > 0 and ar['coarse_half'] > 0 and ar['whole_buffer'] > 0 and ar['overlapped_with_coarse_backward'] is True
-    assert j['sustained']['steps'] == 5
-    assert j['split_bf16_mode']['init_state']['value'] > 0          # the sibling leg ran on both ranks too
-    assert j['psnr_vs_cpu'] is None and j['drop_in_route'] is None  # 1-GPU legs
+    assert j['roofline']['frac'] > 0 and j['roofline']['bound'] == 'mfma'
+    assert j['psnr'] is None and j['siblings'] is None and full['psnr_vs_cpu'] is None and full['drop_in_route'] is None  # 1-GPU legs
 
 
 @pytest.mark.parametrize('scaling', ['strong', 'weak'])
-def test_bench_eight_ranks_on_what_the_box_has(scaling):
-    """Multi-GPU readiness without the hardware: `bench.py --gpus 8` launched exactly as the driver launches it.  On a box with fewer
+def test_bench_eight_ranks_on_what_the_box_has(scaling, tmp_path):
+    """Multi-GPU readiness without the hardware: the BARE `python bench.py --gpus 8 ...` (no launcher: bench.py re-executes itself under
+    torch.distributed.run; a harness that starts N=8 the way it starts N=1 must not die on an assert).  On a box with fewer
     than 8 GPUs the ranks share devices and the collectives run over gloo (plumbing only: 8 shards, n_local / N_global scaling, the two
     half-buffer collectives, max-over-ranks timing, one JSON line); FASTNERF_COLLECTIVE=cabi must then fall back LOUDLY (RCCL cannot
     put two ranks of a communicator on one device) and say so in the JSON.  No scaling number is claimed from this."""
@@ -59,13 +68,14 @@ def test_bench_eight_ranks_on_what_the_box_has(scaling):
         torch.cuda.empty_cache()       # eight ranks of 4096 rays need ~20 GB each on the shared device: give back this process's cached blocks
     if shared:
         env['FASTNERF_DIST_BACKEND'] = 'gloo'
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
-           '--master-port', '29571' if scaling == 'strong' else '29573', os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2',
-           '--warmup', '1', '--sustained-steps', '0', '--no-siblings', '--scaling', scaling]
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--sustained-steps', '0',
+           '--scaling', scaling, '--full-out', os.path.join(str(tmp_path), 'full.json')]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"') and len(lines[0]) <= 4096, out.stdout[-2000:]
     j = json.loads(lines[0])
     per_gpu = 4096 if scaling == 'weak' else 512
     assert j['n_gpus'] == 8 and j['scaling'] == scaling and j['config']['parallelism'] == 'dp8'
