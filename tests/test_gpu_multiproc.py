@@ -29,6 +29,16 @@ def _run(backend, port, scaling, full_out, launcher=True):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
+def _headline(stdout):
+    """Exactly ONE JSON line on stdout, from rank 0, and it is the LAST line (<= 4 KB).  (Over gloo -- 1-GPU boxes only -- every rank's
+    transport prints a '[Gloo] Rank r is connected to ...' line on stdout when the group forms: before the headline, not JSON.)"""
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert sum(l.lstrip().startswith('{') for l in lines) == 1 and lines[-1].startswith('{"metric"'), stdout[-2000:]
+    assert all(l.startswith('[Gloo]') for l in lines[:-1]), lines[:-1]
+    assert len(lines[-1]) <= 4096
+    return json.loads(lines[-1])
+
+
 @pytest.mark.parametrize('scaling,launcher', [('weak', True), ('strong', True), ('weak', False)])
 def test_bench_two_ranks(scaling, launcher, tmp_path):
     # two or more GPUs: the collective MUST be RCCL over xGMI -- a failure there is a failure (no gloo retry);
@@ -37,10 +47,7 @@ def test_bench_two_ranks(scaling, launcher, tmp_path):
     full_out = str(tmp_path / 'full.json')
     out = _run(None if torch.cuda.device_count() >= 2 else 'gloo', port, scaling, full_out, launcher)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith('{"metric"'), out.stdout[-2000:]   # exactly ONE stdout line, the headline, from rank 0
-    assert len(lines[0]) <= 4096
-    j = json.loads(lines[0])
+    j = _headline(out.stdout)
     full = json.load(open(full_out))
     assert full['value'] == j['value'] and full['sustained']['steps'] == 5 and j['sustained_ms_per_step'] > 0
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == scaling and j['value'] > 0 and j['dtype'] == 'f32'
@@ -74,9 +81,7 @@ def test_bench_eight_ranks_on_what_the_box_has(scaling, tmp_path):
            '--scaling', scaling, '--full-out', os.path.join(str(tmp_path), 'full.json')]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith('{"metric"') and len(lines[0]) <= 4096, out.stdout[-2000:]
-    j = json.loads(lines[0])
+    j = _headline(out.stdout)
     per_gpu = 4096 if scaling == 'weak' else 512
     assert j['n_gpus'] == 8 and j['scaling'] == scaling and j['config']['parallelism'] == 'dp8'
     assert j['config']['rays_per_gpu_per_step'] == per_gpu and j['config']['rays_per_step'] == 8 * per_gpu
