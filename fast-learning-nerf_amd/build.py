@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfastnerf.so')
-SOURCES = ['rays.hip', 'composite.hip', 'train.hip', 'mlp.hip', 'mlp_bf16.hip', 'tree.cpp', 'render.cpp', 'comm.cpp']
+SOURCES = ['rays.hip', 'composite.hip', 'train.hip', 'mlp_pack.hip', 'mlp_fwd.hip', 'mlp_bwd_dx.hip', 'mlp_bwd_dw.hip', 'mlp_bf16.hip', 'tree.cpp', 'render.cpp', 'comm.cpp']
 # -fno-slp-vectorize: with SLP on, hipcc (ROCm 7.2) packs the epilogues' scalar fp32 adds into v_pk_add_f32; on
 # gfx950 the split-bf16 forward then produced sporadic wrong sums (bias dropped in lanes 48..63 of one register,
 # ~0.1% of points, timing dependent) -- and packed fp32 VALU next to MFMAs is slower anyway.
@@ -30,7 +30,10 @@ def build(force=False, verbose=False):
     if not force and not _stale() and not os.environ.get('FASTNERF_VARIANT'):
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    extra = os.environ.get('FASTNERF_CFLAGS', '').split()   # tuning experiments, e.g. -DTM=128
+    extra = os.environ.get('FASTNERF_CFLAGS', '').split()   # tuning experiments
+    if any(f.startswith('-DFASTNERF_ABLATION') for f in extra) and not os.environ.get('FASTNERF_VARIANT'):
+        # timing-only builds compute WRONG RESULTS by design (csrc/mlp_common.h): they may only exist as variants/<name>.so
+        raise RuntimeError('FASTNERF_ABLATION builds need FASTNERF_VARIANT=<name>: the product library is never an ablation build')
     objs = []
     procs = []
     variant = os.environ.get('FASTNERF_VARIANT')   # tuning builds: variants/<name>.so, loaded with FASTNERF_LIB=...

@@ -33,82 +33,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
-#ifndef DW_PIPE
-#define DW_PIPE 0   // 1: read the LDS fragments of k-step q+1 under the MFMAs of k-step q (needs DW_NST >= 4)
-#endif
-#ifndef DW_NST
-#define DW_NST 3   // LDS stages of the dW operand ring (DW_NST - 1 k-steps prefetched)
-#endif
-#ifndef DW_DMA_LATE
-#define DW_DMA_LATE 1   // issue a k-step's operand DMA between its fragment reads and their wait
-#endif
-#ifndef DW_AUX
-#define DW_AUX 2   // cache-policy bits of the dW operand DMA (saved tensors are read exactly once)
-#endif
-#ifndef DW_CFG
-#define DW_CFG 4, 2, 2, 4   // WO, WI, TO, TI of the 256 x 256 dW jobs: 8 waves (two per SIMD) x (2 x 4) tiles.  Round 1 ran 4 waves x
-                            // (4 x 4) tiles = ONE wave per SIMD, where nothing hides the operand DMA issue, the fragment reads and
-                            // the bias sums behind the MFMAs: the loop is issue-bound, not HBM-bound (round-2 ablations: no gain from
-                            // contiguous operand runs or a 4th ring stage, and only -0.5 ms without ANY operand DMA); with two waves
-                            // per SIMD on today's LDS-DMA ring the fine-pass backward goes 6.14 -> 5.88 ms (16 waves: equal)
-#endif
-#ifndef BF_PRIO
-#define BF_PRIO 1   // s_setprio level of a wave inside the k-loops (0: none); +1..2 % with two workgroups per CU
-#endif
-#ifndef BF_BUFLD
-#ifndef DW_SKIP_IDLE
-#define DW_SKIP_IDLE 1   // dW workgroups without tiles write no partials and breduce skips them (0: A/B)
-#endif
-#ifndef BF_WAUX
-#define BF_WAUX 0   // cache-policy bits of the weight-fragment loads (1 = sc0, 2 = sc1 / slc, 3 = both): measured, see DESIGN section 9
-#endif
-#define BF_BUFLD 1   // weight fragments via buffer_load_dwordx4 (scalar offsets) instead of 64-bit vector pointers
-#endif
-#ifndef BF_SKIP_DEAD
-#define BF_SKIP_DEAD 1   // FN_FWD_SKIP_DEAD_RGB support in the inference forward (0: compiled out, for A/B timing)
-#endif
-#ifndef BF_PRE_FWD
-#define BF_PRE_FWD 0   // forward: next layer's first weight fragments loaded ahead of the epilogue (measured -1 %: spills)
-#endif
-#ifndef BF_PRE_DX
-#define BF_PRE_DX 1    // dX: same (measured +1 %)
-#endif
-#ifndef BF_PF
-#define BF_PF 2   // weight fragments two k-steps ahead in the fwd / dX k-loops (1: one ahead)
-#endif
-#ifndef BF_LATE_SAVE
-#define BF_LATE_SAVE 0   // experiment: keep a layer's 16 saved-tensor stores per wave in registers and issue them at the END of the
-                         // next k-loop (no weight load queues behind them in the in-order vmcnt queue); costs 64 VGPRs
-#endif
-#ifndef BF_PRE_STEPS
-#define BF_PRE_STEPS 1   // k-steps of the next layer prefetched ahead of an epilogue (PRE): 2 costs 16 more VGPRs -> scratch spills in dX
-#endif
 // Bisection hook for the SLP-vectoriser corruption (tools/slp_bisect.py): what is executed at every
 // k-loop exit, in front of the epilogue.  0: nothing (product); 1: 34 idle wait states (drains the matrix pipe);
 // 2: s_waitcnt vmcnt(0) lgkmcnt(0) (drains every outstanding load, incl. the pre-loaded bias / mask words)
-#ifndef BF_DBG_DRAIN
-#define BF_DBG_DRAIN 0
-#endif
 __device__ __forceinline__ void bdbg_drain() {
-#if BF_DBG_DRAIN == 1
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 1" ::: "memory");
-#elif BF_DBG_DRAIN == 2
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
 }
 #define BTM 64
 #define BNTHR 256
-#ifdef BF_TRACE   // tuning builds only: per-wave s_memtime stamps of the forward's phases (tools/trace_fwd.py)
-#define TR_NEV 40
-#define TR_NBLK 512
-__device__ long long g_trace[TR_NBLK * 4 * TR_NEV];
-#define TR(e) do { if (trace_on && lane == 0) g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + (e)] = clock64(); } while (0)
-extern "C" int fastnerf_debug_trace(long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(long long) * n);
-}
-#else
-#define TR(e)
-#endif
 #define BLDS_BYTES (2 * BTM * 256 * 2 + 2 * BTM * 64 * 2)   // 81920
 
 static int b_num_cus() {
@@ -301,14 +232,13 @@ __device__ __forceinline__ f32x16 bmfma(const uint4& a, const uint4& b, f32x16 c
 // not have to drain them (vmcnt retires in order; a k-loop that starts behind 16 KiB of stores per wave measured
 // +30 %: 11.5 k vs 8.9 k ticks, tools/trace_fwd.py).
 template <int NT>
-struct BPre { uint4 h0[NT], l0[NT], h1[NT], l1[NT]; };
+struct BPre { uint4 h0[NT], l0[NT]; };   // k-step 0 (a second prefetched k-step costs 16 VGPRs: scratch spills in dX)
 template <int NT>
 __device__ __forceinline__ void bprefetch(BPre<NT>& p, const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const uint4* q = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128 + lane;
     p.h0[nt] = q[0]; p.l0[nt] = q[64];
-    if (BF_PRE_STEPS == 2) { p.h1[nt] = q[128]; p.l1[nt] = q[192]; }
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -316,7 +246,7 @@ __device__ __forceinline__ void bprefetch(BPre<NT>& p, const uint4* __restrict__
 // accumulate nks (even) k-steps of 16.  A planes in LDS (H layout or E layout); B packed in global.
 // PRE: the fragments of k-steps 0 and 1 are already in *pre (needs nks >= 4).
 // AMODE: 0 = H planes, 1 = E planes, 2 = X2 block (pass Ahi = Hhi + X2_HI_OFF, Alo = Hhi + X2_LO_OFF)
-template <int NT, int AMODE, bool PRE = false, int PF = BF_PF>
+template <int NT, int AMODE, bool PRE = false, int PF = 2>
 __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, const char* Alo, int a_ks0, int nks,
                                       const uint4* __restrict__ Bp, int KS, int b_ks0, int nt0, int lane,
                                       const BPre<NT>* pre = nullptr) {
@@ -331,18 +261,11 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
   };
   // weight fragments through buffer loads: resource = this layer's packed block (uniform), VGPR offset = lane * 16
   // (loop invariant), the (column tile, k-step, plane) part is a scalar offset -> no vector address arithmetic
-#if BF_BUFLD
   const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Bp), 0, 0x7fffffff, 0x00020000);
   const int bvofs = lane * 16;
   int bsofs[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bsofs[nt] = ((nt0 + nt) * KS + b_ks0) * 2048;
-#else
-  const uint4* bptr[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bptr[nt] = Bp + ((int64_t)(nt0 + nt) * KS + b_ks0) * 128;
-  const unsigned blane = (unsigned)lane;
-#endif
   auto ldA = [&](uint4 (&ah)[2], uint4 (&al)[2], int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -354,13 +277,9 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
   auto ldB = [&](uint4 (&bh)[NT], uint4 (&bl)[NT], int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-#if BF_BUFLD
       typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
-      bh[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048, BF_WAUX));
-      bl[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048 + 1024, BF_WAUX));
-#else
-      bh[nt] = (bptr[nt] + ks * 128)[blane]; bl[nt] = (bptr[nt] + ks * 128 + 64)[blane];
-#endif
+      bh[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048, 0));
+      bl[nt] = __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(brsrc, bvofs, bsofs[nt] + ks * 2048 + 1024, 0));
     }
   };
   auto mm = [&](const uint4 (&ah)[2], const uint4 (&al)[2], const uint4 (&bh)[NT], const uint4 (&bl)[NT]) __attribute__((always_inline)) {
@@ -378,21 +297,14 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bmfma(al[mt], bh[nt], acc[mt][nt]);
   };
   uint4 ah0[2], al0[2], ah1[2], al1[2], bh0[NT], bl0[NT], bh1[NT], bl1[NT];
-#if BF_PRIO
-  __builtin_amdgcn_s_setprio(BF_PRIO);
-#endif
+  __builtin_amdgcn_s_setprio(1);
   // weights two k-steps ahead (four register sets), activations one ahead; nks % 4 == 0 except the 2-step segments
   if (PF == 2 && nks >= 4) {
     uint4 bh2[NT], bl2[NT], bh3[NT], bl3[NT];
     if (PRE) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) { bh0[nt] = pre->h0[nt]; bl0[nt] = pre->l0[nt]; }
-      if (BF_PRE_STEPS == 2) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { bh1[nt] = pre->h1[nt]; bl1[nt] = pre->l1[nt]; }
-      } else {
-        ldB(bh1, bl1, 1);
-      }
+      ldB(bh1, bl1, 1);
     } else {
       ldB(bh0, bl0, 0); ldB(bh1, bl1, 1);
     }
@@ -409,9 +321,7 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
       if (ks + 4 < nks) { ldB(bh1, bl1, ks + 5); ldA(ah0, al0, ks + 4); }
       mm(ah1, al1, bh3, bl3);
     }
-#if BF_PRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
     bdbg_drain();
     return;
   }
@@ -423,9 +333,7 @@ __device__ __forceinline__ void bgemm(f32x16 (&acc)[2][NT], const char* Ahi, con
     if (ks + 2 < nks) { ldB(bh0, bl0, ks + 2); ldA(ah0, al0, ks + 2); }
     mm(ah1, al1, bh1, bl1);
   }
-#if BF_PRIO
   __builtin_amdgcn_s_setprio(0);
-#endif
   bdbg_drain();
 }
 
@@ -443,50 +351,14 @@ __device__ __forceinline__ void bzero(f32x16 (&acc)[2][NT]) {
 // C layout of the 32x32 MFMAs: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int bcrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-#ifndef BF_NT
-#define BF_NT 1   // non-temporal stores for the saved tensors (streamed once, read by dW much later)
-#endif
 __device__ __forceinline__ void gstore8(uint2* p, const uint2& v) {   // 8-byte piece of a saved K-fragment element
-#if BF_NT
   __builtin_nontemporal_store(((u64)v.y << 32) | v.x, reinterpret_cast<u64*>(p));
-#else
-  *p = v;
-#endif
 }
 
-#ifndef BF_W16
-#define BF_W16 1
-#endif
 __device__ __forceinline__ void gstore16(uint4* p, const uint4& v) {
-#ifdef BF_ABL_NOSTORE   // ablation builds (tools/trace_fwd.py): what do the saved-tensor stores cost the k-loop?
-  if (v.x != 0x12345678u) return;
-#endif
-#if BF_NT
   typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
   const u32x4s t = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(t, reinterpret_cast<u32x4s*>(p));
-#else
-  *p = v;
-#endif
-}
-
-// stores of one 256-wide layer held back (BF_LATE_SAVE): index ((mt*2 + nt)*2 + k2)*2 + part
-struct BPend {
-  uint4 v[16];
-  uint4* base;   // tensor tile base + this lane's (half*32 + j); the per-store offset is a constant of (wn, index)
-};
-__device__ __forceinline__ void bpend_flush(const BPend& pd, int wn) {
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-          const int ct = wn * 2 + nt, ks = mt * 2 + k2;
-          gstore16(pd.base + ((ct * 4 + ks) * 2 + part) * 64, pd.v[((mt * 2 + nt) * 2 + k2) * 2 + part]);
-        }
 }
 
 struct EpiArgs {
@@ -544,9 +416,9 @@ __device__ __forceinline__ float mask_get(unsigned m, int k, float v) {
 //   - LDS: the column pair is one packed 32-bit store per plane and row,
 //   - global: 4 consecutive rows of one column = 8 bytes of a K-fragment element (see the file header),
 //   - sign bits (forward, ReLU layers): 64 per thread and layer, order mt, r, nt.
-template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE, bool LATESAVE = false>
+template <bool BIAS, bool RELU, bool MASK, bool RANK1, bool MOUT, bool GSAVE>
 __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs& ea, char* Hhi, char* Hlo, int wn,
-                                        int lane, BPend& pend) {
+                                        int lane) {
   asm volatile("" : "+v"(lane));
   const int j = lane & 31, half = lane >> 5;
   const int n0 = wn * 64 + 2 * j;
@@ -585,7 +457,6 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
     }
     if (mt) mout2.y = mo; else mout2.x = mo;
     if (GSAVE) {
-#if BF_W16
       // 16-byte stores: exchange halves so that lanes 0..31 hold the whole 8-point element of the even k-group
       // and lanes 32..63 that of the odd one (v_permlane32_swap: X.hi <-> Y.lo); one wave store = 1 KiB contiguous
 #pragma unroll
@@ -607,30 +478,10 @@ __device__ __forceinline__ void bepi256(const f32x16 (&acc)[2][2], const EpiArgs
               const auto r = __builtin_amdgcn_permlane32_swap(xe[part][w], xo[part][w], false, false);
               xe[part][w] = r[0]; xo[part][w] = r[1];
             }
-            if (LATESAVE) {
-              pend.v[((mt * 2 + nt) * 2 + k2) * 2 + part] = make_uint4(xe[part][0], xe[part][1], xo[part][0], xo[part][1]);
-              pend.base = reinterpret_cast<uint4*>(ea.gsave) + half * 32 + j;
-            } else {
-              uint4* p4 = reinterpret_cast<uint4*>(ea.gsave) + (((ct * 4 + ks) * 2 + part) * 64 + half * 32 + j);
-              gstore16(p4, make_uint4(xe[part][0], xe[part][1], xo[part][0], xo[part][1]));
-            }
+            uint4* p4 = reinterpret_cast<uint4*>(ea.gsave) + (((ct * 4 + ks) * 2 + part) * 64 + half * 32 + j);
+            gstore16(p4, make_uint4(xe[part][0], xe[part][1], xo[part][0], xo[part][1]));
           }
         }
-#else
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int ct = wn * 2 + nt, ks = mt * 2 + (g >> 1), kb = g & 1;
-          uint2* p = ea.gsave + ((((ct * 4 + ks) * 2) * 64 + kb * 32 + j) * 2 + half);
-          const unsigned sel = nt ? 0x07060302u : 0x05040100u;   // the nt-th 16 bits of two consecutive rows
-          uint2 h, l;
-          h.x = __builtin_amdgcn_perm(H[4 * g + 1], H[4 * g], sel); h.y = __builtin_amdgcn_perm(H[4 * g + 3], H[4 * g + 2], sel);
-          l.x = __builtin_amdgcn_perm(L[4 * g + 1], L[4 * g], sel); l.y = __builtin_amdgcn_perm(L[4 * g + 3], L[4 * g + 2], sel);
-          gstore8(p, h);
-          gstore8(p + 128, l);
-        }
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -756,15 +607,6 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     if (live_idx) pp = live_idx[pp];
     const int64_t ray = pp / S;
     const float* rr = rays + ray * 11;
-#ifdef BF_TRACE
-    const bool trace_on = blockIdx.x < TR_NBLK && titer == 4;
-    TR(0);
-    if (trace_on && lane == 0) {
-      g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 38] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
-      g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 39] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
-      g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 36] = wall_clock64();                      // 100 MHz
-    }
-#endif
     // store one PE channel at row pm: E planes (c < 64) or the X2 block (c >= 64), and (SAVE, stage) the K-fragment
     // staging copy that aliases the head of H
     auto est = [&](int c, float v, bool stage = true) {
@@ -835,11 +677,9 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     }
     f32x16 acc[2][2];
     EpiArgs ea{};
-    constexpr bool PRE = !BG && (BF_PF == 2) && BF_PRE_FWD;   // (the background variant has no registers to spare)
-    constexpr bool LATE = BF_LATE_SAVE && SAVE && !BG;
-    constexpr int KPF = (BG || (LATE && BF_LATE_SAVE == 2)) ? 1 : BF_PF;   // background net: weight fragments one k-step ahead (two would spill: 256 VGPRs + scratch)
+    constexpr bool PRE = false;           // (next layer's first weight fragments ahead of the epilogue: measured -1 % in the forward -- spills; dX keeps it)
+    constexpr int KPF = BG ? 1 : 2;       // background net: weight fragments one k-step ahead (two would spill: 256 VGPRs + scratch)
     BPre<2> pre;
-    BPend pend;
     // L0
     ea.bias = params + lay.LB[0];
     bepi256_preload<true, false, false>(ea, wn, lane);
@@ -856,11 +696,10 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       ea.mask_out = maskw_all + (tile * 8 + 0) * 256;
     }
     if (PRE) bprefetch<2>(pre, pk + boff.off[1], 16, 0, wn * 2, lane);
-    bepi256<true, true, false, false, SAVE, SAVE, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
+    bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
-      TR(4 * l);
       ea.bias = params + lay.LB[l];
       bepi256_preload<true, false, false>(ea, wn, lane);
       bzero<2>(acc);
@@ -880,10 +719,7 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       } else {
         bgemm<2, 0, PRE, KPF>(acc, Hhi, Hlo, 0, 16, B, 16, 0, wn * 2, lane, &pre);
       }
-      TR(4 * l + 1);
-      if (LATE) bpend_flush(pend, wn);   // h_{l-1}: behind this k-loop's last weight load, in front of a whole epilogue
       __syncthreads();
-      TR(4 * l + 2);
       if (SAVE) {
         ea.gsave = reinterpret_cast<uint2*>(act + ba_h(nt_lay, l) + tile * 4096);
         ea.mask_out = maskw_all + (tile * 8 + l) * 256;
@@ -892,11 +728,9 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         const int ln = l + 1;
         bprefetch<2>(pre, pk + boff.off[ln], ln == 5 ? 20 : 16, 0, wn * 2, lane);
       }
-      bepi256<true, true, false, false, SAVE, SAVE, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
-      TR(4 * l + 3);
+      bepi256<true, true, false, false, SAVE, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
       __syncthreads();
     }
-    TR(32);
     // alpha head + view-direction encoding
     float alpha_val;
     {
@@ -942,13 +776,11 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
         estv(6 + 6 * k + dim, ca_);
       }
     }
-    TR(33);
     // FN_FWD_SKIP_DEAD_RGB (inference launches of the NeRF net only): when EVERY sample of the tile has sigma <= 0, every one
     // of them gets alpha = 0 and weight = 0 exactly in the compositing (no sigma noise in this mode: the caller's promise), so
     // their colour logits can reach no output and no gradient -- the feature layer, the view layer and the colour head (17 % of
     // the tile's MACs) are skipped and the logits are written as zeros.  Rays that miss the scene are whole tiles of this kind.
     bool skip_tail = false;
-#if BF_SKIP_DEAD
     if (!SAVE && !BG && (flags & 1)) {
       // (no __syncthreads_and: it brings a static LDS word, and 80 KiB + 4 bytes per workgroup means ONE workgroup per CU.)
       // One word per wave in 16 bytes of the encoding plane that are free here: channels 56..63 of row 0 -- the point encoding
@@ -959,7 +791,6 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       __syncthreads();
       skip_tail = (slot[0] | slot[1] | slot[2] | slot[3]) == 0;
     }
-#endif
     if (skip_tail) {
       if (pq == 0 && pm < valid && raw) *reinterpret_cast<float4*>(raw + (p0 + pm) * 4) = make_float4(0.f, 0.f, 0.f, alpha_val);
     } else {
@@ -968,12 +799,11 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
     bepi256_preload<true, false, false>(ea, wn, lane);
     bzero<2>(acc);
     bgemm<2, 0, PRE, KPF>(acc, Hhi, Hlo, 0, 16, pk + boff.off[8], 16, 0, wn * 2, lane, &pre);
-    if (LATE) bpend_flush(pend, wn);     // h7
     __syncthreads();
     if (SAVE) ea.gsave = reinterpret_cast<uint2*>(act + ba_feat(nt_lay) + tile * 4096);
     BPre<1> prev;
     if (PRE) bprefetch<1>(prev, pk + boff.off[9], 18, 0, wn, lane);
-    bepi256<true, false, false, false, false, SAVE>(acc, ea, Hhi, Hlo, wn, lane, pend);
+    bepi256<true, false, false, false, false, SAVE>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // view layer: [feat256 | vpe32] -> 128, ReLU
     {
@@ -1018,10 +848,6 @@ mlp_fwd_bf16_kernel(int64_t P, int S, const float* __restrict__ rays, const floa
       }
     }
     }   // !skip_tail
-    TR(34);
-#ifdef BF_TRACE
-    if (trace_on && lane == 0) g_trace[((int)blockIdx.x * 4 + wn) * TR_NEV + 37] = wall_clock64();
-#endif
     tile = b_next_tile(sched, sched_word, tid);   // (contains the tile's closing barrier)
   }
   b_sched_exit(sched, tid);
@@ -1035,12 +861,6 @@ static int b_fwd_launch(int kind, int64_t n, int S, const float* rays11, const f
   const int64_t P = n * S;
   const int64_t ntiles = (P + BTM - 1) / BTM;
   int grid = b_num_cus() * 2;
-#ifdef BF_TRACE
-  if (getenv("BF_ONE_WG")) grid = b_num_cus();
-#endif
-#ifdef BF_EXPERIMENT
-  if (getenv("FASTNERF_FWD_WGS")) grid = atoi(getenv("FASTNERF_FWD_WGS"));
-#endif
   if (ntiles < grid) grid = (int)ntiles;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1135,11 +955,9 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     }
     __syncthreads();
     EpiArgs ea{};
-    constexpr int DXPF = (BF_LATE_SAVE == 2) ? 1 : BF_PF;
-    constexpr bool PRE = (DXPF == 2) && BF_PRE_DX;
+    constexpr int DXPF = 2;
+    constexpr bool PRE = true;            // the next product's first weight fragments are loaded ahead of the epilogue (+1 %)
     BPre<2> pre;
-    constexpr bool LATE = BF_LATE_SAVE;
-    BPend pend;
     // ---- dYv = (drgb . Wr) * [hv > 0] -> H[:, 0:128] ---------------------------------------------------
     {
       f32x16 av[2][1];
@@ -1167,7 +985,7 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_feat(nt_lay) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[1], 16, 0, wn * 2, lane);
-    bepi256<false, false, false, false, false, true, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
+    bepi256<false, false, false, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY7 = (dfeat . Wf + dalpha x wa) * [h7 > 0] ---------------------------------------------------
     ea.mask_in = maskw_all + (tile * 8 + 7) * 256;
@@ -1176,11 +994,10 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
     bepi256_preload<false, true, true>(ea, wn, lane);
     bzero<2>(acc);
     bgemm<2, 0, PRE, DXPF>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[1], 16, 0, wn * 2, lane, &pre);
-    if (LATE) bpend_flush(pend, wn);   // dfeat
     __syncthreads();
     ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, 7) + tile * 4096);
     if (PRE) bprefetch<2>(pre, pkt + boff.off[2], 16, 0, wn * 2, lane);
-    bepi256<false, false, true, true, false, true, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
+    bepi256<false, false, true, true, false, true>(acc, ea, Hhi, Hlo, wn, lane);
     __syncthreads();
     // ---- dY_{l-1} = (dY_l . W_l[:, h part]) * [h_{l-1} > 0],  l = 7..1 ---------------------------------
 #pragma unroll 1
@@ -1189,14 +1006,12 @@ mlp_bwd_dx_bf16_kernel(int64_t P, const float* __restrict__ draw, const uint4* _
       bepi256_preload<false, true, false>(ea, wn, lane);
       bzero<2>(acc);
       bgemm<2, 0, PRE, DXPF>(acc, Hhi, Hlo, 0, 16, pkt + boff.off[9 - l], 16, 0, wn * 2, lane, &pre);
-      if (LATE) bpend_flush(pend, wn);   // dY_l
       __syncthreads();
       ea.gsave = reinterpret_cast<uint2*>(dact + bd_y(nt_lay, l - 1) + tile * 4096);
       if (PRE && l > 1) bprefetch<2>(pre, pkt + boff.off[10 - l], 16, 0, wn * 2, lane);
-      bepi256<false, false, true, false, false, true, LATE>(acc, ea, Hhi, Hlo, wn, lane, pend);
+      bepi256<false, false, true, false, false, true>(acc, ea, Hhi, Hlo, wn, lane);
       if (l > 1) __syncthreads();
     }
-    if (LATE) bpend_flush(pend, wn);     // dY_0: nothing follows in this tile
     tile = b_next_tile(sched, sched_word, tid);   // (contains the tile's closing barrier)
   }
   b_sched_exit(sched, tid);
@@ -1337,9 +1152,7 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
   if (t1 > ntiles) t1 = ntiles;
   // a workgroup without tiles (short live lists: 390 tiles leave 61 of 256 idle) writes nothing: breduce_kernel sums the
   // partials of the first ceil(ntiles / per) workgroups only
-#if DW_SKIP_IDLE
   if (t0 >= ntiles) return;
-#endif
 
   f32x16 acc[TO][TI];
 #pragma unroll
@@ -1365,15 +1178,10 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
       const int p = i * NW + wave;
       if (NPIECE % NW == 0 || p < NPIECE) {
         const int ct = p >> 1, half = p & 1;
-#ifdef DW_ABL_CONTIG   // timing-only ablation: a k-step's operand tiles contiguous in memory (16 KiB runs instead of 2 KiB at 8 KiB stride)
-        const uint4* src = (ct < CTO) ? dY + ((tile * 4 + ks) * CTO + ct) * 128 + half * 64 + lane
-                                      : X + ((tile * 4 + ks) * CTI + (ct - CTO)) * 128 + half * 64 + lane;
-#else
         const uint4* src = (ct < CTO) ? dY + ((tile * CTO + ct) * 4 + ks) * 128 + half * 64 + lane
                                       : X + ((tile * CTI + (ct - CTO)) * 4 + ks) * 128 + half * 64 + lane;
-#endif
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, DW_AUX);
+                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 2);
       }
     }
   };
@@ -1386,7 +1194,7 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
       else if (n == 2) { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PPW - 1)) : "memory"); }
       else { if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (PPW - 1)) : "memory"); }
     };
-    static_assert(DW_NST <= 5 && 3 * PPW < 64, "wait_stages counts up to three stages in flight (vmcnt is 6 bits)");
+    static_assert(3 <= 5 && 3 * PPW < 64, "wait_stages counts up to three stages in flight (vmcnt is 6 bits)");
     // `newer` stages were issued after the one that has to be complete: let min(newer, cap) of them stay in flight
     auto wait_newer = [&](int64_t newer, int cap) __attribute__((always_inline)) {
       if (newer >= cap) wait_stages(cap);
@@ -1394,52 +1202,9 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
       else if (newer == 1) wait_stages(1);
       else wait_stages(0);
     };
-#if DW_PIPE
-    // Software pipeline: the fragment reads of k-step q+1 are issued before the MFMAs of k-step q and waited for after
-    // them, so the matrix pipe does not idle for the LDS round trip every k-step.  The ring is one stage deeper than the
-    // plain loop's for the same DMA lead: stage q+2 has to be complete at the END of k-step q.
-    //   k-step q:  reads(q+1) -> set B | DMA(q+NST-1) -> stage (q-1) % NST | MFMAs(q) from set A | wait B | wait DMA(q+2) | barrier
-    // stage q-1 is free at k-step q: its reads were waited for before the barrier that ended k-step q-2.
-    static_assert(DW_NST >= 4, "DW_PIPE needs a ring of >= 4 stages");
 #pragma unroll
-    for (int i = 0; i < DW_NST - 1; ++i) dma_stage(i, i);
-    const uint4* ring = reinterpret_cast<const uint4*>(dsm);
-    DwFrag<TO, TI> fa, fb;
-    wait_stages(DW_NST - 2);   // stage 0 landed (own pieces)
-    __builtin_amdgcn_s_barrier();
-    dw_issue_reads<WO, WI, TO, TI>(fa, ring, wo, wi, lane);
-    wait_stages(DW_NST - 3);   // stage 1
-    dw_wait_reads<TO, TI>(fa);
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;               // stage of k-step q
-    auto kstep = [&](int64_t q, DwFrag<TO, TI>& cur, DwFrag<TO, TI>& nxt) __attribute__((always_inline)) {
-      float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
-      if (RANK1 && wo == (wi + 1) % WO) {   // before the DMA issue: its wait must not drain the newest stage
-        const float4* dp = reinterpret_cast<const float4*>(dalpha + (t0 + (q >> 2)) * 64 + (q & 3) * 16 + (lane >> 5) * 8);
-        d0 = dp[0]; d1 = dp[1];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      const int b1 = (buf == DW_NST - 1) ? 0 : buf + 1;
-      const int bn = (buf >= 1) ? buf - 1 : DW_NST - 1;
-      if (q + 1 < nq) dw_issue_reads<WO, WI, TO, TI>(nxt, ring + b1 * STAGE_U4, wo, wi, lane);
-      if (q + DW_NST - 1 < nq) dma_stage(q + DW_NST - 1, bn);
-      dw_mfma<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, cur, wo, wi, d0, d1);
-      dw_wait_reads<TO, TI>(nxt);
-      const int64_t newer = (nq - 1 - (q + 2));   // stages issued after q+2 (clamped)
-      wait_newer(newer, DW_NST - 3);
-      __builtin_amdgcn_s_barrier();
-      buf = b1;
-    };
-#pragma unroll 1
-    for (int64_t q = 0; q < nq; q += 2) {   // nq is even: the register sets swap roles by unrolling
-      kstep(q, fa, fb);
-      kstep(q + 1, fb, fa);
-    }
-  }
-#else
-#pragma unroll
-    for (int i = 0; i < DW_NST - 1; ++i) dma_stage(i, i);
-    wait_stages(DW_NST - 2);   // stage 0 landed (own pieces)
+    for (int i = 0; i < 3 - 1; ++i) dma_stage(i, i);
+    wait_stages(3 - 2);   // stage 0 landed (own pieces)
     __builtin_amdgcn_s_barrier();
     int buf = 0;
 #pragma unroll 1
@@ -1450,30 +1215,17 @@ mlp_bwd_dw_lds_bf16_kernel(int64_t P, int64_t ntiles, const uint4* __restrict__ 
         d0 = dp[0]; d1 = dp[1];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      const int bn = (buf >= 1) ? buf - 1 : DW_NST - 1;   // (buf + DW_NST - 1) % DW_NST: the stage consumed at step q-1
-#ifdef DW_ABL_NODMA   // timing-only ablation: no operand DMA after the prologue (what do issue + HBM cost the loop?)
-      const int64_t qn = nq;
-#else
-      const int64_t qn = q + DW_NST - 1;
-#endif
-#if DW_DMA_LATE
+      const int bn = (buf >= 1) ? buf - 1 : 3 - 1;   // (buf + DW_NST - 1) % DW_NST: the stage consumed at step q-1
+      const int64_t qn = q + 3 - 1;
       dw_stage_compute<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, reinterpret_cast<const uint4*>(dsm) + buf * STAGE_U4, wo, wi,
                                                     lane, d0, d1, [&]() __attribute__((always_inline)) { if (qn < nq) dma_stage(qn, bn); });
-#else
-      if (qn < nq) dma_stage(qn, bn);
-      dw_stage_compute<WO, WI, TO, TI, BIAS, RANK1>(acc, bsum, rsum, reinterpret_cast<const uint4*>(dsm) + buf * STAGE_U4, wo, wi,
-                                                    lane, d0, d1, []() {});
-#endif
       // stage q+1 must have landed; the newer ones may stay in flight
       const int64_t newer = (nq - 1 - (q + 1));   // stages issued after q+1 (clamped below)
-      wait_newer(newer, DW_NST - 2);
-#ifndef DW_ABL_NOBAR   // timing-only ablation (with DW_ABL_NODMA): how much does the per-k-step lockstep of the waves cost?
+      wait_newer(newer, 3 - 2);
       __builtin_amdgcn_s_barrier();
-#endif
-      buf = (buf == DW_NST - 1) ? 0 : buf + 1;
+      buf = (buf == 3 - 1) ? 0 : buf + 1;
     }
   }
-#endif
   float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
 #pragma unroll
   for (int i = 0; i < TO; ++i)
@@ -1553,13 +1305,11 @@ __host__ __device__ inline int b_unperm(int q) { return (q & ~63) + 2 * (q & 31)
 __global__ void __launch_bounds__(256) breduce_kernel(BRedTable tab, const float* __restrict__ partial,
                                                        float* __restrict__ grads, int64_t ntiles, const int* __restrict__ live_cnt) {
   BRedSeg sg = tab.s[blockIdx.y];
-#if DW_SKIP_IDLE
   if (sg.dw) {   // the dW workgroups that had tiles: the first ceil(ntiles / per), per = ceil(ntiles / nwg) (mlp_bwd_dw_lds_bf16_kernel)
     if (live_cnt) ntiles = ((int64_t)*live_cnt + BTM - 1) / BTM;
     const int64_t per = (ntiles + sg.nwg - 1) / sg.nwg;
     sg.nwg = per > 0 ? (int)((ntiles + per - 1) / per) : 0;
   }
-#endif
   const int64_t total = (int64_t)sg.rows * sg.cols;
   const float* src = partial + sg.src;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1615,7 +1365,7 @@ static int b_launch_dw(int64_t P, int64_t ntiles, const uint4* dY, int CTo, cons
   float* pb = base + (int64_t)nwg * NO * KI;
   float* pr = pb + (BIAS ? (int64_t)nwg * NO : 0);
   FN_CHECK_ARG(CTo == WO * TO && CTi == WI * TI, "dW job shape");
-  constexpr int lds = DW_NST * (WO * TO + WI * TI) * 128 * 16;
+  constexpr int lds = 3 * (WO * TO + WI * TI) * 128 * 16;
   auto kern = mlp_bwd_dw_lds_bf16_kernel<WO, WI, TO, TI, BIAS, RANK1>;
   static bool attr = false;
   if (!attr) {
@@ -1646,9 +1396,6 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
   const uint4* act = reinterpret_cast<const uint4*>(act_f);
   uint4* dact = reinterpret_cast<uint4*>(dact_f);
   int grid = ncu * 2;
-#ifdef BF_EXPERIMENT
-  if (getenv("FASTNERF_DX_WGS")) grid = atoi(getenv("FASTNERF_DX_WGS"));
-#endif
   if (nt < grid) grid = (int)nt;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1663,9 +1410,6 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
   FN_LAUNCH_CHECK();
 
   int nwg = ncu;
-#ifdef BF_EXPERIMENT
-  if (getenv("FASTNERF_DW_WGS")) nwg = atoi(getenv("FASTNERF_DW_WGS"));
-#endif
   // (always one workgroup per CU, also for batches of fewer tiles -- idle workgroups write zero partials: the order in
   // which the partial sums meet is then a function of the tile count alone, which makes the live-list backward bit-identical
   // to the plain backward of the same points)
@@ -1691,7 +1435,7 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
   segs(0, L.LW[0], L.in_pe, L.in_pe, 1, L.LB[0], 0);
   // L1..L7 (h part)
   for (int l = 1; l < 8; ++l) {
-    if ((rc = b_launch_dw<DW_CFG, true, false>(P, nt, dact + bd_y(nt, l), 8, act + ba_h(nt, l - 1), 8, nullptr, region(l), nwg, st, live_cnt))) return rc;
+    if ((rc = b_launch_dw<4, 2, 2, 4, true, false>(P, nt, dact + bd_y(nt, l), 8, act + ba_h(nt, l - 1), 8, nullptr, region(l), nwg, st, live_cnt))) return rc;
     segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, 3, L.LB[l], 0);
   }
   // L5 pe part
@@ -1700,7 +1444,7 @@ static int b_bwd_launch(int kind, int64_t n, int S, const float* draw, const flo
   if (rc) return rc;
   segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 1, 0, 0);
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
-  if ((rc = b_launch_dw<DW_CFG, true, true>(P, nt, dact + bd_feat(nt), 8, act + ba_h(nt, 7), 8,
+  if ((rc = b_launch_dw<4, 2, 2, 4, true, true>(P, nt, dact + bd_feat(nt), 8, act + ba_h(nt, 7), 8,
                                                  reinterpret_cast<const float*>(dact + bd_alpha(nt)), region(9), nwg, st, live_cnt))) return rc;
   segs(9, L.FW, 256, 256, 3, L.FB, L.AW);
   // view layer

@@ -59,9 +59,6 @@ inline __host__ __device__ int64_t act_vpe(int64_t P, int pe_pad) { return P * (
 inline __host__ __device__ int64_t act_hv(int64_t P, int pe_pad) { return P * (pe_pad + 2048 + 256 + 32); }
 inline __host__ __device__ int64_t act_mask(int64_t P, int pe_pad) { return P * (pe_pad + ACT_REST); }  // uint64 words
 inline int64_t act_floats(int64_t P, int pe_pad) { return P * (pe_pad + ACT_REST + ACT_MASK) + 8192; }
-// f16x3 with X6_DW_H3: the last 32 floats of the slack hold the maxima of the pass's saved tensors (uint views): pe | h0 .. h7 | feat | 1.0
-// (the sign words of a ragged last tile end at most 4032 floats into the 8192)
-inline __host__ __device__ int64_t act_xmax(int64_t P, int pe_pad) { return P * (pe_pad + ACT_REST + ACT_MASK) + 8192 - 32; }
 // ---- pre-activation gradients, SoA ----
 constexpr int DACT_FLOATS = 8 * 256 + 256 + 128;
 inline __host__ __device__ int64_t dact_y(int64_t P, int l) { return (int64_t)l * P * 256; }

@@ -1,0 +1,19 @@
+#!/bin/bash
+# runs ON THE GPU BOX: the whole GPU suite while the box's idle host cores extend the CPU PSNR ensemble G22 (one thread per seed);
+# usage: tools/gpu_suite_with_g22.sh FIRST_SEED N_WORKERS [pytest args]
+first=$1; n=$2; shift 2
+mkdir -p gpurun_out/g22_parts
+free -g | head -2 > gpurun_out/box_mem.txt; nproc >> gpurun_out/box_mem.txt
+pids=()
+for ((w = 0; w < n; w++)); do
+  s=$((first + w))
+  G22_THREADS=1 OMP_NUM_THREADS=1 MKL_NUM_THREADS=1 nice -n 10 python -m oracle.make_golden_psnr_ensemble --parts gpurun_out/g22_parts --seeds $s $((s + 1)) \
+    > gpurun_out/g22_parts/w_$s.log 2>&1 &
+  pids+=($!)
+done
+python -m pytest tests -m gpu -q "$@" > gpurun_out/gputest.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/gputest.log
+tail -5 gpurun_out/gputest.log
+t0=$(date +%s)
+for p in "${pids[@]}"; do wait $p; done
+echo "waited $(( $(date +%s) - t0 )) s more for the ensemble workers; parts: $(ls gpurun_out/g22_parts/*.json 2>/dev/null | wc -l)"
