@@ -9,7 +9,7 @@ sampling -> PE -> coarse / fine MLP -> compositing -> 2 x MSE + per-(image, leaf
 far 6; every batch = 4096 rays drawn uniformly from all 64 M pixels, targets U[0,1)^3 (values do not affect timing), nets at
 their default initialisation (seed 0), perturb = 1, white background, leaf tags of a depth-5 quadtree; fp32-WIDTH arithmetic
 and the PLAIN backward (every sample goes through loss.backward(); FASTNERF_COMPACT is forced to 0 for this leg).  Inputs are
-resident in HBM before the timed region.  The arithmetic is the `bf16x6` mode of csrc/mlp.hip: every fp32 operand decomposed
+resident in HBM before the timed region.  The arithmetic is the `bf16x6` mode of csrc/mlp_*.hip: every fp32 operand decomposed
 EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits), every product the sum of its six piece products of weight >= 2^-16
 with fp32 accumulation on v_mfma_f32_32x32x16_bf16 -- the dropped terms are <= 2^-24 of the product, fp32's own rounding; measured
 against fp64 its logits / head-layer gradients are as close as the fp32-MFMA kernels' (tests/test_gpu_mlp.py::

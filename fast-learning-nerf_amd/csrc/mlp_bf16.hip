@@ -4,10 +4,10 @@
 // a*b is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation on v_mfma_f32_32x32x16_bf16 (three
 // 32-cycle K=16 instructions instead of eight 64-cycle K=2 fp32 instructions: 5.3x the matrix rate).  The
 // dropped lo*lo term and the residual of the two-term split are ~2^-17 relative per product; measured against
-// the fp32-MFMA kernels of mlp.hip this moves raw network outputs by ~1e-6 relative and the rendered RGB by
+// the fp32-MFMA kernels of mlp_fwd / mlp_bwd_*.hip this moves raw network outputs by ~1e-6 relative and the rendered RGB by
 // 5e-7 (tools/bf16x3_study.py), i.e. fp32 rounding class -- two orders below the 1e-4 parity tolerance.
 //
-// Same network functions as mlp.hip (nerf-ours/model.py:37-63, nerf++-ours/nerf_network.py:70-142); kinds 0/1 and the
+// Same network functions as mlp_fwd.hip (nerf-ours/model.py:37-63, nerf++-ours/nerf_network.py:70-142); kinds 0/1 and the
 // nerf++ background net (kind 2: 4-D inverted-sphere input, 84-channel encoding).
 //
 // Tiling: 64-point tiles, two 256-thread workgroups per CU, wave = 64x64 output block (2x2 MFMA tiles).
@@ -534,7 +534,7 @@ __device__ __forceinline__ void bepi128(const f32x16 (&acc)[2][1], const EpiArgs
 // =========================================================================================
 // forward
 // =========================================================================================
-// inverted-sphere background point (x', y', z', 1/r) of nerf++ (ddp_model.py:16-45); same arithmetic as mlp.hip
+// inverted-sphere background point (x', y', z', 1/r) of nerf++ (ddp_model.py:16-45); same arithmetic as mlp_fwd.hip
 __device__ __forceinline__ void b_bg_point(const float* __restrict__ o, const float* __restrict__ d, float depth, float x[4]) {
   const float dd = fadd(fadd(fmul(d[0], d[0]), fmul(d[1], d[1])), fmul(d[2], d[2]));
   const float od = fadd(fadd(fmul(d[0], o[0]), fmul(d[1], o[1])), fmul(d[2], o[2]));

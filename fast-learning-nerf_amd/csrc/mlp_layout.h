@@ -51,7 +51,7 @@ inline NetLayout make_layout(int kind) {
 
 // ---- saved activations, SoA over P points: pe | h0..h7 | feat | vpe32 | hv128 | ReLU sign words ----
 constexpr int ACT_REST = 8 * 256 + 256 + 32 + 128;   // 2464 floats per point after the pe block
-constexpr int ACT_MASK = 64;                         // 256 bytes of sign words per point (one 64-bit word per lane, layer and wave: mlp.hip epilogue_fwd)
+constexpr int ACT_MASK = 64;                         // 256 bytes of sign words per point (one 64-bit word per lane, layer and wave: mlp_common.h epilogue_fwd)
 inline __host__ __device__ int64_t act_pe(int64_t P, int pe_pad) { return 0; }
 inline __host__ __device__ int64_t act_h(int64_t P, int pe_pad, int l) { return P * pe_pad + (int64_t)l * P * 256; }
 inline __host__ __device__ int64_t act_feat(int64_t P, int pe_pad) { return P * (pe_pad + 2048); }

@@ -1,4 +1,4 @@
-// sched.h -- dynamic tile scheduling shared by the persistent forward / dX kernels of mlp.hip and mlp_bf16.hip.
+// sched.h -- dynamic tile scheduling shared by the persistent forward / dX kernels of mlp_fwd / mlp_bwd_*.hip and mlp_bf16.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <mutex>

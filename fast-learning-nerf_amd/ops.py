@@ -19,14 +19,14 @@ DACT_FLOATS = 2432
 
 
 # ---- matrix-core math mode of the 8x256 MLP kernels ---------------------------------------------
-# 'fp32'   : v_mfma_f32_32x32x2_f32 (csrc/mlp.hip), every kind: the products and sums of an fp32 FMA chain
-# 'bf16x6' : csrc/mlp.hip MM_X6 -- every fp32 operand decomposed EXACTLY into three bf16 pieces, a product = its six piece
+# 'fp32'   : v_mfma_f32_32x32x2_f32 (csrc/mlp_*.hip), every kind: the products and sums of an fp32 FMA chain
+# 'bf16x6' : csrc/mlp_*.hip MM_X6 -- every fp32 operand decomposed EXACTLY into three bf16 pieces, a product = its six piece
 #            products of weight >= 2^-16, fp32 accumulation on v_mfma_f32_32x32x16_bf16: fp32-WIDTH products (the dropped terms
 #            are <= 2^-24 of the product) at 2.67x the matrix rate of the fp32 instruction; same buffers as 'fp32' except the
 #            packed weights (three bf16 planes)
 # 'bf16x3' : 3-term split-bf16 (two pieces, 16 significand bits) on the same instruction (csrc/mlp_bf16.hip): NARROWER than
 #            fp32 (products ~2^-17 relative), ~2.5x the rate of 'fp32'; rendered RGB still within 1e-6 of the fp32 kernels
-# 'f16x3'  : csrc/mlp.hip MM_H3 -- the forward and dX products of 'bf16x6' on TWO fp16 pieces with a scaled residual
+# 'f16x3'  : csrc/mlp_*.hip MM_H3 -- the forward and dX products of 'bf16x6' on TWO fp16 pieces with a scaled residual
 #            (x = h + 2^-12 l', both rounded to nearest: <= 2^-23 relative, rms 2^-24.4 -- one bit short of fp32) and THREE products with fp32
 #            accumulation; dW as 'bf16x6'.  Logits as close to fp64 as the 'fp32' kernels' (accumulation dominates) at half the matrix work (profiles/r04_f16x3_study.md);
 #            fp16's RANGE applies: weights and activations must stay below 65504 in magnitude (they do on this path)

@@ -315,7 +315,7 @@ int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N
                                   float* draw_ws, float* act_ws, float* dact_ws, float* partial_ws, int32_t* live_ws,
                                   float* grads_c, float* grads_f, int32_t* counts_out, fn_stream_t stream);
 
-/* ---- "bf16x6" math mode: fp32-WIDTH products on the bf16 matrix cores (csrc/mlp.hip, MM_X6) -------------------------------
+/* ---- "bf16x6" math mode: fp32-WIDTH products on the bf16 matrix cores (csrc/mlp_*.hip, MM_X6) -------------------------------
  * Same network functions and call protocol as fastnerf_mlp_pack_ex / fwd_ex / fwd_flags_ex / bwd_ex / fwd_live_ex / bwd_live_ex
  * (run_nerf.py:50-64 run_network -> model.py:37-63, autograd backward of the same).  Every fp32 operand is decomposed EXACTLY
  * into three bf16 pieces (8 + 8 + 8 significand bits) and a product is the sum of the six piece products whose weight is
@@ -325,9 +325,9 @@ int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N
  * n*S*FASTNERF_DACT_FLOATS, fastnerf_mlp_bwd_partial_floats).  fwd: act == NULL -> inference, flags as
  * fastnerf_mlp_fwd_flags_ex (ignored when act != NULL). */
 /* The arithmetic behind the fastnerf_mlp_x6_* entry points (and math_mode 2 of the fused ones), process-wide.  0 (default): bf16x6 as
- * described above.  1: "f16x3" (csrc/mlp.hip, MM_H3) -- the forward and dX products on TWO fp16 pieces with a scaled residual,
+ * described above.  1: "f16x3" (csrc/mlp_*.hip, MM_H3) -- the forward and dX products on TWO fp16 pieces with a scaled residual,
  * x = h + 2^-12 l' with h = fp16(x), l' = fp16((x - h) 2^12), both rounded to nearest (|x - h - 2^-12 l'| <= 2^-23 |x|, rms 2^-24.4: one bit short of fp32), THREE products with fp32
- * accumulation (the cross terms in their own accumulators); dW unchanged (a build with -DX6_DW_H3=1 runs the dW jobs of the plain kind-0 backward on two fp16 pieces as well, each tensor scaled by a power of two taken from its measured maximum: faster, but the gradient then depends in its last bits on points whose own gradient is zero -- off by default).  Measured against fp64 the logits are as close as the exact-fp32 kernels' (fp32 accumulation dominates) at half the matrix work; fp16's
+ * accumulation (the cross terms in their own accumulators); dW unchanged.  fp16's
  * range applies: |weights|, |activations| < 65504.  Same buffer sizes; weights packed under one arithmetic are garbage to the other --
  * call fastnerf_mlp_x6_pack again after a change.  Returns the previous setting; any other argument only queries.  Replaces nothing in
  * the reference (which has one arithmetic, torch fp32: nerf-ours/model.py:38-63). */

@@ -407,7 +407,7 @@ def test_tile_scheduler_back_to_back_and_streams(fn, weights):
 
 
 def test_bf16x6_decomposition_is_exact_and_products_have_fp32_width(fn, weights):
-    """The bf16x6 mode's claim (csrc/mlp.hip, MM_X6): every fp32 operand is decomposed EXACTLY into three bf16 pieces, so a product
+    """The bf16x6 mode's claim (csrc/mlp_*.hip, MM_X6): every fp32 operand is decomposed EXACTLY into three bf16 pieces, so a product
     evaluated from the six leading piece products is as accurate as fp32's own rounding of it.
     (a) the packed weight planes of every layer sum back to the fp32 weights bit for bit (h + m + l in fp64, rounded to fp32);
     (b) against an fp64 evaluation of the network on the same fp32 inputs, the logits of the bf16x6 kernels are as close as the
@@ -428,7 +428,7 @@ def test_bf16x6_decomposition_is_exact_and_products_have_fp32_width(fn, weights)
             w = weights[name].numpy()
             N = w.shape[0]
             kp = 64 if l == 0 else (320 if l == 5 else (288 if l == 9 else 256))
-            # fragment order of v_mfma_f32_16x16x32_bf16 (csrc/mlp.hip, X6_SHAPE16): column tiles of 16, k-steps of 32
+            # fragment order of v_mfma_f32_16x16x32_bf16 (csrc/mlp_*.hip): column tiles of 16, k-steps of 32
             n_u4 = (N // 16) * (kp // 32) * 3 * 64
             blk = u16[off * 8:(off + n_u4) * 8].reshape(N // 16, kp // 32, 3, 64, 8)
             tot = bf(blk[:, :, 0]) + bf(blk[:, :, 1]) + bf(blk[:, :, 2])          # [tile][ks][lane][8]
@@ -470,7 +470,7 @@ def test_bf16x6_decomposition_is_exact_and_products_have_fp32_width(fn, weights)
 
 
 def test_f16x3_split_is_one_bit_short_of_fp32(fn, weights):
-    """The f16x3 mode's claim (csrc/mlp.hip, MM_H3): x = h + 2^-12 l' with h = fp16(x) and l' = fp16((x - h) 2^12), both rounded to
+    """The f16x3 mode's claim (csrc/mlp_*.hip, MM_H3): x = h + 2^-12 l' with h = fp16(x) and l' = fp16((x - h) 2^12), both rounded to
     nearest, represents an fp32 operand to 2^-23 relative (one bit short of fp32's unit roundoff; most values exactly).  The packed weight planes (h | l' | zero, the
     fragment order of the bf16x6 packing) decode to the fp32 weights within that bound, bit-exactly for most; switching the
     arithmetic re-tags the buffers (packed bf16x6 weights are refused under f16x3 and vice versa)."""

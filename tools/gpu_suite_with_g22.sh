@@ -11,6 +11,13 @@ for ((w = 0; w < n; w++)); do
     > gpurun_out/g22_parts/w_$s.log 2>&1 &
   pids+=($!)
 done
+if [ -n "$G23_SEEDS" ]; then    # the longer horizon (G23): 1000 iterations, 4 threads per seed
+  for s in $G23_SEEDS; do
+    G22_THREADS=4 OMP_NUM_THREADS=4 MKL_NUM_THREADS=4 nice -n 10 python -m oracle.make_golden_psnr_ensemble --long --parts gpurun_out/g22_parts --seeds $s $((s + 1)) \
+      > gpurun_out/g22_parts/wl_$s.log 2>&1 &
+    pids+=($!)
+  done
+fi
 python -m pytest tests -m gpu -q "$@" > gpurun_out/gputest.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/gputest.log
 tail -5 gpurun_out/gputest.log
