@@ -11,14 +11,12 @@ their default initialisation (seed 0), perturb = 1, white background, leaf tags 
 and the PLAIN backward (every sample goes through loss.backward(); FASTNERF_COMPACT is forced to 0 for this leg).  Inputs are
 resident in HBM before the timed region.  The arithmetic is the `bf16x6` mode of csrc/mlp_*.hip: every fp32 operand decomposed
 EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits), every product the sum of its six piece products of weight >= 2^-16
-with fp32 accumulation on v_mfma_f32_32x32x16_bf16 -- the dropped terms are <= 2^-24 of the product, fp32's own rounding; measured
+with fp32 accumulation on v_mfma_f32_16x16x32_bf16 -- the dropped terms are <= 2^-24 of the product, fp32's own rounding; measured
 against fp64 its logits / head-layer gradients are as close as the fp32-MFMA kernels' (tests/test_gpu_mlp.py::
 test_bf16x6_decomposition_is_exact_and_products_have_fp32_width, profiles/r03_precision_vs_fp64.md).
 
 Everything else rides in the same JSON line as named sibling blocks and never feeds `value`:
   fp32_mfma_mode     the same protocol on v_mfma_f32_32x32x2_f32 (an fp32 FMA chain bit for bit; 157 TFLOP/s ceiling);
-  f16x3_mode         the same protocol with the forward / dX products on two fp16 pieces + scaled residual (three products; operands one bit
-                     short of fp32, logits vs fp64 as close as fp32's): the faster arithmetic, offered beside the headline, never `value`;
   split_bf16_mode    the same protocol in the split-bf16 mode (3 bf16 MFMA products per fp32 product, 16-bit operands: faster and
                      NARROWER than fp32, hence not the headline), plus that mode on a trained sparse scene with the exact
                      zero-gradient compaction (what a converged Lego-like field looks like to the backward);
@@ -69,7 +67,6 @@ PROFILE_ROUND = 'r05'
 MAIN_MODE = 'bf16x6'                        # the headline's arithmetic: fp32-width products on the bf16 matrix cores (docstring)
 MODE_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 1.0, 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'mlp_fwd_kernel', ', 0'),
              'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6.0, 6.0, 'dense bf16 MFMA 2500 TFLOP/s / 6 piece products per fp32 product', 'mlp_fwd_kernel', ', 1'),
-             'f16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 3.0, 'dense fp16 MFMA 2500 TFLOP/s / 3 piece products per fp32 product (forward and dX; the dW launches of this mode are bf16x6\'s)', 'mlp_fwd_kernel', ', 2'),
              'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 3.0, 'dense bf16 MFMA 2500 TFLOP/s / 3 split terms per product', 'mlp_fwd_bf16_kernel', '')}
 H = W = 800
 FOCAL = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
@@ -814,7 +811,7 @@ def main():
             inf[mode] = {'value': n_inf / dt_i, 'unit': 'rays/s', 'ms_per_call': 1e3 * dt_i}
         return inf
 
-    split_block = fp32_block = f16_block = drop_in = infer = psnr_block = cfg_blocks = main_sparse = None
+    split_block = fp32_block = drop_in = infer = psnr_block = cfg_blocks = main_sparse = None
     kte_b = kte_32 = None
     dd = None
     if siblings:
@@ -824,13 +821,6 @@ def main():
             fp32_block, _, kte_32 = r_
             fp32_block['init_state']['step_frac_of_fp32_mfma_peak'] = (fp32_block['init_state']['value'] * TRAIN_FLOP_PER_RAY / 1e12
                                                                        / FP32_MFMA_PEAK_TFLOPS)
-        r_ = guarded('f16x3_mode', lambda: mode_leg(
-            'f16x3', dtype='f16x3: forward and dX products as Ah*Wh + 2^-12 (Ah*Wl + Al*Wh) on the fp16 matrix cores (v_mfma_f32_16x16x32_f16), '
-                           'x = h + 2^-12 l with two roundings to nearest: operands to 2^-23 relative (ONE BIT short of fp32), fp32 accumulation; '
-                           'dW as bf16x6.  A sibling because its operands are not bit-for-bit fp32-wide and fp16 has a range limit (guarded: '
-                           'DESIGN 4)'))
-        if r_ is not None:
-            f16_block = r_[0]
         r_ = guarded('split_bf16_mode', lambda: mode_leg(
             'bf16x3', dtype='split-bf16 x3: every fp32 product as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation; '
                             'operands carry 16 significand bits -- NARROWER than fp32, hence a sibling'))
@@ -958,7 +948,7 @@ def main():
             return None if blk is None else round(blk['init_state']['ms_per_step'], 3)
         summary = None
         if siblings:
-            summary = {'ms_per_step': {'fp32': ms_of(fp32_block), 'f16x3': ms_of(f16_block), 'bf16x3': ms_of(split_block),
+            summary = {'ms_per_step': {'fp32': ms_of(fp32_block), 'bf16x3': ms_of(split_block),
                                        'drop_in_' + MAIN_MODE: None if drop_in is None else round(drop_in[MAIN_MODE]['ms_per_step'], 3)},
                        'sparse_scene_' + MAIN_MODE: None if main_sparse is None else {
                            'ms_per_step': round(main_sparse['ms_per_step'], 3), 'rays_per_s': round(main_sparse['value']),
@@ -990,7 +980,6 @@ def main():
             'psnr': psnr_head,
             'psnr_vs_cpu': psnr_block,
             'fp32_mfma_mode': fp32_block,
-            'f16x3_mode': f16_block,
             'split_bf16_mode': split_block,
             MAIN_MODE + '_sparse_scene': main_sparse,
             'drop_in_route': drop_in,

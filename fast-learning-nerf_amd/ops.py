@@ -2,6 +2,7 @@
 
 PyTorch is plumbing here: it owns device memory and the stream; every op calls
 straight into libfastnerf.so with raw pointers.  No op has a CPU fallback."""
+import os
 import weakref
 
 import numpy as np
@@ -46,6 +47,11 @@ def set_math(mode):
     next packed() call; do not mix buffers produced under different modes."""
     global _MATH
     assert mode in MATH_MODES
+    if mode == 'f16x3' and os.environ.get('FASTNERF_EXPERIMENTAL_F16X3') != '1':
+        # PARKED (round 5, DESIGN section 4): fp16 pieces overflow at 65504 and the dX kernel keeps gradients x 2^14 in LDS; nothing detects an
+        # overflow / flush or falls back, so the mode is a measured research sibling (1.2x the bf16x6 step rate), not something to train with
+        raise RuntimeError("math mode 'f16x3' is an UNGUARDED experimental arithmetic (fp16 range: |w|, |h| < 65504, |dY| < 4; no overflow "
+                           "detection); set FASTNERF_EXPERIMENTAL_F16X3=1 to use it knowingly.  The fp32-width default is 'bf16x6'.")
     _MATH = mode
     _sync_arith()
 

@@ -1,6 +1,8 @@
 #!/bin/bash
-# (build container only: needs /root/reference)  Regenerate EVERY fixture of tests/golden/ from the reference into a scratch
-# directory and compare with the committed files: arrays bit for bit (npz members), other files byte for byte.
+# (build container only: needs /root/reference)  Regenerate EVERY reference-derived fixture of tests/golden/ from the reference into a
+# scratch directory and compare with the committed files: arrays bit for bit (npz members), other files byte for byte.  The two PSNR
+# ensembles (G22, G23) are recorded from the ORACLE, not from the reference (hours of host time; free runs are chaotic): for those, K
+# recorded seeds are re-run with the recorded thread count and compared at 1e-3 dB (G22_CHECK_SEEDS, default 2; 0 skips).
 set -e
 cd "$(dirname "$0")/.."
 D=$(mktemp -d /tmp/goldens.XXXXXX)
@@ -14,7 +16,8 @@ import os, sys
 import numpy as np
 new, old = sys.argv[1], 'tests/golden'
 bad = 0
-names = sorted(f for f in os.listdir(old) if not f.startswith('.'))
+ORACLE_RECORDED = ('g22_psnr_cpu_ensemble.npz', 'g23_psnr_cpu_long.npz')     # checked by make_golden_psnr_ensemble --check below
+names = sorted(f for f in os.listdir(old) if not f.startswith('.') and f not in ORACLE_RECORDED)
 for f in names:
     a, b = os.path.join(old, f), os.path.join(new, f)
     if not os.path.exists(b):
@@ -30,3 +33,9 @@ for f in names:
 print(f'{len(names) - bad} of {len(names)} fixtures reproduce bit for bit')
 sys.exit(1 if bad else 0)
 PY
+K=${G22_CHECK_SEEDS:-2}
+if [ "$K" != "0" ]; then
+  unset FASTNERF_GOLDEN_OUT
+  G22_THREADS=8 python -m oracle.make_golden_psnr_ensemble --check "$K" || { echo "G22: recorded seeds do not reproduce"; exit 1; }
+  echo "G22: $K recorded seeds reproduce at 1e-3 dB"
+fi

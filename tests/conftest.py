@@ -1,4 +1,6 @@
 import os
+
+os.environ.setdefault('FASTNERF_EXPERIMENTAL_F16X3', '1')   # the parked f16x3 mode stays under test (ops.set_math refuses it otherwise)
 import sys
 
 import pytest

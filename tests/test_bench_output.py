@@ -37,7 +37,7 @@ def _worst_case_record(world=8):
         'psnr': {'iters': 200, 'rays_per_iter': 256, 'gpu_train_db': 26.730632431504313, 'gpu_held_out_db': 27.787402617614918,
                  'cpu_train_db': 26.00215655553397, 'cpu_held_out_db': 27.55402213826612, 'lockstep_delta_db': -7.281735352293595e-05,
                  'lockstep_max_rel_loss_diff': 0.0004934942203400715, 'paired_ensemble': B.PAIRED_PSNR_NOTE},
-        'siblings_summary': {'ms_per_step': {'fp32': 30.713, 'f16x3': 15.321, 'bf16x3': 12.582, 'drop_in_bf16x6': 18.999},
+        'siblings_summary': {'ms_per_step': {'fp32': 30.713, 'bf16x3': 12.582, 'drop_in_bf16x6': 18.999},
                              'sparse_scene_bf16x6': {'ms_per_step': 9.123, 'rays_per_s': 449000, 'live_fine': 0.1821, 'plain_ms': 19.012},
                              'configs_rays_per_s': {'configs[2]': 230377, 'configs[3]': 289625, 'configs[4]': 102061},
                              'inference_rays_per_s': 777496},
@@ -63,7 +63,7 @@ def test_headline_is_short_and_complete():
         assert c['value'] == out['cpu_baseline']['value'] and c['cores'] == 32 and c['kind'] == 'port' and len(c['sample']) <= 200
         assert abs(h['vs_cpu_baseline'] - out['value'] / out['cpu_baseline']['value']) < 1e-9
         # the sibling blocks never ride in the line
-        for k in ('other_configs', 'psnr_vs_cpu', 'fp32_mfma_mode', 'split_bf16_mode', 'f16x3_mode', 'drop_in_route', 'inference'):
+        for k in ('other_configs', 'psnr_vs_cpu', 'fp32_mfma_mode', 'split_bf16_mode', 'drop_in_route', 'inference'):
             assert k not in h
 
 

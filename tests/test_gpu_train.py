@@ -213,37 +213,12 @@ def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
         fn.render.set_compact(old_c)
 
 
-def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
-    """north_star's "PSNR within 0.1 dB at equal iteration count" as a PAIRED two-sample test at the BASELINE shape (100 cameras of
-    800 x 800, 64 + 128 samples, 200 iterations of 256 uniformly drawn rays): tests/golden/g22_psnr_cpu_ensemble.npz holds the CPU
-    oracle's PSNR for initialisation seeds 0 .. n-1 (oracle/make_golden_psnr_ensemble.py, ~2.3 minutes of 8 host cores per seed,
-    recorded once in the build container); here the GPU starts from the SAME weights (oracle/psnr_protocol.py init_weights), sees the
-    SAME batches / t_rand / u (generated on the CPU from seeds, digest checked) and the statistic is the mean over seeds of
-    PSNR_gpu(s) - PSNR_cpu(s) -- pairing removes the 3 dB that the initialisation moves a run's PSNR by; averaging each seed's GPU
-    value over 2 members (the un-jittered run + one whose weights carry a 1e-6 relative perturbation) removes part of the GPU side's
-    chaos.  Asserted: (a) POWER -- the standard error of the mean difference is below 0.09 dB, i.e. a 0.15 dB bias is visible at
-    >= 1.7 standard errors and a 0.25 dB bias at >= 2.8; (b) the mean difference is compatible with a bias below 0.05 dB:
-    |mean| < 0.05 + 2.6 SE (a true bias of 0.3 dB fails this with > 95 % probability); (c) runs that collapse to the empty scene
-    (PSNR < 15 dB) are the same seeds on both sides, up to two.  The headline arithmetic, the fp32 FMA-chain mode and f16x3."""
-    import os
-    from oracle import psnr_protocol as P
-    path = os.path.join(golden_dir, 'g22_psnr_cpu_ensemble.npz')
-    z = np.load(path)
-    seeds = [int(s) for s in z['seeds']]
-    assert len(seeds) >= 24 and [int(x) for x in z['protocol']] == [P.ITERS, P.RAYS, P.HELD_OUT, P.WINDOW, P.N_SAMPLES, P.N_IMPORTANCE]
-    data = P.inputs(lambda o, d: fn.synthetic.render_rays(o, d, cutoff=0.0))
-    digest = [float(data['ro'].double().sum()), float(data['tgt'].double().sum()), float(data['u'].double().sum())]
-    # rays and jitter streams regenerate bit for bit from their seeds; the targets go through exp / cumprod of the host's vector math
-    # library, which may differ in the last bit between CPU models (the per-seed first-loss check below bounds what that is worth)
-    assert np.allclose([digest[0], digest[2]], [z['input_digest'][0], z['input_digest'][2]], rtol=1e-12, atol=0) and \
-        abs(digest[1] - z['input_digest'][1]) < 1e-7 * abs(z['input_digest'][1]), 'the inputs regenerated here are not the recorded run\'s'
-    dev = torch.device('cuda')
+def _paired_runner(fn, P, data, iters, dev):
+    """-> gpu_run(seed, mode, member): one free GPU run of the paired protocol from init_weights(seed) (member > 0: weights x (1 + 1e-6 N(0, 1)))."""
     dd = {k: v.to(dev) for k, v in data.items()}
     K = np.array([[P.FOCAL, 0, 0.5 * P.W], [0, P.FOCAL, 0.5 * P.H], [0, 0, 1]])
     args = fn.run_nerf.make_args(N_importance=P.N_IMPORTANCE, N_samples=P.N_SAMPLES, perturb=1.0, white_bkgd=True, no_reload=True,
                                  lrate=5e-4, lrate_decay=500)
-    old, old_c = fn.ops.get_math(), fn.render.get_compact()
-    members = 2          # per seed: the un-jittered run + one with a 1e-6 relative perturbation (more members buy < 5 % of standard error)
 
     def gpu_run(seed, mode, member):
         fn.ops.set_math(mode)
@@ -259,39 +234,122 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
                 tr.flat.mul_(1.0 + 1e-6 * torch.randn(tr.flat.shape, generator=g, device=dev))
         tr.repack()
         ls = []
-        for it in range(P.ITERS):
+        for it in range(iters):
             ls.append(tr.step(dd['ro'][it], dd['rd'][it], dd['tgt'][it], t_rand=dd['t_rand'][it], u=dd['u'][it])[0][0])
         ls = torch.stack(ls).cpu().numpy()
         with torch.no_grad():
             rgb = fn.render.render(P.H, P.W, K, chunk=P.HELD_OUT, rays=(dd['ho_ro'], dd['ho_rd']), near=2.0, far=6.0, **kte)[0]
             mse = float(torch.mean((rgb - dd['ho_tgt']) ** 2))
         return P.psnr(np.mean(ls[-P.WINDOW:])), P.psnr(mse), float(ls[0])
-    checks = []
+    return gpu_run
+
+
+def _check_inputs(z, data):
+    digest = [float(data['ro'].double().sum()), float(data['tgt'].double().sum()), float(data['u'].double().sum())]
+    # rays and jitter streams regenerate bit for bit from their seeds; the targets go through exp / cumprod of the host's vector math
+    # library, which may differ in the last bit between CPU models (the per-seed first-loss check bounds what that is worth)
+    assert np.allclose([digest[0], digest[2]], [z['input_digest'][0], z['input_digest'][2]], rtol=1e-12, atol=0) and \
+        abs(digest[1] - z['input_digest'][1]) < 1e-7 * abs(z['input_digest'][1]), 'the inputs regenerated here are not the recorded run\'s'
+
+
+G22_MEMBERS_MAIN, G22_MEMBERS_OTHER, G22_SEEDS_OTHER = 3, 2, 88
+
+
+def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
+    """north_star's "PSNR within 0.1 dB at equal iteration count" as a PAIRED two-sample test at the BASELINE shape (100 cameras of
+    800 x 800, 64 + 128 samples, 200 iterations of 256 uniformly drawn rays): tests/golden/g22_psnr_cpu_ensemble.npz holds the CPU
+    oracle's PSNR for every recorded initialisation seed (oracle/make_golden_psnr_ensemble.py: one free run each, ~10 minutes of one host
+    core); here the GPU starts from the SAME weights (oracle/psnr_protocol.py init_weights), sees the SAME batches / t_rand / u (generated
+    on the CPU from seeds, digest checked) and the statistic is the mean over seeds of d(s) = mean_members PSNR_gpu(s) - PSNR_cpu(s).
+    Pairing removes the 3 dB the initialisation moves a run's PSNR by; what is left per seed is the chaos of two free trajectories
+    (std ~0.45 dB on either side), so the statement is about the MEAN and its standard error.
+
+    HEADLINE ARITHMETIC (bf16x6), asserted for the training PSNR and the held-out PSNR:
+      (a) the two-sided 95 % confidence interval of mean(d), mean +- 1.96 SE, lies INSIDE +-0.1 dB (north_star's bound as an equivalence
+          statement; it needs SE <= ~0.04, which is why the ensemble has > 200 seeds and the GPU side 3 members per seed);
+      (b) the runs that collapse to the empty-scene solution (PSNR < 15 dB: the level is bimodal, 6.5 dB or > 20 dB) are EXACTLY the same
+          seeds on the GPU's un-perturbed member as on the CPU: collapse is a property of the initial weights, not of the arithmetic.
+    fp32-MFMA and f16x3 (sibling modes, the first %d seeds, 2 members): SE < 0.09 and |mean| < 0.05 + 2.6 SE (round 4's statement).""" % G22_SEEDS_OTHER
+    import os
+    from oracle import psnr_protocol as P
+    z = np.load(os.path.join(golden_dir, 'g22_psnr_cpu_ensemble.npz'))
+    seeds = [int(s) for s in z['seeds']]
+    assert len(seeds) >= 150 and [int(x) for x in z['protocol']] == [P.ITERS, P.RAYS, P.HELD_OUT, P.WINDOW, P.N_SAMPLES, P.N_IMPORTANCE]
+    data = P.inputs(lambda o, d: fn.synthetic.render_rays(o, d, cutoff=0.0))
+    _check_inputs(z, data)
+    dev = torch.device('cuda')
+    gpu_run = _paired_runner(fn, P, data, P.ITERS, dev)
+    old, old_c = fn.ops.get_math(), fn.render.get_compact()
+    checks, report = [], []
     try:
         for mode in ('bf16x6', 'fp32', 'f16x3'):
+            main = mode == 'bf16x6'
+            use = list(range(len(seeds))) if main else list(range(min(G22_SEEDS_OTHER, len(seeds))))
+            members = G22_MEMBERS_MAIN if main else G22_MEMBERS_OTHER
             g_train, g_held = [], []
-            for i, seed in enumerate(seeds):
-                runs = [gpu_run(seed, mode, j) for j in range(members)]
+            for i in use:
+                runs = [gpu_run(seeds[i], mode, j) for j in range(members)]
                 assert abs(runs[0][2] - float(z['first_loss'][i])) < 2e-5 * float(z['first_loss'][i]) + 1e-7      # same weights, same batch
                 g_train.append([r[0] for r in runs]); g_held.append([r[1] for r in runs])
             out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
-            if os.path.isdir(out_dir):      # (a record of the GPU side of the pairs for profiles/r04_psnr_paired.md; not part of the test)
-                np.savez(os.path.join(out_dir, 'g22_gpu_%s.npz' % mode), seeds=np.array(seeds), train=np.array(g_train), held=np.array(g_held))
-            for name, gv, cv in (('train', np.array(g_train), z['train_psnr_db']), ('held-out', np.array(g_held), z['held_out_psnr_db'])):
+            if os.path.isdir(out_dir):      # (a record of the GPU side of the pairs for profiles/r05_psnr_paired.md; not part of the test)
+                np.savez(os.path.join(out_dir, 'g22_gpu_%s.npz' % mode), seeds=np.array(seeds)[use], train=np.array(g_train), held=np.array(g_held))
+            for name, gv, cv in (('train', np.array(g_train), z['train_psnr_db'][use]), ('held-out', np.array(g_held), z['held_out_psnr_db'][use])):
                 alive_g, alive_c = gv[:, 0] > 15.0, cv > 15.0
-                assert int((alive_g != alive_c).sum()) <= 2, (mode, name, alive_g.tolist(), alive_c.tolist())
                 ok = alive_c & (gv > 15.0).all(1)
                 d = gv[ok].mean(1) - cv[ok]
                 se = float(np.std(d, ddof=1) / np.sqrt(len(d)))
-                print('G22 paired %s %s PSNR: %d of %d seeds train on both sides; CPU mean %.3f, GPU mean %.3f, mean difference %+.3f dB, per-seed std %.3f, '
-                      'standard error %.3f; within-seed GPU std %.3f' % (mode, name, len(d), len(seeds), cv[ok].mean(), gv[ok].mean(), d.mean(),
-                                                                         np.std(d, ddof=1), se, float(np.mean(np.std(gv[ok], axis=1, ddof=1)))))
-                checks.append((len(d) >= 20 and se < 0.09, (mode, name, len(d), se)))
-                checks.append((abs(float(d.mean())) < 0.05 + 2.6 * se, (mode, name, float(d.mean()), se)))
+                lo, hi = float(d.mean()) - 1.96 * se, float(d.mean()) + 1.96 * se
+                report.append('G22 paired %s %s PSNR: %d of %d seeds train on both sides (collapsed: CPU %d, GPU %d, mismatching %d); CPU mean %.3f, GPU mean '
+                              '%.3f, mean difference %+.4f dB, per-seed std %.3f, SE %.4f, 95 %% CI [%+.4f, %+.4f]; within-seed GPU std %.3f' % (
+                                  mode, name, len(d), len(use), int((~alive_c).sum()), int((~alive_g).sum()), int((alive_g != alive_c).sum()), cv[ok].mean(),
+                                  gv[ok].mean(), d.mean(), np.std(d, ddof=1), se, lo, hi, float(np.mean(np.std(gv[ok], axis=1, ddof=1)))))
+                print(report[-1])
+                if main:
+                    checks.append((bool((alive_g == alive_c).all()), (mode, name, 'collapsed seeds differ', np.array(seeds)[use][alive_g != alive_c].tolist())))
+                    checks.append((lo > -0.1 and hi < 0.1, (mode, name, 'the 95 % interval leaves +-0.1 dB', float(d.mean()), se, lo, hi)))
+                else:
+                    checks.append((int((alive_g != alive_c).sum()) <= 2, (mode, name, alive_g.tolist(), alive_c.tolist())))
+                    checks.append((len(d) >= 20 and se < 0.09, (mode, name, len(d), se)))
+                    checks.append((abs(float(d.mean())) < 0.05 + 2.6 * se, (mode, name, float(d.mean()), se)))
     finally:
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)
     assert all(ok for ok, _ in checks), [info for ok, info in checks if not ok]
+
+
+def test_psnr_paired_long_horizon_g23(fn, golden_dir):
+    """"PSNR@N-iters" at a second N: the same paired protocol with 1000 iterations (batch seed 3), a handful of seeds
+    (tests/golden/g23_psnr_cpu_long.npz, ~15 minutes of four host cores each).  With ~8 seeds the mean difference has a standard error of
+    ~0.1 - 0.2 dB, so this is a consistency check, not an equivalence test: the mean of GPU - CPU is within 3 standard errors of zero and
+    within 0.5 dB, every seed that trains on the CPU trains on the GPU, and 800 more iterations did raise the PSNR above G22's level."""
+    import os
+    from oracle import psnr_protocol as P
+    path = os.path.join(golden_dir, 'g23_psnr_cpu_long.npz')
+    if not os.path.exists(path):
+        pytest.skip('G23 not recorded')
+    z = np.load(path)
+    seeds = [int(s) for s in z['seeds']]
+    assert len(seeds) >= 4 and [int(x) for x in z['protocol']] == [P.LONG_ITERS, P.RAYS, P.HELD_OUT, P.WINDOW, P.N_SAMPLES, P.N_IMPORTANCE]
+    data = P.inputs(lambda o, d: fn.synthetic.render_rays(o, d, cutoff=0.0), iters=P.LONG_ITERS, batch_seed=3)
+    _check_inputs(z, data)
+    gpu_run = _paired_runner(fn, P, data, P.LONG_ITERS, torch.device('cuda'))
+    old, old_c = fn.ops.get_math(), fn.render.get_compact()
+    try:
+        g = np.array([[gpu_run(s, 'bf16x6', j)[:2] for j in range(3)] for s in seeds])      # [seed, member, (train, held-out)]
+    finally:
+        fn.ops.set_math(old)
+        fn.render.set_compact(old_c)
+    for k, (name, cv) in enumerate((('train', z['train_psnr_db']), ('held-out', z['held_out_psnr_db']))):
+        alive_c = cv > 15.0
+        assert ((g[:, 0, k] > 15.0) == alive_c).all(), (name, g[:, 0, k].tolist(), cv.tolist())
+        ok = alive_c & (g[:, :, k] > 15.0).all(1)
+        d = g[ok, :, k].mean(1) - cv[ok]
+        se = float(np.std(d, ddof=1) / np.sqrt(len(d)))
+        print('G23 paired bf16x6 %s PSNR @ %d iterations: %d of %d seeds; CPU mean %.3f, GPU mean %.3f, mean difference %+.3f dB, per-seed std %.3f, SE %.3f' % (
+            name, P.LONG_ITERS, len(d), len(seeds), cv[ok].mean(), g[ok, :, k].mean(), d.mean(), np.std(d, ddof=1), se))
+        assert len(d) >= 3 and abs(float(d.mean())) < max(3.0 * se, 0.15) and abs(float(d.mean())) < 0.5, (name, float(d.mean()), se)
+        assert cv[ok].mean() > 28.0, cv[ok].mean()        # (G22's 200-iteration level is 26.5 / 27.8 dB)
 
 
 def test_train_driver_with_quadtree(fn):
