@@ -18,19 +18,32 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fn
          '-Wno-unused-result']
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _digest(extra=()):
+    """sha256 over the sources the library is made of (+ the flags): what `libfastnerf.so.src` records next to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, '..', 'include', 'fastnerf.h')]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b'\0')
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS + list(extra)).encode())
+    return h.hexdigest()
+
+
+def _stale(extra=()):
+    # by CONTENT, not by mtime: a library that travelled (gpurun snapshot, checkout) is fresh exactly when it was built from these sources
+    if not os.path.exists(LIB) or not os.path.exists(LIB + '.src'):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'fastnerf.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(LIB + '.src') as f:
+        return f.read().strip() != _digest(extra)
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale() and not os.environ.get('FASTNERF_VARIANT'):
+    extra = os.environ.get('FASTNERF_CFLAGS', '').split()   # tuning experiments
+    if not force and not _stale(extra) and not os.environ.get('FASTNERF_VARIANT'):
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    extra = os.environ.get('FASTNERF_CFLAGS', '').split()   # tuning experiments
     if any(f.startswith('-DFASTNERF_ABLATION') for f in extra) and not os.environ.get('FASTNERF_VARIANT'):
         # timing-only builds compute WRONG RESULTS by design (csrc/mlp_common.h): they may only exist as variants/<name>.so
         raise RuntimeError('FASTNERF_ABLATION builds need FASTNERF_VARIANT=<name>: the product library is never an ablation build')
@@ -58,6 +71,8 @@ def build(force=False, verbose=False):
     if r.returncode != 0:
         sys.stderr.write(r.stdout.decode())
         raise RuntimeError('link failed')
+    with open(lib + '.src', 'w') as f:
+        f.write(_digest(extra) + '\n')
     return lib
 
 

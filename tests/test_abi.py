@@ -53,3 +53,17 @@ def test_f16x3_is_parked_behind_an_explicit_opt_in(monkeypatch):
         assert fastnerf.ops.get_math() == 'f16x3'
     finally:
         fastnerf.ops.set_math(old)
+
+
+def test_build_freshness_is_by_source_content(monkeypatch):
+    """`__graft_entry__.build()` skips the compile only when libfastnerf.so.src records the digest of the sources + flags it sees now
+    (a library that travelled with a snapshot must not count as fresh because of its mtime)."""
+    import importlib
+    b = importlib.import_module('fast-learning-nerf_amd.build')
+    if not os.path.exists(b.LIB + '.src'):      # (a library from before the digest existed: build() replaces it, ~40 s)
+        b.build()
+    assert os.path.exists(b.LIB + '.src'), 'build() writes the digest next to the library'
+    assert not b._stale(), 'the in-tree library was built from the sources in the tree'
+    assert b._stale(extra=('-DSOMETHING',)), 'other flags are another build'
+    monkeypatch.setattr(b, 'FLAGS', b.FLAGS + ['-O2'])
+    assert b._stale()

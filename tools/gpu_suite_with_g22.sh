@@ -4,6 +4,13 @@
 first=$1; n=$2; shift 2
 mkdir -p gpurun_out/g22_parts
 free -g | head -2 > gpurun_out/box_mem.txt; nproc >> gpurun_out/box_mem.txt
+# a worker holds ~1.7 GB (256 rays x 192 samples of autograd state): never plan more than the box's free memory / 3 GB or its cores - 24
+avail_gb=$(awk '/MemAvailable/ {print int($2 / 1048576)}' /proc/meminfo)
+cap=$(( avail_gb / 3 )); cores=$(( $(nproc) - 24 - 4 * $(echo $G23_SEEDS | wc -w) ))
+[ $cap -lt $n ] && n=$cap
+[ $cores -lt $n ] && n=$cores
+[ $n -lt 0 ] && n=0
+echo "workers: $n (MemAvailable ${avail_gb} GB)" >> gpurun_out/box_mem.txt
 pids=()
 for ((w = 0; w < n; w++)); do
   s=$((first + w))
