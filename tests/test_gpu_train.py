@@ -252,7 +252,7 @@ def _check_inputs(z, data):
         abs(digest[1] - z['input_digest'][1]) < 1e-7 * abs(z['input_digest'][1]), 'the inputs regenerated here are not the recorded run\'s'
 
 
-G22_MEMBERS_MAIN, G22_MEMBERS_OTHER, G22_SEEDS_OTHER = 3, 2, 88
+G22_MEMBERS_MAIN, G22_MEMBERS_OTHER, G22_SEEDS_OTHER = 2, 2, 88
 
 
 def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
@@ -266,10 +266,15 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
 
     HEADLINE ARITHMETIC (bf16x6), asserted for the training PSNR and the held-out PSNR:
       (a) the two-sided 95 % confidence interval of mean(d), mean +- 1.96 SE, lies INSIDE +-0.1 dB (north_star's bound as an equivalence
-          statement; it needs SE <= ~0.04, which is why the ensemble has > 200 seeds and the GPU side 3 members per seed);
+          statement.  Power: the per-seed difference scatters by ~0.55 dB (two free trajectories; 2 GPU members per seed), so the interval's half
+          width is 1.96 x 0.55 / sqrt(pairs); for the test to pass with > 95 % probability when the true bias is ZERO the standard error has
+          to be <= 0.1 / (2 x 1.96) = 0.0255, i.e. >= ~430 pairs = ~540 seeds (one seed in five collapses on both sides and is not a pair).
+          That is why the ensemble is this large; the CPU side is ~11 core-minutes per seed, recorded on the idle host cores of the GPU
+          boxes, oracle/make_golden_psnr_ensemble.py --parts);
       (b) the runs that collapse to the empty-scene solution (PSNR < 15 dB: the level is bimodal, 6.5 dB or > 20 dB) are EXACTLY the same
           seeds on the GPU's un-perturbed member as on the CPU: collapse is a property of the initial weights, not of the arithmetic.
-    fp32-MFMA and f16x3 (sibling modes, the first %d seeds, 2 members): SE < 0.09 and |mean| < 0.05 + 2.6 SE (round 4's statement).""" % G22_SEEDS_OTHER
+    fp32-MFMA (sibling mode, the first %d seeds, 2 members): SE < 0.09 and |mean| < 0.05 + 2.6 SE (round 4's statement).  (The parked f16x3
+    mode is no longer part of this test: it cannot be `value`, VERDICT r4 item 4.)""" % G22_SEEDS_OTHER
     import os
     from oracle import psnr_protocol as P
     z = np.load(os.path.join(golden_dir, 'g22_psnr_cpu_ensemble.npz'))
@@ -282,7 +287,7 @@ def test_psnr_paired_with_the_cpu_ensemble_g22(fn, golden_dir):
     old, old_c = fn.ops.get_math(), fn.render.get_compact()
     checks, report = [], []
     try:
-        for mode in ('bf16x6', 'fp32', 'f16x3'):
+        for mode in ('bf16x6', 'fp32'):
             main = mode == 'bf16x6'
             use = list(range(len(seeds))) if main else list(range(min(G22_SEEDS_OTHER, len(seeds))))
             members = G22_MEMBERS_MAIN if main else G22_MEMBERS_OTHER

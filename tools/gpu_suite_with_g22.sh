@@ -29,5 +29,12 @@ python -m pytest tests -m gpu -q "$@" > gpurun_out/gputest.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/gputest.log
 tail -5 gpurun_out/gputest.log
 t0=$(date +%s)
-for p in "${pids[@]}"; do wait $p; done
+# the box's GPU minutes are what the round budgets: wait at most G22_WAIT seconds (default 120) for the workers once the GPU work is done,
+# then stop the rest (a seed's JSON appears only when the seed is complete: nothing partial is kept)
+deadline=$(( t0 + ${G22_WAIT:-120} ))
+for p in "${pids[@]}"; do
+  while kill -0 $p 2>/dev/null && [ $(date +%s) -lt $deadline ]; do sleep 5; done
+  kill $p 2>/dev/null
+done
+wait
 echo "waited $(( $(date +%s) - t0 )) s more for the ensemble workers; parts: $(ls gpurun_out/g22_parts/*.json 2>/dev/null | wc -l)"
