@@ -98,14 +98,14 @@ def main():
                        'nets, U[0,1) targets, plain backward); counters are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports '
                        '1/2 of wide coalesced reads); per-step = sum over every kernel of the step / 4; kernels[...] = the LARGEST launch of that '
                        'kernel in a step = its fine pass (786 432 points)'}
-    md = ['# Round 4 rocprofv3 summary (MI355X, 1 GPU)', '',
+    md = ['# Round 5 rocprofv3 summary (MI355X, 1 GPU)', '',
           'Collected by `tools/collect_profiles_r05.sh` (through gpurun), summarised by `tools/summarize_prof_r05.py`.', '',
           '## bench.py under the profiler', '',
           '`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --psnr-iters 0`', '',
-          'bench line of that run (`profiles/r05_bench_line_under_rocprof.json`): **%.0f rays/s, %.2f ms/step** in the headline mode (%s); '
-          'fp32-MFMA mode %.0f rays/s; split-bf16 mode %.0f rays/s (all three: SURVEY 8(d) protocol, plain backward); split-bf16 on the trained sparse scene, '
-          'compacted backward %.0f rays/s.' % (j['value'], j['ms_per_step'], j['math_mode'].split(':')[0], j['fp32_mfma_mode']['init_state']['value'],
-                                                j['split_bf16_mode']['init_state']['value'], j['split_bf16_mode']['sparse_scene']['value']), '',
+          'bench line of that run (`profiles/r05_bench_line_under_rocprof.json`, the <= 4 KB headline of the round-5 output contract): **%.0f rays/s, %.2f ms/step** '
+          'in the headline mode (%s); sibling legs of the same process, ms per step: %s; bf16x6 on the trained sparse scene, compacted backward: %s.' % (
+              j['value'], j['ms_per_step'], j['config']['math_mode'], json.dumps((j.get('siblings') or {}).get('ms_per_step')),
+              json.dumps((j.get('siblings') or {}).get('sparse_scene_bf16x6'))), '',
           'roofline leg (HIP events inside bench.py): `%s` %.3f ms/launch = %.1f TFLOP/s algorithmic = frac %.3f of %.1f.' % (
               j['roofline']['kernel'], j['roofline']['avg_launch_ms'], j['roofline']['achieved'], j['roofline']['frac'], j['roofline']['peak']), '']
     rows = list(csv.DictReader(open(os.path.join(SRC, 'bench', 'bench_kernel_stats.csv'))))
