@@ -2,7 +2,8 @@
 # (build container only: needs /root/reference)  Regenerate EVERY reference-derived fixture of tests/golden/ from the reference into a
 # scratch directory and compare with the committed files: arrays bit for bit (npz members), other files byte for byte.  The two PSNR
 # ensembles (G22, G23) are recorded from the ORACLE, not from the reference (hours of host time; free runs are chaotic): for those, K
-# recorded seeds are re-run with the recorded thread count and compared at 1e-3 dB (G22_CHECK_SEEDS, default 2; 0 skips).
+# recorded seeds of G22 are re-run with the recorded thread count and compared at 1e-3 dB (G22_CHECK_SEEDS, default 2; 0 skips).  G23's seeds
+# (1000 iterations, ~1 h of one core each) are not re-run here: `G22_THREADS=1 python -m oracle.make_golden_psnr_ensemble --long --check 1` does it.
 set -e
 cd "$(dirname "$0")/.."
 D=$(mktemp -d /tmp/goldens.XXXXXX)
