@@ -101,7 +101,6 @@ SIGNATURES = {
     'fastnerf_mlp_fwd_live_ex': (I, [I, L, I, P, P, P, P, P, P, P, P]),
     'fastnerf_mlp_bwd_live_ex': (I, [I, L, I, P, P, P, P, P, P, P, P, P, P]),
     'fastnerf_render_rays_bwd_live': (I, [I, L, I, I, P, I] + [P] * 22 + [P]),
-    'fastnerf_mlp_x6_arith': (I, [I]),
     'fastnerf_mlp_x6_packed_floats': (L, [I, I]),
     'fastnerf_mlp_x6_pack': (I, [I, P, P, P, P]),
     'fastnerf_mlp_x6_fwd': (I, [I, L, I, P, P, P, P, P, P, I, P]),

@@ -13,7 +13,7 @@ int fn_launch_dx(int mm, int grid, hipStream_t st, int64_t P, const float* draw,
 // WO x WI waves (4 or 8), each wave TO x TI MFMA tiles:  NO = WO*TO*32, KI = WI*TI*32.
 // The 256x256 jobs run 8 waves x 128 accumulator registers (two waves per SIMD) so that one wave's
 // staging / bias work overlaps the other's MFMAs.
-template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>     // (the fp32-MFMA dW; bf16x6 / f16x3: mlp_bwd_dw6_kernel below)
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1>     // (the fp32-MFMA dW; bf16x6: mlp_bwd_dw6_kernel below)
 __global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
 mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx,
                   const float* __restrict__ draw /*RANK1: dalpha = draw[p*4+3]*/, float* __restrict__ partial_w,
@@ -180,13 +180,13 @@ mlp_bwd_dw_kernel(int64_t P, const float* __restrict__ dY, int ldy, const float*
 // feature and encoded direction, ride in ONE job: their common dY is read and split once).
 // CTO2 > 0: the last CTO2 of the WO * TO output tiles come from a second gradient tensor dY2 of width 32 * CTO2 (layers 0 and 5 both
 // multiply the positional encoding: it is read and split once); bias sums are taken over dY only.
+// wg / nwg: this workgroup's chunk of the k-steps and the number of chunks (mlp_bwd_dw6_kernel: blockIdx.x / gridDim.x; the trunk
+// launch below: blockIdx.x / a function of the point count)
 template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int CTI2 = 0, int CTO2 = 0>
-__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
-mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restrict__ X,
-                   const float* __restrict__ draw, float* __restrict__ partial_w, float* __restrict__ partial_b,
-                   float* __restrict__ partial_r, const int* __restrict__ live_idx, const int* __restrict__ live_cnt,
-                   const float* __restrict__ X2 = nullptr, const float* __restrict__ dY2 = nullptr) {
-  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
+__device__ __forceinline__ void dw6_body(const int64_t P, const float* __restrict__ dY, const float* __restrict__ X,
+                                         const float* __restrict__ draw, float* __restrict__ partial_w, float* __restrict__ partial_b,
+                                         float* __restrict__ partial_r, const int* __restrict__ live_idx,
+                                         const float* __restrict__ X2, const float* __restrict__ dY2, const int wg, const int nwg) {
   constexpr int NO = WO * TO * 32, KI = WI * TI * 32;
   constexpr int CTO = WO * TO, CTI = WI * TI, NTILE = CTO + CTI;
   constexpr int NW = WO * WI;
@@ -198,8 +198,8 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave / WI, wi = wave % WI;
   const int64_t nq_all = (P + 15) / 16;
-  const int64_t per = (nq_all + gridDim.x - 1) / gridDim.x;
-  const int64_t q0 = blockIdx.x * per;
+  const int64_t per = (nq_all + nwg - 1) / nwg;
+  const int64_t q0 = wg * per;
   int64_t q1 = q0 + per;
   if (q1 > nq_all) q1 = nq_all;
   const int nq = (int)(q1 - q0);
@@ -406,8 +406,8 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
 #pragma unroll 1
     for (int d = dmain; d < n2; ++d) pair(d, ANY);
   }
-  // write partials (zeros from workgroups without points: reduce_all sums every workgroup's region)
-  float* pw = partial_w + (int64_t)blockIdx.x * NO * KI;
+  // write partials (zeros from workgroups without points: reduce_all sums every chunk's region)
+  float* pw = partial_w + (int64_t)wg * NO * KI;
 #pragma unroll
   for (int i = 0; i < TO; ++i)
 #pragma unroll
@@ -425,12 +425,62 @@ mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restr
       if (NTILE % NW == 0 || t < NTILE) {
         const float sv = ssum[k] + __shfl_xor(ssum[k], 32, 64);
         if (lane < 32) {
-          if (BIAS && t < CTO1) partial_b[(int64_t)blockIdx.x * NO1 + t * 32 + lane] = sv;
-          if (RANK1 && t >= CTO) partial_r[(int64_t)blockIdx.x * KI + (t - CTO) * 32 + lane] = sv;
+          if (BIAS && t < CTO1) partial_b[(int64_t)wg * NO1 + t * 32 + lane] = sv;
+          if (RANK1 && t >= CTO) partial_r[(int64_t)wg * KI + (t - CTO) * 32 + lane] = sv;
         }
       }
     }
   }
+}
+
+template <int WO, int WI, int TO, int TI, bool BIAS, bool RANK1, int CTI2 = 0, int CTO2 = 0>
+__global__ void __launch_bounds__(WO * WI * 64, WO * WI / 4)
+mlp_bwd_dw6_kernel(int64_t P, const float* __restrict__ dY, const float* __restrict__ X,
+                   const float* __restrict__ draw, float* __restrict__ partial_w, float* __restrict__ partial_b,
+                   float* __restrict__ partial_r, const int* __restrict__ live_idx, const int* __restrict__ live_cnt,
+                   const float* __restrict__ X2 = nullptr, const float* __restrict__ dY2 = nullptr) {
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
+  dw6_body<WO, WI, TO, TI, BIAS, RANK1, CTI2, CTO2>(P, dY, X, draw, partial_w, partial_b, partial_r, live_idx, X2, dY2, (int)blockIdx.x,
+                                                    (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The eight 256 x 256 jobs of a pass (L1 .. L7 and the feature layer with the alpha head's rank-1 row) in ONE launch (round 6): grid =
+// (chunks, 8 jobs).  The number of split-K chunks per job is a function of the POINT COUNT ALONE (dw_trunk_chunks: an eighth of the chip per
+// 256 k-steps of 16 points, between 1/8 of the CUs and all of them), so that
+//   * the partials and their reduction shrink with the batch: a 512-ray shard (the reference's configs train at 1024 - 1920 rays,
+//     lego.txt:16; an 8-way strong-scaling shard of BASELINE configs[1] is 512) writes 32 chunks per job instead of 256 -- 75 MB per
+//     pass through reduce_all instead of 0.7 GB -- while 8 jobs x ncu / 8 chunks still fill every CU with whole rounds of equal work;
+//   * the order in which partial sums meet depends on the point count only: the live-list backward (device-side count) chunks exactly like
+//     the plain backward of the same points -- bit-identical gradients (tests/test_gpu_compact.py).  The host sizes the grid for
+//     the capacity P_total; chunks beyond dw_trunk_chunks(P) exit and are not reduced.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DW_QMAX 256   // k-steps (of 16 points) a chunk grows to before the next eighth of the chip is added
+__host__ __device__ static inline int dw_trunk_chunks(int64_t P, int ncu) {
+  const int unit = ncu >= 8 ? ncu / 8 : 1;
+  const int64_t nq = (P + 15) / 16;
+  int64_t k = (nq + (int64_t)unit * DW_QMAX - 1) / ((int64_t)unit * DW_QMAX);
+  k = k < 1 ? 1 : (k > 8 ? 8 : k);
+  return unit * (int)k;
+}
+struct DwTrunk {
+  const float* dY[8];
+  const float* X[8];
+  float* pw[8];
+  float* pb[8];
+};
+__global__ void __launch_bounds__(512, 2)
+mlp_bwd_dw6_trunk_kernel(int64_t P, DwTrunk J, const float* __restrict__ draw, float* __restrict__ partial_r,
+                         const int* __restrict__ live_idx, const int* __restrict__ live_cnt, int ncu) {
+  if (live_idx) P = (int64_t)__builtin_amdgcn_readfirstlane(*live_cnt);
+  const int nact = dw_trunk_chunks(P, ncu);
+  if ((int)blockIdx.x >= nact) return;
+  const int job = (int)blockIdx.y;
+  if (job == 7)
+    dw6_body<4, 2, 2, 4, true, true>(P, J.dY[7], J.X[7], draw, J.pw[7], J.pb[7], partial_r, live_idx, nullptr, nullptr, (int)blockIdx.x, nact);
+  else
+    dw6_body<4, 2, 2, 4, true, false>(P, J.dY[job], J.X[job], nullptr, J.pw[job], J.pb[job], nullptr, live_idx, nullptr, nullptr,
+                                      (int)blockIdx.x, nact);
 }
 
 // rgb head + alpha bias gradients (VALU reduction over points): per-workgroup partials
@@ -480,6 +530,7 @@ struct RedSeg {
   int64_t wg_stride;  // floats between consecutive workgroups' partials
   int64_t dst;        // offset into the flat gradient
   int nwg, rows, cols, ld, valid_cols;
+  int dyn;            // 1: the segment's chunk count is dw_trunk_chunks(point count) (the trunk launch); nwg is its capacity
 };
 #define MAX_SEGS 32
 struct RedTable {
@@ -488,8 +539,13 @@ struct RedTable {
 };
 
 __global__ void __launch_bounds__(256) reduce_all_kernel(RedTable tab, const float* __restrict__ partial,
-                                                          float* __restrict__ grads) {
-  const RedSeg sg = tab.s[blockIdx.y];
+                                                          float* __restrict__ grads, int64_t P, const int* __restrict__ live_cnt, int ncu) {
+  RedSeg sg = tab.s[blockIdx.y];
+  if (sg.dyn) {
+    if (live_cnt) P = (int64_t)*live_cnt;
+    const int n = dw_trunk_chunks(P, ncu);
+    sg.nwg = n < sg.nwg ? n : sg.nwg;
+  }
   const int64_t total = (int64_t)sg.rows * sg.cols;
   const float* src = partial + sg.src;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -578,17 +634,17 @@ static int launch_dw(int64_t P, const float* dY, int ldy, const float* X, int ld
 }
 
 static void add_seg(RedTable& T, int64_t src, int64_t wg_stride, int nwg, int rows, int cols, int64_t dst, int ld,
-                    int valid_cols) {
+                    int valid_cols, int dyn = 0) {
   RedSeg& s = T.s[T.n++];
   s.src = src; s.wg_stride = wg_stride; s.nwg = nwg; s.rows = rows; s.cols = cols; s.dst = dst; s.ld = ld;
-  s.valid_cols = valid_cols;
+  s.valid_cols = valid_cols; s.dyn = dyn;
 }
 
 template <int MM>
 static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                       const float* packed_bwd, float* dact, float* partial, float* grads, const int* live_idx,
                       const int* live_cnt, fn_stream_t stream) {
-  constexpr int MW = (MM == MM_H3) ? MM_X6 : MM;   // the dW jobs of f16x3 are bf16x6's (three bf16 pieces of the saved fp32 tensors)
+  constexpr int MW = MM;
   const NetLayout& L = layout_of(kind);
   const int PEP = L.pe_pad;
   hipStream_t st = fn::S(stream);
@@ -599,22 +655,23 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
   if (ntiles < grid) grid = (int)ntiles;
   if (int rc_dx = fn_launch_dx(MM, grid, st, P, draw, act, params, packed_bwd, dact, L, live_idx, live_cnt)) return rc_dx;
 
-  // ---- dW jobs: every job writes per-workgroup partials into its own region ------------------
-  // (always one workgroup per CU and a fixed head-gradient grid, also for small batches: the order in which partial sums
-  // meet then depends on the point count alone -- live-list backward == plain backward of the same points, bit for bit)
+  // ---- dW jobs: every job writes per-chunk partials into its own region ------------------
+  // (grids and chunk counts are functions of the point count alone -- one workgroup per CU and a fixed head-gradient grid for the jobs with
+  // their own launch, dw_trunk_chunks for the eight 256 x 256 jobs of the bf16x6 trunk launch -- so the order in which partial sums meet
+  // depends on the point count only: live-list backward == plain backward of the same points, bit for bit)
   const int nwg = ncu;
   RedTable T;
   T.n = 0;
   int rc;
   const float* a_pe = act + act_pe(P, PEP);
   auto region = [&](int j) { return partial + dw_job_base(j, ncu, PEP); };
-  auto segs = [&](int j, int64_t dstW, int ld, int validc, int64_t dstB, int64_t dstR) {
+  auto segs = [&](int j, int64_t dstW, int ld, int validc, int64_t dstB, int64_t dstR, int dyn = 0) {
     const DwJobDesc d = dw_job(j, PEP);
     const int64_t b = dw_job_base(j, ncu, PEP);
-    add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc);
+    add_seg(T, b, (int64_t)d.NO * d.KI, nwg, d.NO, d.KI, dstW, ld, validc, dyn);
     int64_t o = b + (int64_t)nwg * d.NO * d.KI;
-    if (d.bias) { add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO); o += (int64_t)nwg * d.NO; }
-    if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI);
+    if (d.bias) { add_seg(T, o, d.NO, nwg, 1, d.NO, dstB, d.NO, d.NO, dyn); o += (int64_t)nwg * d.NO; }
+    if (d.rank1) add_seg(T, o, d.KI, nwg, 1, d.KI, dstR, d.KI, d.KI, dyn);
   };
   // L0 (+ L5's pe part in the same job under MM_X6: one read and one split of the positional encoding for both;
   //     8 waves x (64 outputs x all pe tiles), partials [512][pe] + bias [256] across the neighbouring regions of jobs 0 and 8)
@@ -632,10 +689,12 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     if (rc) return rc;
     segs(0, L.LW[0], L.in_pe, L.in_pe, L.LB[0], 0);
   }
-  // L1..L7 (h part)
-  for (int l = 1; l < 8; ++l) {
-    if ((rc = launch_dw<4, 2, 2, 4, true, false, MW>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
-    segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
+  // L1..L7 (h part); MM_X6: together with the feature layer in the trunk launch below
+  if constexpr (MW != MM_X6) {
+    for (int l = 1; l < 8; ++l) {
+      if ((rc = launch_dw<4, 2, 2, 4, true, false, MW>(P, dact + dact_y(P, l), 256, act + act_h(P, PEP, l - 1), 256, nullptr, region(l), nwg, st, live_idx, live_cnt))) return rc;
+      segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0);
+    }
   }
   // L5 pe part (MM_X6: done with L0 above)
   if constexpr (MW != MM_X6) {
@@ -645,8 +704,31 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     segs(8, L.LW[5], 256 + L.in_pe, L.in_pe, 0, 0);
   }
   // feature / remap layer (+bias) with the alpha / sigma head as a rank-1 row
-  if ((rc = launch_dw<4, 2, 2, 4, true, true, MW>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
-  segs(9, L.FW, 256, 256, L.FB, L.AW);
+  if constexpr (MW == MM_X6) {
+    // the trunk launch: jobs 0..6 = L1..L7, job 7 = the feature layer; chunk w of a job writes where workgroup w of its own launch did
+    DwTrunk J;
+    for (int l = 1; l <= 8; ++l) {
+      const int j = l < 8 ? l : 9;
+      J.dY[l - 1] = l < 8 ? dact + dact_y(P, l) : dact + dact_feat(P);
+      J.X[l - 1] = act + act_h(P, PEP, l - 1);
+      J.pw[l - 1] = region(j);
+      J.pb[l - 1] = region(j) + (int64_t)nwg * 256 * 256;
+    }
+    float* pr = J.pb[7] + (int64_t)nwg * 256;
+    constexpr int lds6 = 2 * 16 * 3 * 1024 + 128;
+    static bool attr_t = false;
+    if (!attr_t) {
+      FN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dw6_trunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds6));
+      attr_t = true;
+    }
+    hipLaunchKernelGGL(mlp_bwd_dw6_trunk_kernel, dim3(dw_trunk_chunks(P, ncu), 8), dim3(512), lds6, st, P, J, draw, pr, live_idx, live_cnt, ncu);
+    FN_LAUNCH_CHECK();
+    for (int l = 1; l < 8; ++l) segs(l, L.LW[l] + (l == 5 ? L.in_pe : 0), l == 5 ? 256 + L.in_pe : 256, 256, L.LB[l], 0, 1);
+    segs(9, L.FW, 256, 256, L.FB, L.AW, 1);
+  } else {
+    if ((rc = launch_dw<4, 2, 2, 4, true, true, MW>(P, dact + dact_feat(P), 256, act + act_h(P, PEP, 7), 256, draw, region(9), nwg, st, live_idx, live_cnt))) return rc;
+    segs(9, L.FW, 256, 256, L.FB, L.AW);
+  }
   // view layer
   if constexpr (MW == MM_X6) {
     // one job for both inputs of the view layer (feature [P,256] | encoded direction [P,32]): dYv is read and split once; 12 waves,
@@ -671,14 +753,13 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387);   // dWr (384) + dbr (3), contiguous in every layout
     add_seg(T, hb + 387, 388, hg, 1, 1, L.AB, 1, 1);   // dba
   }
-  hipLaunchKernelGGL(reduce_all_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads);
+  hipLaunchKernelGGL(reduce_all_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads, P, live_cnt, ncu);
   FN_LAUNCH_CHECK();
   return 0;
 }
 static int bwd_launch(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                       const float* packed_bwd, float* dact, float* partial, float* grads, const int* live_idx,
                       const int* live_cnt, fn_stream_t stream, int mm = MM_F32) {
-  if (mm == MM_H3) return bwd_launch_t<MM_H3>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream);
   return mm == MM_X6 ? bwd_launch_t<MM_X6>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream)
                      : bwd_launch_t<MM_F32>(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream);
 }
@@ -710,12 +791,12 @@ extern "C" int fastnerf_mlp_x6_bwd(int kind, int64_t n, int S, const float* draw
                                    const float* packed_bwd, float* dact, float* partial, float* grads, fn_stream_t stream) {
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads, "null pointer");
-  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, nullptr, nullptr, stream, fn_x6_mm());
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, nullptr, nullptr, stream, MM_X6);
 }
 extern "C" int fastnerf_mlp_x6_bwd_live(int kind, int64_t n, int S, const float* draw, const float* act, const float* params,
                                         const float* packed_bwd, float* dact, float* partial, float* grads,
                                         const int32_t* live_idx, const int32_t* live_cnt, fn_stream_t stream) {
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(draw && act && params && packed_bwd && dact && partial && grads && live_idx && live_cnt, "null pointer");
-  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream, fn_x6_mm());
+  return bwd_launch(kind, n, S, draw, act, params, packed_bwd, dact, partial, grads, live_idx, live_cnt, stream, MM_X6);
 }

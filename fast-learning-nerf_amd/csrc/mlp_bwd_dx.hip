@@ -124,9 +124,7 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       const bool ok = pm < valid;
       const int64_t pp = ok ? p0 + pm : P - 1;
       const float4 dr = *reinterpret_cast<const float4*>(draw + (live_idx ? (int64_t)live_idx[pp] : pp) * 4);
-      constexpr float GS = (float)(1 << X6_H3_GSHIFT);   // MM_H3: the tile's gradients live in LDS x GS (a power of two: exact)
-      if constexpr (MM == MM_H3) { if (pq == 0) Es[pm] = ok ? dr.w * GS : 0.f; }
-      else { if (pq == 0) Es[pm] = ok ? dr.w : 0.f; }
+      if (pq == 0) Es[pm] = ok ? dr.w : 0.f;
       const float* wr = params + lay.RW;
       const float* hv = act + act_hv(PL, lay.pe_pad) + pp * 128;
       float* dyv = dact + dact_yv(PL) + pp * 128;
@@ -143,39 +141,21 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
         o.z = (h.z > 0.f) ? fmaf(dr.z, w2.z, fmaf(dr.y, w1.z, dr.x * w0.z)) : 0.f;
         o.w = (h.w > 0.f) ? fmaf(dr.z, w2.w, fmaf(dr.y, w1.w, dr.x * w0.w)) : 0.f;
         if (!ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (MM == MM_H3)
-          *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = make_float4(o.x * GS, o.y * GS, o.z * GS, o.w * GS);
-        else
-          *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = o;
+        *reinterpret_cast<float4*>(Hs + pm * 256 + ((((k >> 2) ^ (pm & 15))) << 2)) = o;
         if (ok) store_nt(dyv + k, o);
       }
     }
     __syncthreads();
     constexpr bool L16 = MM != MM_F32;
-    // MM_H3: a product's input tile (the gradient it multiplies, x 2^X6_H3_GSHIFT in LDS) is written out by the whole workgroup
-    // BEFORE its k-loop instead of being streamed between the MFMAs of its last k-step (where, with two accumulator sets live, the compiler
-    // spills accumulators around the stores)
-    auto copy_out = [&](float* __restrict__ dst) __attribute__((always_inline)) {
-      constexpr float ig = 1.f / (float)(1 << X6_H3_GSHIFT);
-      for (int i = tid; i < TM * 64; i += NTHR) {
-        const int m = i >> 6, sl = i & 63;
-        if (m < valid) {
-          float4 v = *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4);
-          v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
-          store_nt(dst + m * 256 + ((sl ^ (m & 15)) << 2), v);
-        }
-      }
-    };
-    // every 256 x 256 product after the first finds its first weights loaded (see mlp_fwd_kernel); not under MM_H3, whose second
-    // accumulator set leaves no registers for them (backward 8.84 -> 8.67 ms without)
-    constexpr bool CHAIN = L16 && MM != MM_H3;
+    // every 256 x 256 product after the first finds its first weights loaded one layer ahead (gemm_seg16, "chained weights")
+    constexpr bool CHAIN = L16;
     AccT<L16, 2> acc;
-    typename std::conditional<MM == MM_H3, NoChainGrad, WRegsT<L16, 2>>::type wch;
+    WRegsT<L16, 2> wch;
     // ---- dfeat = dYv . Wv[:, :256]  (K = 128) ------------------------------------------
     zero_acc<2>(acc);
     gemm<MM, 2, 0>(acc, Hs, 0, 16, wblock<MM>(packed_t, lay.PB[0]), 16, 0, wn * 2, wm, lane);
     __syncthreads();
-    wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[1]), 32, 0, 32, wn * 2, lane);
+    wprefetch(wch, wblock<MM>(packed_t, lay.PB[1]), 32, 0, 32, wn * 2, lane);
     epilogue_dx<false, false>(acc, Hs, Es, dx_preload<false, false, L16>(nullptr, nullptr, wn, lane), nullptr, wm, wn, lane,
                               valid);
     __syncthreads();
@@ -183,11 +163,10 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
     zero_acc<2>(acc);
     {
       const DxPre pre = dx_preload<true, true, L16>(maskw + (7 * NWAVES + wave) * 64, params + lay.AW, wn, lane);
-      if constexpr (MM == MM_H3) copy_out(dact + dact_feat(PL) + p0 * 256);
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, lay.PB[1]), 32, 0, wn * 2, wm, lane, 0,
-                            MM == MM_H3 ? nullptr : dact + dact_feat(PL) + p0 * 256, valid, wave, wch);    // streams dfeat (what it reads) out
+                            dact + dact_feat(PL) + p0 * 256, valid, wave, wch);    // streams dfeat (what it reads) out
       __syncthreads();
-      wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[2]), 32, 0, 32, wn * 2, lane);
+      wprefetch(wch, wblock<MM>(packed_t, lay.PB[2]), 32, 0, 32, wn * 2, lane);
       epilogue_dx<true, true>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
     }
     __syncthreads();
@@ -197,11 +176,10 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       const int64_t off = lay.PB[9 - l];   // PB[2] = L7t ... PB[8] = L1t
       zero_acc<2>(acc);
       const DxPre pre = dx_preload<true, false, L16>(maskw + ((l - 1) * NWAVES + wave) * 64, nullptr, wn, lane);
-      if constexpr (MM == MM_H3) copy_out(dact + dact_y(PL, l) + p0 * 256);
       gemm<MM, 2, 0, CHAIN>(acc, Hs, 0, 32, wblock<MM>(packed_t, off), 32, 0, wn * 2, wm, lane, 0,
-                            MM == MM_H3 ? nullptr : dact + dact_y(PL, l) + p0 * 256, valid, wave, wch);    // streams dY_l (what it reads) out
+                            dact + dact_y(PL, l) + p0 * 256, valid, wave, wch);    // streams dY_l (what it reads) out
       __syncthreads();
-      wprefetch<MM == MM_H3>(wch, wblock<MM>(packed_t, lay.PB[l > 1 ? 10 - l : 8]), 32, 0, 32, wn * 2, lane);   // (l == 1: nobody's; a re-read)
+      wprefetch(wch, wblock<MM>(packed_t, lay.PB[l > 1 ? 10 - l : 8]), 32, 0, 32, wn * 2, lane);   // (l == 1: nobody's; a re-read)
       epilogue_dx<true, false>(acc, Hs, Es, pre, nullptr, wm, wn, lane, valid);
       __syncthreads();
     }
@@ -209,17 +187,8 @@ mlp_bwd_dx_kernel(int64_t P, const float* __restrict__ draw, const float* __rest
       float* d0 = dact + dact_y(PL, 0) + p0 * 256;
       for (int i = tid; i < TM * 64; i += NTHR) {
         const int m = i >> 6, sl = i & 63;
-        if constexpr (MM == MM_H3) {
-          if (m < valid) {
-            float4 v = *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4);
-            constexpr float ig = 1.f / (float)(1 << X6_H3_GSHIFT);
-            v.x *= ig; v.y *= ig; v.z *= ig; v.w *= ig;
-            store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), v);
-          }
-        } else {
-          if (m < valid)
-            store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
-        }
+        if (m < valid)
+          store_nt(d0 + m * 256 + ((sl ^ (m & 15)) << 2), *reinterpret_cast<const float4*>(Hs + m * 256 + sl * 4));
       }
     }
     tile = b_next_tile(sched, sched_word, tid);   // closing barrier inside: H is rewritten by the next tile's phase A
@@ -244,7 +213,6 @@ static int launch_dx_t(int grid, hipStream_t st, int64_t P, const float* draw, c
 }
 int fn_launch_dx(int mm, int grid, hipStream_t st, int64_t P, const float* draw, const float* act, const float* params, const float* packed_bwd,
                  float* dact, const NetLayout& L, const int* live_idx, const int* live_cnt) {
-  if (mm == MM_H3) return launch_dx_t<MM_H3>(grid, st, P, draw, act, params, packed_bwd, dact, L, live_idx, live_cnt);
   return mm == MM_X6 ? launch_dx_t<MM_X6>(grid, st, P, draw, act, params, packed_bwd, dact, L, live_idx, live_cnt)
                      : launch_dx_t<MM_F32>(grid, st, P, draw, act, params, packed_bwd, dact, L, live_idx, live_cnt);
 }

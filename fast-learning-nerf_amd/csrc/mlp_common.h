@@ -1,5 +1,5 @@
 // mlp_common.h -- what the translation units of the fp32-width MLP kernels share (mlp_pack.hip, mlp_fwd.hip, mlp_bwd_dx.hip, mlp_bwd_dw.hip):
-// math modes, tile constants, the operand splits, the tile GEMMs (fp32 MFMA, bf16x6 / f16x3 on the 16 x 16 x 32 shape), epilogue helpers.
+// math modes, tile constants, the operand split, the tile GEMMs (fp32 MFMA, bf16x6 on the 16 x 16 x 32 shape), epilogue helpers.
 // Everything here is a template or a forceinline device function: each kernel's code is generated in the unit that instantiates it.
 //
 // (file header of the former single unit mlp.hip) the 8x256 NeRF MLP (model.py:8-63) as fused fp32-MFMA kernels for gfx950.
@@ -42,15 +42,14 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 //   MM_X6   "bf16x6": every fp32 operand x is decomposed EXACTLY into three bf16 pieces x = h + m + l (round-to-nearest at
 //           every level: 8 + 8 + 8 significand bits, |m| <= 2^-8 |x|, |l| <= 2^-17 |x|) and a product a*b is evaluated as
 //             a_h b_h + (a_h b_m + a_m b_h) + (a_m b_m + a_h b_l + a_l b_h)
-//           on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: six 32-cycle K=16 instructions instead of eight 64-cycle K=2
-//           ones (2.67x the matrix rate).  The three dropped terms are <= 2^-24 |a b| together, i.e. the product is as
+//           on the bf16 matrix instructions with fp32 accumulation (forward / dX: v_mfma_f32_16x16x32_bf16, dW: v_mfma_f32_32x32x16_bf16):
+//           six products at 16x the fp32 instruction's rate each (2.67x the matrix rate).  The three dropped terms are <= 2^-24 |a b| together, i.e. the product is as
 //           accurate as fp32's own rounding of it -- fp32 width, unlike the two-piece split of mlp_bf16.hip (16 bits).
 //           Weights are packed once per update as three bf16 planes in fragment order; activations / gradients stay fp32 in
 //           LDS and in HBM (same layouts, same bytes as MM_F32) and are split in registers when a fragment is read.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MM_F32 0
 #define MM_X6 1
-#define MM_H3 2   // "f16x3": MM_X6's kernels with the forward / dX products on two fp16 pieces (three products); dW as MM_X6
 // (round 4) the MM_X6 forward / dX kernels multiply on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  The chip is
 // power limited under these kernels and most of an MFMA's register traffic is its accumulator (C in + D out: 128 of ~160 bytes per lane
 // for the 32x32x16 shape); the 16x16x32 shape updates a quarter of the accumulator with twice the K: half the accumulator traffic per flop,
@@ -90,48 +89,27 @@ static inline const NetLayout& layout_of(int kind) {
   static const NetLayout L[3] = {make_layout(0), make_layout(1), make_layout(2)};
   return L[kind < 0 || kind > 2 ? 0 : kind];
 }
-int fn_x6_mm();   // MM_X6 or MM_H3: the arithmetic behind the fastnerf_mlp_x6_* entry points (mlp_pack.hip: fastnerf_mlp_x6_arith)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // operand splits (used by the weight packing and by the kernels)
 // ---------------------------------------------------------------------------------------------------------------------
-// MM_X6: three bf16 planes in fragment order of v_mfma_f32_32x32x16_bf16; uint4 units:
-//   dst[((tile*KS16 + ks)*3 + plane)*64 + l] = 8 bf16 = piece `plane` of W'[...][k = ks*16 + (l>>5)*8 + 0..7]
-//   fwd (n = tile*32 + (l&31)): W'[n][k] with the same k -> source column mapping as pack_kernel;  bwd: W[k][col0 + tile*32 + (l&31)]
+// MM_X6 packing (pack6_kernel): three bf16 planes in the fragment order of v_mfma_f32_16x16x32_bf16 (column tiles of 16, k-steps of 32); uint4 units:
+//   dst[((tile*KS32 + ks)*3 + plane)*64 + l] = 8 bf16 = piece `plane` of W'[...][k = ks*32 + (l>>4)*8 + 0..7]
+//   fwd (n = tile*16 + (l&15)): W'[n][k] with the same k -> source column mapping as pack_kernel;  bwd: W[k][col0 + tile*16 + (l&15)]
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // bf16(a) | bf16(b) << 16 (round to nearest even)
   const f32x2v v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
 }
-// x0, x1 -> packed pieces (h, m, l); exact: x = h + m + l.  The residual x - bf16(x) is one v_dot2c_f32_bf16 per value (the
-// packed piece times (-1, 0) or (0, -1), accumulated onto x: every intermediate is exactly representable), instead of an
-// unpack (shift / mask) and a subtraction: 7 VALU instructions per pair of values.
+// x0, x1 -> packed pieces (h, m, l); exact: x = h + m + l.  Subtract form: v_cvt_pk_bf16_f32 for a piece, shift / mask to unpack its two
+// halves, v_sub_f32 for the residual (every intermediate exactly representable): 11 plain VALU instructions per pair of values as written
+// (X6_VP; 9 - 10 as issued, most pairs of subtractions become one v_pk_add_f32).  The 7-instruction v_dot2c_f32_bf16 form of round 3 is gone:
+// ONE v_dot2c beside an MFMA stream costs 20 cycles (tools/micro/gap_probe.hip), plain VALU half a cycle each.
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
   if constexpr (ABL_NOSPLIT) { h = __float_as_uint(x0); m = __float_as_uint(x1); l = h ^ m; return; }
   h = cvt_pk_bf16(x0, x1);
   const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
   m = cvt_pk_bf16(r0, r1);
   l = cvt_pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
-}
-// MM_H3 ("f16x3", profiles/r04_f16x3_study.md): the forward / dX products of the MM_X6 kernels on TWO fp16 pieces with a scaled
-// residual -- x = h + 2^-12 l', h = fp16_rne(x), l' = fp16_rne((x - h) 2^12): |x - h - 2^-12 l'| <= 2^-23 |x| (rms 2^-24.4; three of four fp32
-// values are held exactly): ONE BIT short of fp32's 2^-24, below the fp32 accumulation error of this path's 128 ... 320-long sums --
-// and THREE products: Ah Wh into the layer's accumulators, Ah Wl' + Al' Wh into a second set that lives for one segment (gemm_seg16) and is
-// folded in (x 2^-12) at its end; the dropped Al' Wl' is 2^-24 relative (tests: logits vs fp64 as close as the fp32-MFMA kernels').  Same packed-weight layout as MM_X6 (planes h | l' | unused).
-// fp16's RANGE is the price: operands must stay below 65504 (activations and weights of this path do), and the dX kernel keeps its
-// gradients x 2^X6_H3_GSHIFT in LDS.  The dW jobs of this mode are bf16x6's (a two-piece fp16 dW with per-tensor scales was measured in round 4 -- step 15.4 -> 14.7 ms -- and removed: a data-dependent scale breaks the bit-exact live-list contract of DESIGN 4a; profiles/r04_f16x3_study.md section 4).
-typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#define X6_H3_SHIFT 12
-#define X6_H3_GSHIFT 14   // the dX kernel keeps its gradients x 2^14 in LDS (fp16's range: |dY| from 4e-9 normal, up to 4) and saves them unscaled
-__device__ __forceinline__ void split2h_pair(float x0, float x1, unsigned& h, unsigned& l) {
-  const f32x2v v = {x0, x1};
-  const f16x2v hv = __builtin_convertvector(v, f16x2v);
-  // (x - h) 2^12 as fma(h, -2^12, 2^12 x): every intermediate exact; the compiler reads the fp16 halves directly (v_fma_mix_f32):
-  // v_cvt_pk_f16_f32, 2 v_mul_f32, 2 v_fma_mix_f32, v_cvt_pk_f16_f32 = 6 instructions per pair (8 with a conversion back and a subtraction)
-  constexpr float SC = (float)(1 << X6_H3_SHIFT);
-  const f32x2v rv = {__builtin_fmaf((float)hv.x, -SC, x0 * SC), __builtin_fmaf((float)hv.y, -SC, x1 * SC)};
-  h = __builtin_bit_cast(unsigned, hv);
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, f16x2v));
 }
 // =========================================================================================
 // tile GEMM pieces shared by fwd and bwd_dx
@@ -260,7 +238,7 @@ __device__ __forceinline__ void interleave6() {
     interleave6<I + 1, NM, NVALU, SYNC>();
   }
 }
-// ---- MM_X6 / MM_H3 on v_mfma_f32_16x16x32_{bf16,f16} ------------------------------------------------------------------------------
+// ---- MM_X6 on v_mfma_f32_16x16x32_bf16 ---------------------------------------------------------------------------------------------
 // A wave's 64 x 64 outputs are 4 x 4 tiles of 16 x 16 (64 accumulator registers, as before); a k-step is 32 wide.  Lane (r16 = lane & 15,
 // kc = lane >> 4) holds 8 consecutive k of row / column r16 for both operands.  The weight pieces of a k-step (4 column tiles x 3
 // pieces = 48 registers) are held for the whole k-step and double buffered; the activation pieces are streamed ROW TILE by row tile:
@@ -272,60 +250,50 @@ template <bool L16, int NT> struct AccSel { typedef f32x16 type[2][NT]; };
 template <int NT> struct AccSel<true, NT> { typedef f32x4m type[4][2 * NT]; };
 template <bool L16, int NT> using AccT = typename AccSel<L16, NT>::type;
 
-template <bool H3>
 __device__ __forceinline__ f32x4m mfma16(const uint4& a, const uint4& b, f32x4m c) {
-  if constexpr (H3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-template <bool H3> struct X6A {   // the arithmetic of a 16 x 16 x 32 tile product
-  static constexpr int NPL = H3 ? 2 : 3;               // weight / activation pieces
-  static constexpr int NPROD = H3 ? 3 : 6;             // MFMAs; H3: (l', h) and (h, l') into the segment's cross-term accumulators, (h, h) into the layer's
-  static constexpr int VP = H3 ? 6 : 11;     // VALU instructions of one pair's split (pin counts of the interleave)
-};
+// the arithmetic of a 16 x 16 x 32 tile product: weight / activation pieces, MFMAs, VALU instructions of one pair's split (pin count of the interleave)
+constexpr int X6_NPL = 3, X6_NPROD = 6, X6_VP = 11;
 struct Pieces16 { unsigned v[3][4]; };   // [piece h | m | l][pair of k] of ONE row tile
 __device__ __forceinline__ uint4 piece_frag16(const Pieces16& p, int pl) { return make_uint4(p.v[pl][0], p.v[pl][1], p.v[pl][2], p.v[pl][3]); }
-template <bool H3>
 __device__ __forceinline__ void split_pair16(const float4 (&ar)[2], Pieces16& pn, int q) {
   const float4& s4 = ar[q >> 1];
   const float x0 = (q & 1) ? s4.z : s4.x, x1 = (q & 1) ? s4.w : s4.y;
-  if constexpr (H3) split2h_pair(x0, x1, pn.v[0][q], pn.v[1][q]);
-  else split3_pair(x0, x1, pn.v[0][q], pn.v[1][q], pn.v[2][q]);
+  split3_pair(x0, x1, pn.v[0][q], pn.v[1][q], pn.v[2][q]);
 }
 // one unit: 6 * CT MFMAs of row tile MT on the pieces pc and the k-step's weight pieces b; between them the split of `ar` (the next unit's
 // raw fragment) into pn and, behind its last pair, `refill()` (the LDS reads that reload ar for the unit after that)
-#define X6_PA(H3) {(H3) ? 1 : 2, 0, (H3) ? 0 : 1, 1, 0, 0}   // piece of the activations / of the weights in product t
-#define X6_PB(H3) {0, (H3) ? 1 : 2, (H3) ? 0 : 1, 0, 1, 0}
-// (H3: the products t < NPROD - 1 are the cross terms and go to acc2, the segment's second accumulator set)
-template <bool H3, int CT, int MT, int SYNC, typename ACC, typename RF>
-__device__ __forceinline__ void unit16(ACC& acc, ACC& acc2, const Pieces16& pc, const uint4 (&b)[CT][3], float4 (&ar)[2], Pieces16& pn, RF&& refill) {
-  constexpr int PA[6] = X6_PA(H3), PB[6] = X6_PB(H3);
-  constexpr int NPROD = X6A<H3>::NPROD, NM = NPROD * CT;
+#define X6_PA {2, 0, 1, 1, 0, 0}   // piece of the activations / of the weights in product t (small terms first)
+#define X6_PB {0, 2, 1, 0, 1, 0}
+template <int CT, int MT, int SYNC, typename ACC, typename RF>
+__device__ __forceinline__ void unit16(ACC& acc, const Pieces16& pc, const uint4 (&b)[CT][3], float4 (&ar)[2], Pieces16& pn, RF&& refill) {
+  constexpr int PA[6] = X6_PA, PB[6] = X6_PB;
+  constexpr int NPROD = X6_NPROD, NM = NPROD * CT;
 #pragma unroll
   for (int t = 0; t < NPROD; ++t)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int i = t * CT + ct;
-      if (H3 && t < NPROD - 1) acc2[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b[ct][PB[t]], acc2[MT][ct]);
-      else acc[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b[ct][PB[t]], acc[MT][ct]);
+      acc[MT][ct] = mfma16(piece_frag16(pc, PA[t]), b[ct][PB[t]], acc[MT][ct]);
 #pragma unroll
       for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) {
-        split_pair16<H3>(ar, pn, pair);
+        split_pair16(ar, pn, pair);
         if (pair == 3) refill();
       }
     }
-  interleave6<0, NM, 4 * X6A<H3>::VP, SYNC>();
+  interleave6<0, NM, 4 * X6_VP, SYNC>();
 }
 // Chained weights (dX): the weight pieces of a segment's first k-step are loaded by the CALLER one layer ahead -- between the barrier that ends
 // the previous layer's k-loop and its epilogue -- into registers that are dead there (they are the k-loop's own double buffer): the
 // segment starts without waiting for L2 (tools/x6_timing.py: ~2 000 cycles per layer before the first MFMA otherwise).
 struct NoChain {};
-struct NoChainGrad {};   // no preloaded weights either; marks the f16x3 dX kernel's calls (its LDS holds gradients x 2^X6_H3_GSHIFT)
 template <int CT> struct WRegs { uint4 b0[CT][3]; };   // k-step 0 (k-step 1 is not needed for ~3 000 cycles: the segment loads it itself)
 template <bool ON, int NT> struct WRegsSel { typedef NoChain type; };
 template <int NT> struct WRegsSel<true, NT> { typedef WRegs<2 * NT> type; };
 template <bool L16, int NT> using WRegsT = typename WRegsSel<L16, NT>::type;
 // arguments as gemm<>'s: KS, b_ks0, nks in the 8-wide k units of the call sites, nt0 = the wave's first 32-column tile
-template <bool H3, int CT>
+template <int CT>
 __device__ __forceinline__ void wprefetch(WRegs<CT>& w, const void* Bw, int KS, int b_ks0, int /*nks*/, int nt0, int lane) {
   const uint4* Bp = reinterpret_cast<const uint4*>(Bw);
   unsigned blane = (unsigned)lane * 16u;
@@ -334,15 +302,12 @@ __device__ __forceinline__ void wprefetch(WRegs<CT>& w, const void* Bw, int KS, 
   for (int ct = 0; ct < CT; ++ct) {
     const char* p = reinterpret_cast<const char*>(Bp + ((int64_t)(nt0 * 2 + ct) * (KS / 4) + b_ks0 / 4) * 192);
 #pragma unroll
-    for (int pl = 0; pl < X6A<H3>::NPL; ++pl) w.b0[ct][pl] = *reinterpret_cast<const uint4*>((p + (pl * 64) * 16) + blane);
+    for (int pl = 0; pl < X6_NPL; ++pl) w.b0[ct][pl] = *reinterpret_cast<const uint4*>((p + (pl * 64) * 16) + blane);
   }
 }
-template <bool H3>
 __device__ __forceinline__ void wprefetch(NoChain&, const void*, int, int, int, int, int) {}
-template <bool H3>
-__device__ __forceinline__ void wprefetch(NoChainGrad&, const void*, int, int, int, int, int) {}
 
-template <bool H3, int NT, int AMODE, bool PRE, typename ACC, typename W>
+template <int NT, int AMODE, bool PRE, typename ACC, typename W>
 __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ As, int a_ks0, int nks, const uint4* __restrict__ Bp, int KS,
                                            int b_ks0, int nt0, int wm, int lane, float* __restrict__ save_dst, int save_valid, int wave,
                                            W& wext) {
@@ -369,7 +334,7 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int pl = 0; pl < X6A<H3>::NPL; ++pl) {
+      for (int pl = 0; pl < X6_NPL; ++pl) {
         if (pl >= ABL_WPIECES) { b[ct][pl] = b[ct][0]; continue; }
         b[ct][pl] = *reinterpret_cast<const uint4*>((bptr[ct] + (ks * 192 + pl * 64) * 16) + blane);
       }
@@ -377,26 +342,18 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
   const int klast = nks - 1;
   float4 r0[2], r1[2];          // raw fragments of units u + 1 (being split) and u + 2 (in flight)
   Pieces16 pa, pb;              // pieces of the current and the next unit
-  constexpr bool CHAINED = !std::is_same<W, NoChain>::value && !std::is_same<W, NoChainGrad>::value;
-  constexpr bool GRADS = H3 && !std::is_same<W, NoChain>::value;   // the f16x3 dX kernel: rows saved from LDS are x 2^-X6_H3_GSHIFT
+  constexpr bool CHAINED = !std::is_same<W, NoChain>::value;
   static_assert(CHAINED || !PRE, "preloaded weights come through a WRegs");
   WRegs<CT> wloc_;
   WRegs<CT>& wr_ = [&]() -> WRegs<CT>& { if constexpr (CHAINED) return wext; else return wloc_; }();
   uint4 (&b0)[CT][3] = wr_.b0;
   uint4 b1[CT][3];
-  ACC acc2;                     // H3: cross terms of this segment (dead otherwise)
-  if constexpr (H3) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc2[mt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f};
-  }
   if constexpr (!PRE) load_b(b0, 0);
   load_raw(r0, 0, 0);
   load_raw(r1, 1, 0);
   load_b(b1, klast > 0 ? 1 : 0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) split_pair16<H3>(r0, pa, q);     // unit 0 is split up front; its registers then take unit 2
+  for (int q = 0; q < 4; ++q) split_pair16(r0, pa, q);     // unit 0 is split up front; its registers then take unit 2
   load_raw(r0, 2, 0);
   __builtin_amdgcn_s_setprio(1);
   // unit u = 4 ks + mt:   pieces  pa (u even) / pb (u odd);   splits raw r1 (u even) / r0 (u odd) = unit u + 1;   refills it with unit u + 3
@@ -404,10 +361,10 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
   auto kstep = [&](const uint4 (&b)[CT][3], int ks, auto par) __attribute__((always_inline)) {
     constexpr int S0 = 1 + 4 * decltype(par)::value;   // one sched_group_barrier pipeline per unit of the loop body
     const int kn = ks + 1 < klast ? ks + 1 : klast;   // k-step of units u + 3 / u + 4 once they wrap
-    unit16<H3, CT, 0, S0 + 0>(acc, acc2, pa, b, r1, pb, [&]() { load_raw(r1, 3, ks); });
-    unit16<H3, CT, 1, S0 + 1>(acc, acc2, pb, b, r0, pa, [&]() { load_raw(r0, 0, kn); });
-    unit16<H3, CT, 2, S0 + 2>(acc, acc2, pa, b, r1, pb, [&]() { load_raw(r1, 1, kn); });
-    unit16<H3, CT, 3, S0 + 3>(acc, acc2, pb, b, r0, pa, [&]() { load_raw(r0, 2, kn); });
+    unit16<CT, 0, S0 + 0>(acc, pa, b, r1, pb, [&]() { load_raw(r1, 3, ks); });
+    unit16<CT, 1, S0 + 1>(acc, pb, b, r0, pa, [&]() { load_raw(r0, 0, kn); });
+    unit16<CT, 2, S0 + 2>(acc, pa, b, r1, pb, [&]() { load_raw(r1, 1, kn); });
+    unit16<CT, 3, S0 + 3>(acc, pb, b, r0, pa, [&]() { load_raw(r0, 2, kn); });
   };
   constexpr std::integral_constant<int, 0> EVEN{};
   constexpr std::integral_constant<int, 1> ODD{};
@@ -425,8 +382,8 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
     // nks is even (8) for every saved segment: k-step nks - 2 as above, then the LAST k-step with the tile's rows streamed out between
     // its MFMAs (every load of the segment has been issued; rows beyond the valid count are clamped: rewritten with the same bytes)
     kstep(b0, nks - 2, EVEN);
-    constexpr int PA[6] = X6_PA(H3), PB[6] = X6_PB(H3);
-    constexpr int NPROD = X6A<H3>::NPROD, ROWS = TM / NWAVES, NM = NPROD * CT;
+    constexpr int PA[6] = X6_PA, PB[6] = X6_PB;
+    constexpr int NPROD = X6_NPROD, ROWS = TM / NWAVES, NM = NPROD * CT;
     const int last_row = save_valid - 1;
     auto last_unit = [&](auto mtc, const Pieces16& pc, float4 (&ar)[2], Pieces16& pn) __attribute__((always_inline)) {
       constexpr int MT = decltype(mtc)::value;
@@ -435,19 +392,16 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int i = t * CT + ct;
-          if (H3 && t < NPROD - 1) acc2[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b1[ct][PB[t]], acc2[MT][ct]);
-          else acc[MT][ct] = mfma16<H3>(piece_frag16(pc, PA[t]), b1[ct][PB[t]], acc[MT][ct]);
+          acc[MT][ct] = mfma16(piece_frag16(pc, PA[t]), b1[ct][PB[t]], acc[MT][ct]);
           if (MT < 3) {
 #pragma unroll
-            for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) split_pair16<H3>(ar, pn, pair);
+            for (int pair = (i * 4) / NM; pair < ((i + 1) * 4) / NM; ++pair) split_pair16(ar, pn, pair);
           }
 #pragma unroll
           for (int r = (i * (ROWS / 4)) / NM; r < ((i + 1) * (ROWS / 4)) / NM; ++r) {
             int m = (MT * (ROWS / 4) + r) * NWAVES + wave;
             m = m < last_row ? m : last_row;
-            const float4 v0 = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
-            constexpr float ig = GRADS ? 1.f / (float)(1 << X6_H3_GSHIFT) : 1.f;
-            const float4 v = GRADS ? make_float4(v0.x * ig, v0.y * ig, v0.z * ig, v0.w * ig) : v0;
+            const float4 v = *reinterpret_cast<const float4*>(As + m * 256 + lane * 4);
             store_nt(save_dst + (unsigned)(m * 256 + ((lane ^ (m & 15)) << 2)), v);
           }
         }
@@ -459,12 +413,6 @@ __device__ __forceinline__ void gemm_seg16(ACC& acc, const float* __restrict__ A
     last_unit(std::integral_constant<int, 3>{}, pb, r0, pa);
   }
   __builtin_amdgcn_s_setprio(0);
-  if constexpr (H3) {   // fold the segment's cross terms in
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[mt][ct] += acc2[mt][ct] * (1.f / (float)(1 << X6_H3_SHIFT));   // (as an explicit fma the saving forward spills 450 registers)
-  }
 }
 
 // one call site for both math modes: k-steps in the 8-wide units of gemm_seg, Bw = the layer's block in this mode's packing
@@ -472,8 +420,8 @@ template <int MM, int NT, int AMODE, bool PRE, typename W>
 __device__ __forceinline__ void gemm(f32x4m (&acc)[4][2 * NT], const float* __restrict__ As, int a_ks0, int nks, const void* Bw,
                                      int KS, int b_ks0, int nt0, int wm, int lane, int dbg,
                                      float* __restrict__ save_dst, int save_valid, int wave, W& w) {
-  static_assert(MM != MM_F32, "the 16 x 16 accumulator layout belongs to the bf16x6 / f16x3 kernels");
-  gemm_seg16<MM == MM_H3, NT, AMODE, PRE>(acc, As, a_ks0 / 4, nks / 4, reinterpret_cast<const uint4*>(Bw), KS / 4, b_ks0 / 4, nt0, wm, lane, save_dst,
+  static_assert(MM == MM_X6, "the 16 x 16 accumulator layout belongs to the bf16x6 kernels");
+  gemm_seg16<NT, AMODE, PRE>(acc, As, a_ks0 / 4, nks / 4, reinterpret_cast<const uint4*>(Bw), KS / 4, b_ks0 / 4, nt0, wm, lane, save_dst,
                              save_valid, wave, w);
 }
 template <int MM, int NT, int AMODE>

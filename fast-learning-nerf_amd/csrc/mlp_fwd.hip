@@ -141,7 +141,7 @@ mlp_fwd_kernel(int64_t P, int S, const float* __restrict__ rays, const float* __
         }
       }
     }
-    constexpr bool L16 = MM != MM_F32;    // the bf16x6 / f16x3 kernels: 16 x 16 accumulator tiles
+    constexpr bool L16 = MM != MM_F32;    // the bf16x6 kernels: 16 x 16 accumulator tiles
     constexpr bool FOLD = L16;            // ... whose accumulators start from the bias (no bias add in the epilogue)
     // (the forward loads a segment's first weights in its own prologue: a one-layer look-ahead as in dX cost 3.99 -> 4.28 ms, r04 ab_chain2/3)
     AccT<L16, 2> acc;
@@ -330,10 +330,6 @@ static int fwd_launch(int kind, int64_t n, int S, const float* rays11, const flo
     if (kind == 2) return act ? FN_FWD(true, true, MM_X6) : FN_FWD(false, true, MM_X6);
     return act ? FN_FWD(true, false, MM_X6) : FN_FWD(false, false, MM_X6);
   }
-  if (mm == MM_H3) {
-    if (kind == 2) return act ? FN_FWD(true, true, MM_H3) : FN_FWD(false, true, MM_H3);
-    return act ? FN_FWD(true, false, MM_H3) : FN_FWD(false, false, MM_H3);
-  }
   if (kind == 2) return act ? FN_FWD(true, true, MM_F32) : FN_FWD(false, true, MM_F32);
   return act ? FN_FWD(true, false, MM_F32) : FN_FWD(false, false, MM_F32);
 #undef FN_FWD
@@ -375,7 +371,7 @@ extern "C" int fastnerf_mlp_x6_fwd(int kind, int64_t n, int S, const float* rays
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n >= 0 && S >= 1, "kind in 0..2, n>=0, S>=1");
   FN_CHECK_ARG(n == 0 || (rays11 && z && params && packed_fwd && raw), "null pointer");
   if (n == 0) return 0;
-  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream, flags, fn_x6_mm());
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, raw, act, nullptr, nullptr, stream, flags, MM_X6);
 }
 extern "C" int fastnerf_mlp_x6_fwd_live(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,
                                         const float* packed_fwd, float* act, const int32_t* live_idx, const int32_t* live_cnt,
@@ -383,5 +379,5 @@ extern "C" int fastnerf_mlp_x6_fwd_live(int kind, int64_t n, int S, const float*
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && n > 0 && S >= 1, "kind in 0..2, n>0, S>=1");
   FN_CHECK_ARG(rays11 && z && params && packed_fwd && act && live_idx && live_cnt, "null pointer");
   FN_CHECK_ARG(n * (int64_t)S < ((int64_t)1 << 31), "live lists index points with int32");
-  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, nullptr, act, live_idx, live_cnt, stream, 0, fn_x6_mm());
+  return fwd_launch(kind, n, S, rays11, z, params, packed_fwd, nullptr, act, live_idx, live_cnt, stream, 0, MM_X6);
 }

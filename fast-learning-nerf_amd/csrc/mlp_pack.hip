@@ -55,7 +55,6 @@ __global__ void __launch_bounds__(256) pack_kernel(PackTable tab, const float* _
   }
 }
 
-template <bool H3>
 __global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* __restrict__ params,
                                                      uint4* __restrict__ pf, uint4* __restrict__ pb) {
   const PackDesc d = tab.d[blockIdx.y];
@@ -87,8 +86,7 @@ __global__ void __launch_bounds__(256) pack6_kernel(PackTable tab, const float* 
     unsigned h[4], m[4], lo[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if constexpr (H3) { split2h_pair(v[2 * q], v[2 * q + 1], h[q], m[q]); lo[q] = 0u; }   // planes: h | l' | (unused)
-      else split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], lo[q]);
+      split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], lo[q]);
     }
     uint4* o = dst + (blk * 3) * 64 + l;
     o[0] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -154,26 +152,12 @@ extern "C" int64_t fastnerf_mlp_x6_packed_floats(int kind, int which) {
   const NetLayout& L = layout_of(kind);
   return (which == 1 ? L.pf_total : L.pb_total) * 3 / 2;
 }
-// The arithmetic behind the fastnerf_mlp_x6_* entry points (process-wide; the packed weights of one arithmetic are garbage to the other:
-// re-pack after a change).  0: bf16x6 (default) -- three bf16 pieces, six products everywhere.  1: f16x3 (MM_H3) -- forward and dX on two fp16
-// pieces with a scaled residual, three products; dW as bf16x6.  Returns the previous setting; any other argument only queries.
-static int g_x6_arith = 0;   // (this translation unit owns the setting; fn_x6_mm() hands it to the forward / backward entry points)
-extern "C" int fastnerf_mlp_x6_arith(int arith) {
-  const int prev = g_x6_arith;
-  if (arith == 0 || arith == 1) g_x6_arith = arith;
-  return prev;
-}
-int fn_x6_mm() { return g_x6_arith ? MM_H3 : MM_X6; }
 extern "C" int fastnerf_mlp_x6_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream) {
   FN_CHECK_ARG(kind >= 0 && kind <= 2 && params && packed_fwd && packed_bwd, "kind in 0..2, non-null pointers");
   static const PackTable T[3] = {make_pack_table(layout_of(0)), make_pack_table(layout_of(1)),
                                  make_pack_table(layout_of(2))};
-  if (g_x6_arith)   // f16x3: planes h | l' | (zero); weights must be below fp16's 65504 in magnitude
-    hipLaunchKernelGGL(pack6_kernel<true>, dim3(32, 19), dim3(256), 0, fn::S(stream), T[kind], params,
-                       reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
-  else
-    hipLaunchKernelGGL(pack6_kernel<false>, dim3(32, 19), dim3(256), 0, fn::S(stream), T[kind], params,
-                       reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
+  hipLaunchKernelGGL(pack6_kernel, dim3(32, 19), dim3(256), 0, fn::S(stream), T[kind], params,
+                     reinterpret_cast<uint4*>(packed_fwd), reinterpret_cast<uint4*>(packed_bwd));
   FN_LAUNCH_CHECK();
   return 0;
 }

@@ -27,13 +27,10 @@ DACT_FLOATS = 2432
 #            packed weights (three bf16 planes)
 # 'bf16x3' : 3-term split-bf16 (two pieces, 16 significand bits) on the same instruction (csrc/mlp_bf16.hip): NARROWER than
 #            fp32 (products ~2^-17 relative), ~2.5x the rate of 'fp32'; rendered RGB still within 1e-6 of the fp32 kernels
-# 'f16x3'  : csrc/mlp_*.hip MM_H3 -- the forward and dX products of 'bf16x6' on TWO fp16 pieces with a scaled residual
-#            (x = h + 2^-12 l', both rounded to nearest: <= 2^-23 relative, rms 2^-24.4 -- one bit short of fp32) and THREE products with fp32
-#            accumulation; dW as 'bf16x6'.  Logits as close to fp64 as the 'fp32' kernels' (accumulation dominates) at half the matrix work (profiles/r04_f16x3_study.md);
-#            fp16's RANGE applies: weights and activations must stay below 65504 in magnitude (they do on this path)
+# (the two-fp16-piece 'f16x3' experiment of round 4 was deleted in round 6: unguarded fp16 range; its record is profiles/r04_f16x3_*)
 import os
-MATH_MODES = ('fp32', 'bf16x3', 'bf16x6', 'f16x3')
-_MODE_ID = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'f16x3': 2}   # 'f16x3' rides the bf16x6 entry points (fastnerf_mlp_x6_arith selects it)
+MATH_MODES = ('fp32', 'bf16x3', 'bf16x6')
+_MODE_ID = {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2}
 _MATH = os.environ.get('FASTNERF_MATH', 'bf16x6')   # default: the reference's arithmetic width
 assert _MATH in MATH_MODES, 'FASTNERF_MATH must be one of ' + ', '.join(MATH_MODES)
 
@@ -47,29 +44,16 @@ def set_math(mode):
     next packed() call; do not mix buffers produced under different modes."""
     global _MATH
     assert mode in MATH_MODES
-    if mode == 'f16x3' and os.environ.get('FASTNERF_EXPERIMENTAL_F16X3') != '1':
-        # PARKED (round 5, DESIGN section 4): fp16 pieces overflow at 65504 and the dX kernel keeps gradients x 2^14 in LDS; nothing detects an
-        # overflow / flush or falls back, so the mode is a measured research sibling (1.2x the bf16x6 step rate), not something to train with
-        raise RuntimeError("math mode 'f16x3' is an UNGUARDED experimental arithmetic (fp16 range: |w|, |h| < 65504, |dY| < 4; no overflow "
-                           "detection); set FASTNERF_EXPERIMENTAL_F16X3=1 to use it knowingly.  The fp32-width default is 'bf16x6'.")
     _MATH = mode
-    _sync_arith()
-
-
-def _sync_arith():
-    """Point the fastnerf_mlp_x6_* entry points at the arithmetic of the current mode (process-wide switch in the library)."""
-    if _x6():
-        lib().fastnerf_mlp_x6_arith(1 if _MATH == 'f16x3' else 0)
 
 
 def mode_id():
     """math_mode argument of the fused C-ABI entry points (fastnerf_render_rays_*, fastnerf_train_step)."""
-    _sync_arith()
     return _MODE_ID[_MATH]
 
 
 def _x6():
-    return _MATH in ('bf16x6', 'f16x3')
+    return _MATH == 'bf16x6'
 
 
 # math mode a packed-weight buffer was produced under: a Python attribute on the tensor object AND a registry by storage
@@ -228,7 +212,6 @@ def mlp_pack(params, packed_fwd=None, packed_bwd=None, kind=0):
               'fastnerf_mlp_bf16_pack')
         return packed_fwd, packed_bwd
     if _x6():
-        _sync_arith()
         check(lib().fastnerf_mlp_x6_pack(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()), 'fastnerf_mlp_x6_pack')
         return packed_fwd, packed_bwd
     check(lib().fastnerf_mlp_pack_ex(int(kind), ptr(params), ptr(packed_fwd), ptr(packed_bwd), stream()),

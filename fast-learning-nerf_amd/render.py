@@ -91,7 +91,7 @@ class LivePolicy:
     EVERY, PROBE = 4, 256   # (a measurement is a 16-byte asynchronous copy: cheap enough to follow fast changes early in training)
     # break-even live fractions from the measured kernel times (forward without saving + f x (saving forward + backward)
     # against saving forward + backward): 0.76 in the split-bf16 mode, 0.69 in the exact-fp32 mode; hysteresis around them
-    THRESHOLDS = {'bf16x3': (0.78, 0.70), 'fp32': (0.70, 0.62), 'bf16x6': (0.70, 0.62), 'f16x3': (0.70, 0.62)}
+    THRESHOLDS = {'bf16x3': (0.78, 0.70), 'fp32': (0.70, 0.62), 'bf16x6': (0.70, 0.62)}
 
     def __init__(self):
         self.frac = None          # last measured live fraction (both passes together)

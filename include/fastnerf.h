@@ -324,14 +324,6 @@ int fastnerf_render_rays_bwd_live(int math_mode, int64_t n, int N_samples, int N
  * saved activations / gradient workspaces are those of the exact-fp32 kernels (fastnerf_mlp_act_floats,
  * n*S*FASTNERF_DACT_FLOATS, fastnerf_mlp_bwd_partial_floats).  fwd: act == NULL -> inference, flags as
  * fastnerf_mlp_fwd_flags_ex (ignored when act != NULL). */
-/* The arithmetic behind the fastnerf_mlp_x6_* entry points (and math_mode 2 of the fused ones), process-wide.  0 (default): bf16x6 as
- * described above.  1: "f16x3" (csrc/mlp_*.hip, MM_H3) -- the forward and dX products on TWO fp16 pieces with a scaled residual,
- * x = h + 2^-12 l' with h = fp16(x), l' = fp16((x - h) 2^12), both rounded to nearest (|x - h - 2^-12 l'| <= 2^-23 |x|, rms 2^-24.4: one bit short of fp32), THREE products with fp32
- * accumulation (the cross terms in their own accumulators); dW unchanged.  fp16's
- * range applies: |weights|, |activations| < 65504.  Same buffer sizes; weights packed under one arithmetic are garbage to the other --
- * call fastnerf_mlp_x6_pack again after a change.  Returns the previous setting; any other argument only queries.  Replaces nothing in
- * the reference (which has one arithmetic, torch fp32: nerf-ours/model.py:38-63). */
-int fastnerf_mlp_x6_arith(int arith);
 int64_t fastnerf_mlp_x6_packed_floats(int kind, int which);
 int fastnerf_mlp_x6_pack(int kind, const float* params, float* packed_fwd, float* packed_bwd, fn_stream_t stream);
 int fastnerf_mlp_x6_fwd(int kind, int64_t n, int S, const float* rays11, const float* z, const float* params,

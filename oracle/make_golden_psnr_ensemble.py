@@ -31,8 +31,14 @@ synthetic = importlib.import_module('fast-learning-nerf_amd.synthetic')   # the 
 GOLD = os.environ.get('FASTNERF_GOLDEN_OUT') or os.path.join(ROOT, 'tests', 'golden')
 
 
-def out_path(long):
+def out_path(long, member=0):
+    if member:      # the NULL members (CPU' = the CPU oracle from weights x (1 + 1e-6 N(0, 1))): G24 (200 iterations) / G25 (1000)
+        return os.path.join(GOLD, ('g25_psnr_cpu_null_long_m%d.npz' if long else 'g24_psnr_cpu_null_m%d.npz') % member)
     return os.path.join(GOLD, 'g23_psnr_cpu_long.npz' if long else 'g22_psnr_cpu_ensemble.npz')
+
+
+def part_name(long, member, seed):
+    return ('long_' if long else 'seed_') + ('m%d_' % member if member else '') + '%d.json' % seed
 
 
 def make_inputs(long):
@@ -70,15 +76,19 @@ def main():
     ap.add_argument('--merge')
     ap.add_argument('--check', type=int)
     ap.add_argument('--long', action='store_true')
+    ap.add_argument('--member', type=int, default=0, help='0 = the recorded ensemble; k > 0 = the k-th jittered NULL member (G24 / G25)')
+    ap.add_argument('--weights', help='directory for the final weights of every run (cross-evaluation study; not a golden)')
     a = ap.parse_args()
     threads = int(os.environ.get('G22_THREADS', '8'))
     torch.set_num_threads(threads)
-    path = out_path(a.long)
+    path = out_path(a.long, a.member)
     data = make_inputs(a.long)
     if a.merge:
         done = load(path)
-        for f in sorted(glob.glob(os.path.join(a.merge, ('long_' if a.long else 'seed_') + '*.json'))):
+        for f in sorted(glob.glob(os.path.join(a.merge, ('long_' if a.long else 'seed_') + ('m%d_' % a.member if a.member else '') + '*.json'))):
             r = json.load(open(f))
+            if int(r.get('member', 0)) != a.member:
+                continue
             done.setdefault(int(r['seed']), (r['train'], r['held'], r['first'], int(r['threads'])))
         save(path, done, data, a.long)
         print('%d seeds in %s' % (len(done), path))
@@ -100,12 +110,16 @@ def main():
         os.makedirs(a.parts, exist_ok=True)
         todo = a.seed_list if a.seed_list else range(a.seeds[0], a.seeds[1])
         for seed in todo:
-            f = os.path.join(a.parts, ('long_%d.json' if a.long else 'seed_%d.json') % seed)
+            f = os.path.join(a.parts, part_name(a.long, a.member, seed))
             if os.path.exists(f):
                 continue
             t0 = time.time()
-            r = P.cpu_run(seed, data)
-            json.dump({'seed': seed, 'train': r[0], 'held': r[1], 'first': r[2], 'threads': threads, 'seconds': time.time() - t0,
+            r = P.cpu_run(seed, data, member=a.member, return_weights=bool(a.weights))
+            if a.weights:
+                os.makedirs(a.weights, exist_ok=True)
+                np.savez(os.path.join(a.weights, part_name(a.long, a.member, seed).replace('.json', '.npz')),
+                         **{'c.' + k: v.detach().numpy() for k, v in r[3][0].items()}, **{'f.' + k: v.detach().numpy() for k, v in r[3][1].items()})
+            json.dump({'seed': seed, 'member': a.member, 'train': r[0], 'held': r[1], 'first': r[2], 'threads': threads, 'seconds': time.time() - t0,
                        'iters': int(data['ro'].shape[0])}, open(f + '.tmp', 'w'))
             os.replace(f + '.tmp', f)
             print('seed %d: train %.3f dB, held-out %.3f dB  (%.0f s)' % (seed, r[0], r[1], time.time() - t0), flush=True)

@@ -70,11 +70,33 @@ def psnr(mse):
     return float(-10.0 * np.log10(mse))
 
 
-def cpu_run(seed, data):
+def jitter_weights(sdc, sdf, seed, member):
+    """The NULL member of the paired design: the same initialisation times (1 + 1e-6 N(0, 1)), i.e. a perturbation of
+    the size of fp32 rounding.  Two CPU runs that differ by it bound what "another arithmetic of fp32 width" can look like."""
+    g = torch.Generator().manual_seed(7000 + 10 * seed + member)
+    with torch.no_grad():
+        for sd in (sdc, sdf):
+            for w in sd.values():
+                w.mul_(1.0 + 1e-6 * torch.randn(w.shape, generator=g))
+
+
+def held_out_psnr(sdc, sdf, data):
+    with torch.no_grad():
+        rb = O.make_ray_batch(data['ho_ro'], data['ho_rd'], 2.0, 6.0)
+        se = 0.0
+        for s in range(0, HELD_OUT, 256):
+            ret = O.render_rays(rb[s:s + 256], sdc, sdf, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)
+            se += float(((ret['rgb_map'] - data['ho_tgt'][s:s + 256]) ** 2).sum())
+    return psnr(se / (HELD_OUT * 3))
+
+
+def cpu_run(seed, data, member=0, return_weights=False):
     """One free run of the CPU oracle over all iterations `data` holds -> (train PSNR over the last WINDOW iterations, held-out PSNR,
-    first loss)."""
+    first loss) [+ the final (coarse, fine) state dicts].  member > 0: the jittered initialisation of jitter_weights."""
     ITERS = data['ro'].shape[0]
     sdc, sdf = init_weights(seed)
+    if member:
+        jitter_weights(sdc, sdf, seed, member)
     opt = O.Adam(list(sdc.values()) + list(sdf.values()), lr=5e-4)
     losses = []
     for it in range(ITERS):
@@ -82,10 +104,5 @@ def cpu_run(seed, data):
         rb = O.make_ray_batch(data['ro'][it], data['rd'][it], 2.0, 6.0)
         l1, _, _, _ = O.train_step(sdc, sdf, opt, rb, data['tgt'][it], N_SAMPLES, N_IMPORTANCE, True, t_rand=data['t_rand'][it], u=data['u'][it])
         losses.append(float(l1))
-    with torch.no_grad():
-        rb = O.make_ray_batch(data['ho_ro'], data['ho_rd'], 2.0, 6.0)
-        se = 0.0
-        for s in range(0, HELD_OUT, 256):
-            ret = O.render_rays(rb[s:s + 256], sdc, sdf, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)
-            se += float(((ret['rgb_map'] - data['ho_tgt'][s:s + 256]) ** 2).sum())
-    return psnr(np.mean(losses[-WINDOW:])), psnr(se / (HELD_OUT * 3)), losses[0]
+    out = (psnr(np.mean(losses[-WINDOW:])), held_out_psnr(sdc, sdf, data), losses[0])
+    return out + ((sdc, sdf),) if return_weights else out

@@ -1,6 +1,5 @@
 import os
 
-os.environ.setdefault('FASTNERF_EXPERIMENTAL_F16X3', '1')   # the parked f16x3 mode stays under test (ops.set_math refuses it otherwise)
 import sys
 
 import pytest
@@ -13,6 +12,8 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: a statistical STUDY, not a regression test: only runs when the -m expression names it '
+                                       '(-m "gpu and slow") or FASTNERF_SLOW_TESTS=1; results live in profiles/')
 
 
 # ---- the CPU oracle's 200-iteration run of tests/test_gpu_train.py::test_psnr_vs_cpu_at_the_baseline_shape takes ~5 minutes of
@@ -63,6 +64,11 @@ def start_psnr_cpu_run():
 
 @pytest.hookimpl(trylast=True)   # (after -m / -k have deselected)
 def pytest_collection_modifyitems(config, items):
+    if 'slow' not in (config.getoption('markexpr') or '') and os.environ.get('FASTNERF_SLOW_TESTS') != '1':
+        slow = [it for it in items if it.get_closest_marker('slow')]
+        if slow:      # the studies (10 of the suite's 14 minutes in round 5) stay out of `-m gpu`: VERDICT r5 item 3
+            items[:] = [it for it in items if not it.get_closest_marker('slow')]
+            config.hook.pytest_deselected(items=slow)
     if any(it.name == PSNR_TEST for it in items):
         try:
             import torch
@@ -86,7 +92,7 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=['fp32', 'bf16x3', 'bf16x6', 'f16x3'])
+@pytest.fixture(params=['fp32', 'bf16x3', 'bf16x6'])
 def math_mode(request):
     """Run a GPU test under every matrix-core math mode of the MLP kernels (ops.set_math)."""
     import fastnerf

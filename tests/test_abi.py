@@ -37,24 +37,6 @@ def test_missing_gpu_fails_loudly():
         fastnerf.model.NeRF()
 
 
-def test_f16x3_is_parked_behind_an_explicit_opt_in(monkeypatch):
-    """Round 5: the f16x3 arithmetic (fp16 pieces: range-limited, no overflow detection) is a measured research sibling, not a mode to
-    train with -- ops.set_math refuses it unless FASTNERF_EXPERIMENTAL_F16X3=1 (tests/conftest.py sets it so the mode stays under test)."""
-    import pytest
-    import fastnerf
-    old = fastnerf.ops.get_math()
-    try:
-        monkeypatch.delenv('FASTNERF_EXPERIMENTAL_F16X3', raising=False)
-        with pytest.raises(RuntimeError, match='UNGUARDED experimental'):
-            fastnerf.ops.set_math('f16x3')
-        assert fastnerf.ops.get_math() == old
-        monkeypatch.setenv('FASTNERF_EXPERIMENTAL_F16X3', '1')
-        fastnerf.ops.set_math('f16x3')
-        assert fastnerf.ops.get_math() == 'f16x3'
-    finally:
-        fastnerf.ops.set_math(old)
-
-
 def test_build_freshness_is_by_source_content(monkeypatch):
     """`__graft_entry__.build()` skips the compile only when libfastnerf.so.src records the digest of the sources + flags it sees now
     (a library that travelled with a snapshot must not count as fresh because of its mtime)."""

@@ -124,7 +124,7 @@ def test_mlp_forward_points(fn, weights, P, math_mode):
     act = torch.empty(fn.ops.act_floats(P)).cuda()
     raw2 = fn.ops.mlp_fwd(rays, torch.zeros(P, 1).cuda(), flat, pf, act=act)[:, 0]
     assert torch.equal(raw, raw2)
-    if math_mode in ('fp32', 'bf16x6', 'f16x3'):   # (bf16x6 / f16x3 keep the exact-fp32 kernels' buffers)
+    if math_mode in ('fp32', 'bf16x6'):   # (bf16x6 keeps the exact-fp32 kernels' buffers)
         pe = act[:P * 64].view(P, 64).cpu()
     else:   # K-fragment tensors: pe (natural channel order), h0 (wave-permuted order)
         nt = (P + 63) // 64
@@ -137,7 +137,7 @@ def test_mlp_forward_points(fn, weights, P, math_mode):
         assert (h0 - h0_ref).abs().max() < 2e-5
     assert (pe[:, 63] == 0).all()
     # fp32 mode stores fp32; split mode stores (hi, lo) bf16 pairs = 16 significand bits (|x| <= 4 here)
-    assert (pe[:, :63] - O.posenc(pts, 10)).abs().max() < (2e-6 if math_mode in ('fp32', 'bf16x6', 'f16x3') else 4 * 2.0 ** -16)
+    assert (pe[:, :63] - O.posenc(pts, 10)).abs().max() < (2e-6 if math_mode in ('fp32', 'bf16x6') else 4 * 2.0 ** -16)
 
 
 def test_mlp_backward_vs_autograd(fn, weights, math_mode):
@@ -225,7 +225,7 @@ def test_mlp_backward_ragged_point_counts(fn, weights, math_mode, n, S):
     assert torch.isfinite(got).all()
     if n * S <= 64:
         if math_mode != 'fp32':
-            compare(got, grads_in('fp32'), 2e-5 if math_mode in ('bf16x6', 'f16x3') else 2e-2, 'vs fp32-MFMA')
+            compare(got, grads_in('fp32'), 2e-5 if math_mode in ('bf16x6',) else 2e-2, 'vs fp32-MFMA')
         return
     cut = n // 2 + 1
     parts = grads_in(math_mode, slice(0, cut)) + grads_in(math_mode, slice(cut, n))
@@ -233,7 +233,7 @@ def test_mlp_backward_ragged_point_counts(fn, weights, math_mode, n, S):
     if math_mode != 'fp32':
         ref = grads_in('fp32')
         rel = ((got - ref).norm() / ref.norm()).item()
-        assert rel < (2e-3 if math_mode in ('bf16x6', 'f16x3') else 2e-2), ('vs fp32-MFMA, relative L2', rel)
+        assert rel < (2e-3 if math_mode in ('bf16x6',) else 2e-2), ('vs fp32-MFMA, relative L2', rel)
 
 
 def test_run_network_signature(fn, weights):
@@ -265,7 +265,7 @@ def test_mlp_edge_cases(fn, weights, math_mode):
     lib = fn._lib.lib()
     a = (7, 1, 1, fn._lib.ptr(torch.zeros(1, 11).cuda()), fn._lib.ptr(torch.zeros(1, 1).cuda()), fn._lib.ptr(flat), fn._lib.ptr(pf),
          fn._lib.ptr(torch.zeros(1, 1, 4).cuda()), None)
-    if math_mode in ('bf16x6', 'f16x3'):
+    if math_mode in ('bf16x6',):
         rc = lib.fastnerf_mlp_x6_fwd(*a, 0, None)
     else:
         rc = (lib.fastnerf_mlp_bf16_fwd if math_mode == 'bf16x3' else lib.fastnerf_mlp_fwd_ex)(*a, None)
@@ -463,56 +463,6 @@ def test_bf16x6_decomposition_is_exact_and_products_have_fp32_width(fn, weights)
             err[mode] = float((raw - ref).pow(2).mean().sqrt())
         print('rms logit error vs fp64:', err)
         assert err['bf16x6'] <= 1.25 * err['fp32'] + 1e-9, err
-        assert err['f16x3'] <= 1.25 * err['fp32'] + 1e-9, err    # two fp16 pieces, scaled residual: as close to fp64 as fp32 is
         assert err['bf16x3'] >= 1.5 * err['fp32'], err
-    finally:
-        fn.ops.set_math(old)
-
-
-def test_f16x3_split_is_one_bit_short_of_fp32(fn, weights):
-    """The f16x3 mode's claim (csrc/mlp_*.hip, MM_H3): x = h + 2^-12 l' with h = fp16(x) and l' = fp16((x - h) 2^12), both rounded to
-    nearest, represents an fp32 operand to 2^-23 relative (one bit short of fp32's unit roundoff; most values exactly).  The packed weight planes (h | l' | zero, the
-    fragment order of the bf16x6 packing) decode to the fp32 weights within that bound, bit-exactly for most; switching the
-    arithmetic re-tags the buffers (packed bf16x6 weights are refused under f16x3 and vice versa)."""
-    old = fn.ops.get_math()
-    try:
-        flat = flat_of(weights).cuda()
-        fn.ops.set_math('f16x3')
-        pf, pb = fn.ops.mlp_pack(flat)
-        u16 = pf.cpu().numpy().view(np.uint16)             # uint4 units of 8 fp16: [tile][ks][plane][lane][8]
-        off = 0
-        worst = 0.0
-        exact = total = 0
-        for l in range(10):
-            name = ('pts_linears.%d.weight' % l) if l < 8 else ('feature_linear.weight' if l == 8 else 'views_linears.0.weight')
-            w = weights[name].numpy()
-            N = w.shape[0]
-            kp = 64 if l == 0 else (320 if l == 5 else (288 if l == 9 else 256))
-            n_u4 = (N // 16) * (kp // 32) * 3 * 64
-            blk = u16[off * 8:(off + n_u4) * 8].reshape(N // 16, kp // 32, 3, 64, 8)
-            assert not blk[:, :, 2].any(), name                                      # third plane unused
-            tot = blk[:, :, 0].view(np.float16).astype(np.float64) + blk[:, :, 1].view(np.float16).astype(np.float64) * 2.0 ** -12
-            got = tot.reshape(N // 16, kp // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(N, kp)
-            if l == 0:
-                ref = np.concatenate([w, np.zeros((N, 1), np.float32)], 1)
-            elif l == 5:
-                ref = np.concatenate([w[:, :63], np.zeros((N, 1), np.float32), w[:, 63:]], 1)
-            elif l == 9:
-                ref = np.concatenate([w, np.zeros((N, 5), np.float32)], 1)
-            else:
-                ref = w
-            ref = ref.astype(np.float64)
-            big = np.abs(ref) >= 2.0 ** -13                                          # (below: fp16's subnormal grid, absolute 2^-37)
-            rel = np.abs(got - ref)[big] / np.abs(ref)[big]
-            worst = max(worst, float(rel.max()))
-            assert np.abs(got - ref)[~big].max(initial=0.0) <= 2.0 ** -36, name
-            exact += int((got == ref).sum()); total += ref.size
-            off += n_u4
-        assert off * 4 == pf.numel()
-        print('f16x3 packed weights: worst relative error %.3e (2^-23 = %.3e), %.1f %% exact' % (worst, 2.0 ** -23, 100.0 * exact / total))
-        assert worst <= 2.0 ** -23 * 1.0001 and exact > 0.6 * total, (worst, exact, total)
-        fn.ops.set_math('bf16x6')
-        with pytest.raises(AssertionError):
-            fn.ops.mlp_fwd(torch.zeros(1, 11).cuda(), torch.zeros(1, 1).cuda(), flat, pf)
     finally:
         fn.ops.set_math(old)
