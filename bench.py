@@ -63,7 +63,7 @@ BWD_FLOP_PER_POINT = 2 * (2 * MAC_PER_POINT - 35712)   # dX (without the input-s
 TRAIN_FLOP_PER_RAY = 2 * (3 * MAC_PER_POINT - 35712) * (N_SAMPLES + S1)  # 893.2 MFLOP
 FP32_MFMA_PEAK_TFLOPS = 157.3              # MI355X_MICROARCH.md: dense fp32 matrix peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 matrix peak
-PROFILE_ROUND = 'r05'
+PROFILE_ROUND = 'r06'
 MAIN_MODE = 'bf16x6'                        # the headline's arithmetic: fp32-width products on the bf16 matrix cores (docstring)
 MODE_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 1.0, 'dense fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'mlp_fwd_kernel', ', 0'),
              'bf16x6': (BF16_MFMA_PEAK_TFLOPS / 6.0, 6.0, 'dense bf16 MFMA 2500 TFLOP/s / 6 piece products per fp32 product', 'mlp_fwd_kernel', ', 1'),
@@ -75,7 +75,7 @@ MAC_PER_POINT_BG = MAC_PER_POINT + 2 * 21 * 256   # nerf++ background MLPNet: 84
 # measured ceiling of a bare v_mfma_f32_32x32x16_bf16 stream on uniform(-1, 1) data (tools/micro/mfma_power.hip, gap_probe.hip:
 # 1848 - 1871 TFLOP/s issued at the 1.79 GHz the power management grants it) -- a REPO CONSTANT from earlier runs, not measured here
 BF16_MFMA_REAL_DATA_TFLOPS = 1871.0
-PAIRED_PSNR_NOTE = 'tests/test_gpu_train.py::test_psnr_paired_with_the_cpu_ensemble_g22 (profiles/r05_psnr_paired.md)'
+PAIRED_PSNR_NOTE = 'tests/test_gpu_train.py::test_psnr_paired_study_g22 (profiles/r05_psnr_paired.md), null: profiles/r06_psnr_null.md'
 
 
 HEADLINE_MAX_BYTES = 4096
@@ -126,6 +126,9 @@ def headline_record(out):
                                       'step_frac_of_peak')})
     if out.get('sustained'):
         h['sustained_ms_per_step'] = out['sustained']['ms_per_step']
+    for k in ('scaling_weak', 'scaling_strong'):      # --scaling both: the two curves' points of this N in the one line
+        if out.get(k):
+            h[k] = _pick(out[k], ('rays_per_gpu_per_step', 'rays_per_step', 'ms_per_step', 'value'))
     h['siblings'] = out.get('siblings_summary')
     h['errors'] = [_short(e, 160) for e in out.get('errors', [])][:4] or None
     h['full_record'] = out.get('full_record')
@@ -431,8 +434,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
-                    help='weak: 4096 rays per GPU per step; strong: 4096 rays per step split over the GPUs')
+    ap.add_argument('--scaling', choices=['weak', 'strong', 'both', 'auto'], default='auto',
+                    help='weak: 4096 rays per GPU per step (`value`); strong: 4096 rays per step split over the GPUs (`value`); both: `value` '
+                         'is the weak number and the line also carries scaling_weak / scaling_strong blocks (one invocation, both curves); '
+                         'auto (default): weak on one GPU, both on several')
     ap.add_argument('--sustained-steps', type=int, default=150)
     ap.add_argument('--scene-steps', type=int, default=600, help='untimed optimisation steps of the sparse-scene sibling leg')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip both CPU legs (cpu_baseline, psnr_vs_cpu.cpu)')
@@ -456,7 +461,12 @@ def main():
     local = local % max(1, torch.cuda.device_count())   # (only differs in single-GPU plumbing tests of the N>1 path)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    n_local = N_RAYS if a.scaling == 'weak' else N_RAYS // world      # rays per rank per step
+    if a.scaling == 'auto':
+        a.scaling = 'both' if world > 1 else 'weak'
+    both = a.scaling == 'both'
+    # weak is the contract's default and the reference's own practice: nerf++-ours/ddp_train_nerf.py:201-202 quotes its rates at a FIXED
+    # batch per GPU (1920 rays on 2 GPUs, 2880 on 3)
+    n_local = N_RAYS // world if a.scaling == 'strong' else N_RAYS      # rays per rank per step (of the leg that is `value`)
     n_step = n_local * world                                          # rays per step, whole job
     siblings = rank == 0 and world == 1 and not a.no_siblings
     psnr_leg = rank == 0 and world == 1 and a.psnr_iters > 0
@@ -563,7 +573,7 @@ def main():
         dom = rows[0]    # the single launch the plain step spends the most time in (the backward row is 15 launches)
         traffic = step_traffic = None
         pmc_file = None
-        for rnd in (PROFILE_ROUND, 'r04'):   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles_*.sh)
+        for rnd in (PROFILE_ROUND, 'r05', 'r04'):   # HBM bytes from the committed PMC passes (separate rocprofv3 --pmc runs, tools/collect_profiles_*.sh)
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd + '_pmc_traffic.json')))
                 traffic = pmc[mode]['kernels'][dom['kernel']]['hbm_bytes']
@@ -713,6 +723,27 @@ def main():
     if a.sustained_steps > 0:   # power-managed clocks settle within seconds: the same stream of steps for a few seconds more
         ts, _, _ = timed(lambda i: step(tr, i)[0], a.warmup + a.steps, 0, a.sustained_steps)
         sustained = leg(ts, a.sustained_steps, wall_seconds=ts)
+    # ---- --scaling both: the OTHER curve in the same invocation (every rank takes part: the steps hold collectives) ------------------
+    scaling_blocks = None
+    if both:
+        def scaling_leg(n_loc):
+            trs_ = new_trainer()[0]
+            ng = n_loc * world
+
+            def st(i):
+                ro, rd, tgts, tag = batches[i % n_batches]
+                return trs_.step(ro[:n_loc], rd[:n_loc], tgts['noise'][:n_loc], leaf_tag=tag[:n_loc].contiguous(), table=table,
+                                 max_leaves=max_leaves, n_global=ng if world > 1 else None)[0]
+            t_, l_, tl_ = timed(st, 0, a.warmup, a.steps)
+            return {'rays_per_gpu_per_step': n_loc, 'rays_per_step': ng, 'ms_per_step': 1e3 * t_ / a.steps, 'value': ng * a.steps / t_,
+                    'unit': 'rays/s', 'steps': a.steps, 'warmup': a.warmup, 'rank0_ms_per_step': 1e3 * tl_ / a.steps,
+                    'final_loss': [float(x) for x in l_.tolist()]}
+        weak_blk = {'rays_per_gpu_per_step': n_local, 'rays_per_step': n_step, 'ms_per_step': 1e3 * dt / a.steps, 'value': n_step * a.steps / dt,
+                    'unit': 'rays/s', 'steps': a.steps, 'warmup': a.warmup, 'rank0_ms_per_step': 1e3 * t_local / a.steps,
+                    'final_loss': [float(x) for x in loss2.tolist()], 'note': 'this leg is `value`'}
+        strong_blk = scaling_leg(max(1, N_RAYS // world))
+        strong_blk['note'] = '4096 rays per step split over the ranks (BASELINE configs[1] as ONE job): value / (the N=1 value) is the strong-scaling factor'
+        scaling_blocks = {'weak': weak_blk, 'strong': strong_blk}
     roof = mlp_roofline(tr, MAIN_MODE) if rank == 0 else None
     step_tflops = n_step * a.steps / dt * TRAIN_FLOP_PER_RAY / 1e12 / world
 
@@ -811,10 +842,44 @@ def main():
             inf[mode] = {'value': n_inf / dt_i, 'unit': 'rays/s', 'ms_per_call': 1e3 * dt_i}
         return inf
 
-    split_block = fp32_block = drop_in = infer = psnr_block = cfg_blocks = main_sparse = None
+    def batch_size_leg():
+        """The headline step (same arithmetic, plain backward, leaf table on) at the reference's OWN batch sizes and at an 8-way strong-scaling
+        shard of configs[1]: every shipped config trains at N_rand 1024 - 1920 (nerf-ours/configs/lego.txt:16 = 1920, fern.txt:9 = 1536, nine
+        configs at 1024), none at 4096; 4096 / 8 = 512 is what one rank of `--gpus 8 --scaling strong` steps.  The first N rays of the headline's
+        batches; best of three rounds of 30 steps per size (HIP events), sizes interleaved so that clock drift hits them alike."""
+        ops.set_math(MAIN_MODE)
+        fastnerf.render.set_compact('0')
+        sizes = [n for n in (512, 1024, 1920, 4096) if n <= n_local]
+        trs = {n: new_trainer()[0] for n in sizes}
+
+        def one(n, i):
+            ro, rd, tgts, tag = batches[i % n_batches]
+            return trs[n].step(ro[:n], rd[:n], tgts['noise'][:n], leaf_tag=tag[:n].contiguous(), table=table, max_leaves=max_leaves)
+        best = {n: float('inf') for n in sizes}
+        for _ in range(3):
+            for n in sizes:
+                it = [0]
+
+                def f():
+                    one(n, it[0]); it[0] += 1
+                best[n] = min(best[n], time_launch(f, 30))
+        top = sizes[-1] / best[sizes[-1]]
+        blk = {'what': 'the headline protocol at other batch sizes on ONE GPU: ms / step, k rays/s, fraction of the %d-ray rate (best of 3 x 30 steps)' % sizes[-1],
+               'sizes': {str(n): {'ms_per_step': best[n], 'rays_per_s': 1e3 * n / best[n], 'frac_of_%d_rate' % sizes[-1]: (n / best[n]) / top} for n in sizes}}
+        if 512 in best and 4096 in best:
+            ar = 0.1    # ms; ASSUMED: the exposed coarse-half all-reduce of 2.38 MB over xGMI (latency-bound: 7 links, direct reduce-scatter + all-gather
+            #             ~0.05 ms, a ring ~0.14 ms); the fine half rides under the coarse backward (DESIGN 6).  No multi-GPU box has run this.
+            blk['predicted_strong_8'] = {
+                'value': (4096.0 / (best[512] + ar)) / top, 'label': 'PREDICTION from 1-GPU timings, not a measurement',
+                'formula': '8 * 512 / (t_512 + exposed half-buffer all-reduce) / (4096 / t_4096)', 't_512_ms': best[512], 't_4096_ms': best[4096],
+                'assumed_exposed_allreduce_ms': ar, 'without_collective': (4096.0 / best[512]) / top}
+        return blk
+
+    split_block = fp32_block = drop_in = infer = psnr_block = cfg_blocks = main_sparse = batch_sizes = None
     kte_b = kte_32 = None
     dd = None
     if siblings:
+        batch_sizes = guarded('batch_sizes', batch_size_leg)
         r_ = guarded('fp32_mfma_mode', lambda: mode_leg(
             'fp32', dtype='f32: v_mfma_f32_32x32x2_f32, an fp32 FMA chain (157.3 TFLOP/s ceiling)'))
         if r_ is not None:
@@ -921,9 +986,10 @@ def main():
             psnr_head = {'iters': psnr_block['iters'], 'rays_per_iter': PSNR_RAYS, 'gpu_train_db': g_.get('train_psnr_db'),
                          'gpu_held_out_db': g_.get('held_out_psnr_db')}
             if 'train_psnr_db' in psnr_block.get('cpu', {}):
-                psnr_head.update(cpu_train_db=psnr_block['cpu']['train_psnr_db'], cpu_held_out_db=psnr_block['cpu']['held_out_psnr_db'],
-                                 lockstep_delta_db=psnr_block['lockstep'][MAIN_MODE]['delta_db'],
-                                 lockstep_max_rel_loss_diff=psnr_block['lockstep'][MAIN_MODE]['max_rel_loss_diff'])
+                psnr_head.update(cpu_train_db=psnr_block['cpu']['train_psnr_db'], cpu_held_out_db=psnr_block['cpu']['held_out_psnr_db'])
+                ls_ = (psnr_block.get('lockstep') or {}).get(MAIN_MODE)      # absent when the lockstep replay failed (recorded in `errors`)
+                if isinstance(ls_, dict) and 'delta_db' in ls_:
+                    psnr_head.update(lockstep_delta_db=ls_['delta_db'], lockstep_max_rel_loss_diff=ls_.get('max_rel_loss_diff'))
             psnr_head['paired_ensemble'] = PAIRED_PSNR_NOTE
         if world == 1 and not a.no_cpu_baseline:
             cpu = guarded('cpu_baseline', lambda: cpu_baseline(a.cpu_protocol))
@@ -955,11 +1021,21 @@ def main():
                            'live_fine': None if not main_sparse['live_fraction'] else round(main_sparse['live_fraction']['fine'], 4),
                            'plain_ms': round(main_sparse['same_state_plain_backward']['ms_per_step'], 3)},
                        'configs_rays_per_s': None if not cfg_blocks else {k.split('_')[0]: round(v['value']) for k, v in cfg_blocks.items()},
-                       'inference_rays_per_s': None if infer is None or MAIN_MODE not in infer else round(infer[MAIN_MODE]['value'])}
+                       'inference_rays_per_s': None if infer is None or MAIN_MODE not in infer else round(infer[MAIN_MODE]['value']),
+                       # the step at the reference's own batch sizes / an 8-way strong-scaling shard: ms per step, and the predicted (NOT measured)
+                       # 8-GPU strong-scaling factor 8 * 512 / (t_512 + 0.1 ms of exposed all-reduce) over the 4096-ray rate
+                       'batch_ms': None if batch_sizes is None else {k: round(v['ms_per_step'], 3) for k, v in batch_sizes['sizes'].items()},
+                       'batch_frac_of_4096_rate': None if batch_sizes is None else {
+                           k: round(v.get('frac_of_4096_rate', float('nan')), 3) for k, v in batch_sizes['sizes'].items()},
+                       'predicted_strong_8': None if batch_sizes is None or 'predicted_strong_8' not in batch_sizes else round(
+                           batch_sizes['predicted_strong_8']['value'], 2)}
         out = {
             'metric': 'training rays/sec (Lego-like 800x800, 64+128 samples) + PSNR@N-iters', 'value': rays_per_s, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
-            'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'weak' if both else a.scaling, 'vs_baseline': None,
+            'scaling_weak': None if scaling_blocks is None else scaling_blocks['weak'],
+            'scaling_strong': None if scaling_blocks is None else scaling_blocks['strong'],
+            'affinity': parallel.affinity_report(),
             'dtype': 'f32', 'math_mode': MAIN_MODE + ': fp32-width products on the bf16 matrix cores -- operands decomposed exactly into three bf16 '
                                          'pieces, six piece products per fp32 product (weight >= 2^-16; dropped <= 2^-24), fp32 accumulation; '
                                          'activations, gradients, parameters and optimiser state stay fp32',
@@ -981,6 +1057,7 @@ def main():
             'psnr_vs_cpu': psnr_block,
             'fp32_mfma_mode': fp32_block,
             'split_bf16_mode': split_block,
+            'batch_sizes': batch_sizes,
             MAIN_MODE + '_sparse_scene': main_sparse,
             'drop_in_route': drop_in,
             'other_configs': cfg_blocks,

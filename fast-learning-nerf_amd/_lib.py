@@ -94,6 +94,9 @@ SIGNATURES = {
     'fastnerf_tree_adjust': (L, [P, P, I, D]),
     'fastnerf_tree_epoch_plan': (L, [P, D, I, P, P]),
     'fastnerf_epoch_rays': (I, [L, I, P, P, P, P, I, I, I, F, F, F, F, U64, I] + [P] * 10 + [P]),
+    'fastnerf_epoch_rays_shard': (I, [L, I, P, P, P, P, I, I, I, F, F, F, F, U64, I] + [P] * 5 + [L, I, I] + [P] * 5 + [P]),
+    'fastnerf_epoch_shard_rows': (L, [L, L, I, I]),
+    'fastnerf_gauss_noise': (I, [L, F, U64, P, P]),
     'fastnerf_compact_ws_ints': (L, [L]),
     'fastnerf_compact_live': (I, [L, P, P, P, P, P]),
     'fastnerf_mlp_bf16_fwd_live': (I, [I, L, I, P, P, P, P, P, P, P, P]),

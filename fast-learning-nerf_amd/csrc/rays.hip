@@ -256,6 +256,8 @@ __device__ __forceinline__ uint64_t feistel_perm(uint64_t j, uint64_t n, int hal
 
 struct EpochArgs {
   int64_t N;
+  int64_t n_out, batch;   // shard: n_out output rows; output row r is epoch row (r / per_batch) * batch + row0 + (r % per_batch) * stride
+  int row0, stride, per_batch;
   int L, n_img, H, W, shuffle, half_bits;
   float fx, fy, cx, cy;
   uint32_t k0, k1;
@@ -268,8 +270,11 @@ __global__ void __launch_bounds__(256) epoch_rays_kernel(EpochArgs a, const int3
                                                           const double* __restrict__ cum, float* __restrict__ ro,
                                                           float* __restrict__ rd, float* __restrict__ rgb,
                                                           int32_t* __restrict__ tag, int32_t* __restrict__ pix) {
-  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < a.N; j += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = a.shuffle ? (int64_t)feistel_perm((uint64_t)j, (uint64_t)a.N, a.half_bits, a.k0, a.k1) : j;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < a.n_out; r += (int64_t)gridDim.x * blockDim.x) {
+    // the epoch row this output row holds (all rows: j = r; a rank's shard: its rows row0 :: stride of every batch of the epoch)
+    const int64_t jrow = a.stride == 1 && a.row0 == 0 ? r : (r / a.per_batch) * a.batch + a.row0 + (r % a.per_batch) * (int64_t)a.stride;
+    const int64_t i = a.shuffle ? (int64_t)feistel_perm((uint64_t)jrow, (uint64_t)a.N, a.half_bits, a.k0, a.k1) : jrow;
+    const int64_t j = r;
     // leaf of source index i: the last l with offs[l] <= i
     int lo = 0, hi = a.L;   // invariant: offs[lo] <= i < offs[hi]
     while (hi - lo > 1) {
@@ -320,27 +325,50 @@ __global__ void __launch_bounds__(256) epoch_rays_kernel(EpochArgs a, const int3
   }
 }
 
-extern "C" int fastnerf_epoch_rays(int64_t N, int L, const int32_t* plan, const int64_t* offs, const float* images,
-                                   const float* poses, int n_img, int H, int W, float fx, float fy, float cx, float cy,
-                                   uint64_t seed, int shuffle, const int32_t* n_weighted, const int64_t* seg_beg,
-                                   const int64_t* seg_end, const int32_t* order, const double* cum, float* rays_o,
-                                   float* rays_d, float* rgb, int32_t* tag, int32_t* pix, fn_stream_t stream) {
+// rows of an epoch of N rows that rank `row0` of `stride` ranks holds when every batch of `batch` rows is dealt out row0 :: stride
+// (run_nerf.py:472-478 takes batches of N_rand consecutive rows of the shuffled epoch)
+extern "C" int64_t fastnerf_epoch_shard_rows(int64_t N, int64_t batch, int row0, int stride) {
+  if (N < 0 || batch < 1 || stride < 1 || row0 < 0 || row0 >= stride) return -1;
+  const int64_t per = batch > row0 ? (batch - row0 + stride - 1) / stride : 0;
+  const int64_t full = N / batch, tail = N - full * batch;
+  return full * per + (tail > row0 ? (tail - row0 + stride - 1) / stride : 0);
+}
+
+extern "C" int fastnerf_epoch_rays_shard(int64_t N, int L, const int32_t* plan, const int64_t* offs, const float* images,
+                                         const float* poses, int n_img, int H, int W, float fx, float fy, float cx, float cy,
+                                         uint64_t seed, int shuffle, const int32_t* n_weighted, const int64_t* seg_beg,
+                                         const int64_t* seg_end, const int32_t* order, const double* cum, int64_t batch, int row0,
+                                         int stride, float* rays_o, float* rays_d, float* rgb, int32_t* tag, int32_t* pix,
+                                         fn_stream_t stream) {
   FN_CHECK_ARG(N >= 0 && L >= 1 && n_img >= 1 && H >= 1 && W >= 1, "N>=0, L>=1, n_img>=1, H,W>=1");
-  if (N == 0) return 0;
+  FN_CHECK_ARG(batch >= 1 && stride >= 1 && row0 >= 0 && row0 < stride, "batch>=1, 0 <= row0 < stride");
+  if (N == 0 || fastnerf_epoch_shard_rows(N, batch, row0, stride) == 0) return 0;   // (a rank without rows: nothing to write, no buffers needed)
   FN_CHECK_ARG(plan && offs && images && poses && rays_o && rays_d && rgb && tag, "null pointer");
   FN_CHECK_ARG(!n_weighted || (seg_beg && seg_end && order && cum), "weighted picks need seg_beg, seg_end, order, cum");
   FN_CHECK_ARG((int64_t)n_img * H * W < ((int64_t)1 << 31), "pixel ids are int32");
   EpochArgs a;
   a.N = N; a.L = L; a.n_img = n_img; a.H = H; a.W = W; a.shuffle = shuffle;
+  a.n_out = fastnerf_epoch_shard_rows(N, batch, row0, stride);
+  a.batch = batch; a.row0 = row0; a.stride = stride;
+  a.per_batch = (int)(batch > row0 ? (batch - row0 + stride - 1) / stride : 1);
   a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy;
   int bits = 2;
   while (bits < 62 && ((uint64_t)1 << bits) < (uint64_t)N) ++bits;
   a.half_bits = (bits + 1) / 2;
   a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
-  hipLaunchKernelGGL(epoch_rays_kernel, dim3(grid_for(N)), dim3(256), 0, fn::S(stream), a, plan, offs, images, poses, n_weighted,
+  hipLaunchKernelGGL(epoch_rays_kernel, dim3(grid_for(a.n_out)), dim3(256), 0, fn::S(stream), a, plan, offs, images, poses, n_weighted,
                      seg_beg, seg_end, order, cum, rays_o, rays_d, rgb, tag, pix);
   FN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int fastnerf_epoch_rays(int64_t N, int L, const int32_t* plan, const int64_t* offs, const float* images,
+                                   const float* poses, int n_img, int H, int W, float fx, float fy, float cx, float cy,
+                                   uint64_t seed, int shuffle, const int32_t* n_weighted, const int64_t* seg_beg,
+                                   const int64_t* seg_end, const int32_t* order, const double* cum, float* rays_o,
+                                   float* rays_d, float* rgb, int32_t* tag, int32_t* pix, fn_stream_t stream) {
+  return fastnerf_epoch_rays_shard(N, L, plan, offs, images, poses, n_img, H, W, fx, fy, cx, cy, seed, shuffle, n_weighted, seg_beg, seg_end,
+                                   order, cum, N > 0 ? N : 1, 0, 1, rays_o, rays_d, rgb, tag, pix, stream);
 }
 
 // -1./(W/(2.*focal)) is evaluated in double by Python and then applied as an fp32 scalar

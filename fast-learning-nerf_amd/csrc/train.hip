@@ -254,3 +254,47 @@ extern "C" int fastnerf_compact_live(int64_t n_points, const float* draw, int32_
   FN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sigma noise of one render_rays call (render.py:162: noise = torch.randn(raw[..., 3].shape) * raw_noise_std): ONE launch fills the noise of
+// BOTH passes (coarse [n, S0] and fine [n, S0 + Ni], one allocation) -- Philox4x32-10 keyed by the caller's seed, counter = the float4 index,
+// Box-Muller on the four words -- instead of two torch.randn + two multiplications per step (the LLFF configs train with raw_noise_std = 1).
+// The values are N(0, std^2) draws of this library's own stream (the reference draws from torch's global generator: distribution parity, like
+// the jitter streams; the `pytest=True` hook of render_rays still injects the reference's deterministic numpy numbers).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gauss_noise_kernel(int64_t n4, int64_t n, float sd, uint32_t k0, uint32_t k1, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t o[4];
+    philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), 0x6e6f6973u, 0u, k0, k1, o);
+    float v[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)(o[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1): the logarithm stays finite
+      const float u2 = (float)(o[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+      const float r = sqrtf(-2.0f * logf(u1)) * sd;
+      float sn, cs;
+      sincosf(6.28318530717958647692f * u2, &sn, &cs);
+      v[2 * h] = r * cs;
+      v[2 * h + 1] = r * sn;
+    }
+    const int64_t e = i * 4;
+    if (e + 4 <= n) {
+      *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e + q < n) out[e + q] = v[q];
+    }
+  }
+}
+extern "C" int fastnerf_gauss_noise(int64_t n, float std, uint64_t seed, float* out, fn_stream_t stream) {
+  FN_CHECK_ARG(n >= 0 && std >= 0.f, "n>=0, std>=0");
+  if (n == 0) return 0;
+  FN_CHECK_ARG(out && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "out: non-null, 16-byte aligned");
+  const int64_t n4 = (n + 3) / 4;
+  int64_t grid = (n4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(gauss_noise_kernel, dim3((unsigned)grid), dim3(256), 0, fn::S(stream), n4, n, std, (uint32_t)seed, (uint32_t)(seed >> 32), out);
+  FN_LAUNCH_CHECK();
+  return 0;
+}

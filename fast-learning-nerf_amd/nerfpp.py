@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .render import _Workspace, _next_seed
+from .render import _Workspace, _burn_seeds, _next_seed
 
 TINY_NUMBER = 1e-6
 HUGE_NUMBER = 1e10
@@ -317,6 +317,7 @@ class CascadeTrainer:
             self.last_depths = []      # t advance and the parameters drift by momentum)
             return torch.zeros(len(self.nets), device=self.nets[0].flat.device), target.new_zeros((0, 3))
         if n == 0:                     # an empty SHARD of a non-empty global batch: join every collective, take the common update
+            _burn_seeds(2 * len(self.nets) if self.perturb else 0)   # (the draws of the loop below: two per level)
             for m, net in enumerate(self.nets):
                 net.flat_grad.zero_()
                 if dist:

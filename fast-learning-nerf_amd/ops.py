@@ -483,6 +483,16 @@ def mse_leafmax(rgb, rgb0, target, grad_scale=1.0, want_grads=True, leaf_tag=Non
     return loss2, g, g0
 
 
+def sigma_noise(n, S0, S1, std, seed, device):
+    """(noise0 [n, S0], noise1 [n, S1] or None when S1 == 0): N(0, std^2) sigma noise of both passes of one render_rays call
+    (render.py:162), one launch into one allocation (csrc/train.hip gauss_noise_kernel)."""
+    tot0 = (n * S0 + 3) // 4 * 4          # (keeps the second view 16-byte aligned)
+    buf = torch.empty(tot0 + n * S1, device=device, dtype=torch.float32)
+    require_gpu(buf)
+    check(lib().fastnerf_gauss_noise(buf.numel(), float(std), int(seed), ptr(buf), stream()), 'fastnerf_gauss_noise')
+    return buf[:n * S0].view(n, S0), (buf[tot0:].view(n, S1) if S1 > 0 else None)
+
+
 def adam_step(params, grads, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     require_gpu(params, grads, m, v)
     check(lib().fastnerf_adam_step(params.numel(), ptr(params), ptr(grads), ptr(m), ptr(v), float(lr), float(beta1),

@@ -14,6 +14,78 @@ import torch
 import torch.distributed as dist
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpus_for_rank(node_cpus, n_sharing, position):
+    """The contiguous slice number `position` of `n_sharing` equal slices of a NUMA node's CPU list (the GPUs that hang off one node share
+    its cores evenly; SMT siblings are usually listed in the upper half, so a contiguous slice of each half stays on whole cores)."""
+    node_cpus = sorted(node_cpus)
+    if n_sharing <= 1 or len(node_cpus) < 2 * n_sharing:
+        return node_cpus
+    half = len(node_cpus) // 2
+    out = []
+    for part in (node_cpus[:half], node_cpus[half:]):
+        k = len(part) // n_sharing
+        out += part[position * k:(position + 1) * k]
+    return out or node_cpus
+
+
+def gpu_local_cpus(index):
+    """CPUs of the NUMA node GPU `index` hangs off (local_cpulist of its PCI function in sysfs -- the physical bus address, so the answer
+    does not depend on HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumbering), or None where sysfs / the property is unavailable."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        with open('/sys/bus/pci/devices/%s/local_cpulist' % bdf) as f:
+            return parse_cpulist(f.read()) or None
+    except Exception:      # noqa: BLE001  (an affinity hint, never a failure)
+        return None
+
+
+_AFFINITY = None   # what pin_to_gpu_numa_node did in this process (bench.py reports it)
+
+
+def pin_to_gpu_numa_node(index):
+    """One process per GPU: keep the rank's host threads (the step's enqueue loop, the quadtree's host side, the data-parallel progress thread)
+    on the cores next to ITS GPU.  The GPUs sharing a NUMA node split its CPU list evenly, by device order.  FASTNERF_AFFINITY=0 disables;
+    anything the kernel refuses is ignored.  Returns the CPU list set, or None."""
+    global _AFFINITY
+    if os.environ.get('FASTNERF_AFFINITY', 'auto') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    mine = gpu_local_cpus(index)
+    if not mine:
+        return None
+    sharing = [i for i in range(torch.cuda.device_count()) if gpu_local_cpus(i) == mine]
+    cpus = cpus_for_rank(mine, len(sharing), sharing.index(index) if index in sharing else 0)
+    try:
+        allowed = os.sched_getaffinity(0)
+        cpus = [c for c in cpus if c in allowed] or sorted(allowed)
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    _AFFINITY = {'device': int(index), 'numa_cpus': len(mine), 'gpus_on_node': len(sharing), 'pinned_cpus': len(cpus), 'first_cpu': cpus[0]}
+    return cpus
+
+
+def affinity_report():
+    return _AFFINITY
+
+
+def select_device(local_rank):
+    """The device of a rank: LOCAL_RANK modulo the devices this process can see.  A launcher that masks one GPU per rank
+    (HIP_VISIBLE_DEVICES=k) and one that shows all eight both work: the index is taken among the VISIBLE devices."""
+    return int(local_rank) % max(1, torch.cuda.device_count())
+
+
 def init_from_env(device_type=None):
     """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun contract).
     Returns (rank, world_size, local_rank).  No-op for a single process."""
@@ -25,7 +97,9 @@ def init_from_env(device_type=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         use_cuda = torch.cuda.is_available() if device_type is None else device_type == 'cuda'
         if use_cuda:
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+            torch.cuda.set_device(select_device(local))
+            if world <= torch.cuda.device_count():      # (ranks sharing a device -- the 1-GPU plumbing tests -- are not pinned apart)
+                pin_to_gpu_numa_node(select_device(local))
         # FASTNERF_DIST_BACKEND=gloo: plumbing tests of the multi-process path on a box with fewer GPUs than ranks
         backend = os.environ.get('FASTNERF_DIST_BACKEND', 'nccl' if use_cuda else 'gloo')
         dist.init_process_group(backend=backend, rank=rk, world_size=world)
@@ -225,6 +299,26 @@ def shard(n, rk=None, world=None):
     rk = rank() if rk is None else rk
     world = world_size() if world is None else world
     return slice(rk, n, world)
+
+
+def shard_count(n_rows, batch, rk=None, world=None):
+    """Rows of an epoch of n_rows rows that rank rk steps when every batch of `batch` consecutive rows is dealt out rk :: world (the host
+    mirror of fastnerf_epoch_shard_rows)."""
+    rk = rank() if rk is None else rk
+    world = world_size() if world is None else world
+    per = (batch - rk + world - 1) // world if batch > rk else 0
+    full, tail = divmod(int(n_rows), int(batch))
+    return full * per + ((tail - rk + world - 1) // world if tail > rk else 0)
+
+
+def shard_global_rows(n_rows, batch, rk=None, world=None):
+    """The epoch rows behind a rank's local rows, in local order (int64 numpy): what QuadTreeManager.gen_rays_device(shard=...) generates
+    and what run_nerf.train's `rays[b0 + rank : b1 : world]` slices select, batch after batch."""
+    import numpy as np
+    rk = rank() if rk is None else rk
+    world = world_size() if world is None else world
+    out = [np.arange(b0 + rk, min(b0 + batch, n_rows), world, dtype=np.int64) for b0 in range(0, int(n_rows), int(batch))]
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
 
 
 def barrier():

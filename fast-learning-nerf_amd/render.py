@@ -28,7 +28,17 @@ def _next_seed():
     seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     from . import parallel
     rk = parallel.rank()
-    return seed if rk == 0 else (seed ^ ((rk * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)))
+    if rk:
+        seed ^= (rk * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
+    return seed or 1      # (0 means "deterministic" to the samplers: never hand it out as a key)
+
+
+def _burn_seeds(k):
+    """A rank whose shard of a batch is EMPTY skips the step's kernels but must consume the host RNG exactly like the ranks that run it:
+    the redundantly drawn pixel picks of the epoch loop rely on every rank's torch CPU stream staying in step between parallel.sync_seed()
+    calls."""
+    for _ in range(int(k)):
+        _next_seed()
 
 
 def _pytest_rand(shape, device):
@@ -318,9 +328,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         if pytest:
             noise0 = _pytest_rand((n, N_samples), dev) * raw_noise_std
             noise1 = _pytest_rand((n, N_samples + N_importance), dev) * raw_noise_std
-        else:
-            noise0 = torch.randn(n, N_samples, device=dev) * raw_noise_std
-            noise1 = torch.randn(n, N_samples + N_importance, device=dev) * raw_noise_std
+        else:      # one Philox launch for both passes (the injected-tensor path above stays for pytest=True)
+            noise0, noise1 = ops.sigma_noise(n, N_samples, N_samples + N_importance if N_importance > 0 else 0, raw_noise_std, _next_seed(), dev)
     cfg = dict(rays11=rays11, net_c=net_c, net_f=net_f, N_samples=N_samples, N_importance=N_importance,
                lindisp=lindisp, perturb=perturb, white_bkgd=white_bkgd, t_rand=t_rand, u=u, noise0=noise0,
                noise1=noise1,

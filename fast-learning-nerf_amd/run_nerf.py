@@ -18,7 +18,7 @@ import torch
 
 from . import _lib, ops, parallel
 from .model import NeRF, noview_slices
-from .render import LivePolicy, _Workspace, _backward_core, _forward_core, _next_seed, render, render_path  # noqa: F401
+from .render import LivePolicy, _Workspace, _backward_core, _burn_seeds, _forward_core, _next_seed, render, render_path  # noqa: F401
 from .run_nerf_helpers import get_embedder, img2mse, mse2psnr
 from .tree import QuadTreeManager
 
@@ -256,8 +256,7 @@ class Trainer:
             rays11[:, 8:11] = 0.
         noise0 = noise1 = None
         if self.raw_noise_std > 0.:
-            noise0 = torch.randn(n, self.N_samples, device=dev) * self.raw_noise_std
-            noise1 = torch.randn(n, self.N_samples + self.N_importance, device=dev) * self.raw_noise_std
+            noise0, noise1 = ops.sigma_noise(n, self.N_samples, self.N_samples + self.N_importance, self.raw_noise_std, _next_seed(), dev)
         live = self.live.use_live(self.net_c, self.net_f, self.N_importance)
         out, saved = _forward_core(rays11, self.net_c, self.net_f, self.N_samples, self.N_importance, self.lindisp,
                                    self.perturb, self.white_bkgd, t_rand, u, noise0, noise1, save=not live,
@@ -350,8 +349,7 @@ class Trainer:
         a.u = None if u is None else u.data_ptr()
         noise0 = noise1 = None
         if self.raw_noise_std > 0.:
-            noise0 = torch.randn(n, S0, device=dev) * self.raw_noise_std
-            noise1 = torch.randn(n, S1, device=dev) * self.raw_noise_std
+            noise0, noise1 = ops.sigma_noise(n, S0, S1 if Ni > 0 else 0, self.raw_noise_std, _next_seed(), dev)
             hold += [noise0, noise1]
         a.noise0 = None if noise0 is None else noise0.data_ptr()
         a.noise1 = None if noise1 is None else noise1.data_ptr()
@@ -413,6 +411,8 @@ class Trainer:
             if n == 0:
                 # a rank whose shard of a (tail) batch is empty still joins the collective with a zero gradient
                 self.grad.zero_()
+                _burn_seeds((1 if self.raw_noise_std > 0. else 0) + (1 if (self.perturb and t_rand is None) else 0)
+                            + (1 if (self.N_importance > 0 and self.perturb and u is None) else 0))
                 loss2, out = torch.zeros(2, device=self.grad.device), {}
             else:
                 loss2, out = self.forward_backward(rays_o, rays_d, target, leaf_tag, table, max_leaves, t_rand, u, n_global)
@@ -582,12 +582,19 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
     rank, world = parallel.rank(), parallel.world_size()
     history = []
 
-    def run_batches(rays_o, rays_d, tgt, tags, decay, table, max_leaves):
-        n_total = rays_o.shape[0]
+    def run_batches(rays_o, rays_d, tgt, tags, decay, table, max_leaves, local_of=None):
+        """local_of = N: the tensors hold only THIS rank's rows of an epoch of N rows (gen_rays_device(shard=...)), batch after batch."""
+        n_total = rays_o.shape[0] if local_of is None else local_of
         it = 0
+        lo = 0
         for b0 in range(0, n_total, N_rand):
             b1 = min(b0 + N_rand, n_total)
-            sl = slice(b0 + rank, b1, world) if world > 1 else slice(b0, b1)
+            if local_of is None:
+                sl = slice(b0 + rank, b1, world) if world > 1 else slice(b0, b1)
+            else:
+                cnt = parallel.shard_count(b1 - b0, N_rand, rank, world)
+                sl = slice(lo, lo + cnt)
+                lo += cnt
             # (a rank's rows r::world of the global batch are a strided view: the kernels take contiguous buffers)
             loss2, _ = trainer.step(rays_o[sl].contiguous(), rays_d[sl].contiguous(), tgt[sl].contiguous(),
                                     leaf_tag=None if tags is None else tags[sl].contiguous(),
@@ -619,12 +626,16 @@ def train(images, poses, H, W, focal, args, near=2., far=6., device='cuda', log=
         last = epoch_id == args.n_epoch
         if last:
             mgr.epoch_size = mgr.n_images * mgr.h * mgr.w
+        # data parallel with the device generator: every rank generates ONLY the rows it steps (rows rank :: world of every batch; the seed is
+        # the same on every rank after sync_seed, and the row -> ray map is a bijection of the row index: the union is the one epoch)
+        sharded_gen = world > 1 and not compat_rng and dev.type == 'cuda'
         ro, rd, tgt = mgr.gen_rays_v3_multiThread(down_scale=1, prob=False, randSamp_proc=args.randSamp_perc,
-                                                  last_epoch=last, compat_rng=compat_rng)
+                                                  last_epoch=last, compat_rng=compat_rng,
+                                                  shard=(rank, world, N_rand) if sharded_gen else None)
         tags = mgr.result_leaf_tag
         max_leaves = mgr.max_leaves()
         table = torch.zeros(mgr.n_images * max_leaves, device=dev, dtype=torch.int32)
-        loss2, it = run_batches(ro, rd, tgt, tags, True, table, max_leaves)
+        loss2, it = run_batches(ro, rd, tgt, tags, True, table, max_leaves, local_of=mgr.epoch_rows if sharded_gen else None)
         psnr = mse2psnr(loss2[:1].cpu())
         history.append((epoch_id, it, float(loss2[0]), float(psnr[0]), time.time() - t0))
         log('epoch {}: {} iters, fine mse {:.5f} psnr {:.2f}, {:.1f}s'.format(*history[-1]) +

@@ -550,13 +550,21 @@ class QuadTreeManager:
         self._wcache = (key, tabs)
         return tabs
 
-    def gen_rays_device(self, down_scale=1, last_epoch=False, prob=False, rand=1.0, seed=None, shuffle=True, want_pix=False):
+    def gen_rays_device(self, down_scale=1, last_epoch=False, prob=False, rand=1.0, seed=None, shuffle=True, want_pix=False, shard=None):
         """The whole epoch in one launch: per-leaf counts -> prefix sums -> Philox pixel draws -> rays from the poses ->
         colour gather -> (image, leaf) tags, already in shuffled order.  Same distribution as tree.py:377-428 / 569-626
         (and nerf++-ours/tree.py:548-607 with prob=True: int(n * (1 - rand)) variance-weighted picks per leaf, the rest
         uniform); the seed comes from torch's global CPU generator unless given.  Returns (rays_o, rays_d, rgb) on the
-        device and sets result_leaf_tag (int32) / result_leaf_id (float32, lazily) / result_pix (when want_pix)."""
+        device and sets result_leaf_tag (int32) / result_leaf_id (float32, lazily) / result_pix (when want_pix).
+        shard=(rank, world, batch): only the rows this rank steps -- rows rank :: world of every batch of `batch` consecutive epoch rows
+        (parallel.shard_global_rows lists them) -- bit-identical to those rows of the unsharded call with the same seed; the epoch's total
+        row count is left in self.epoch_rows."""
         plan, N = self.epoch_plan(down_scale, last_epoch)
+        self.epoch_rows = N
+        rk, world, batch = (0, 1, max(N, 1)) if shard is None else (int(shard[0]), int(shard[1]), int(shard[2]))
+        n_out = int(lib().fastnerf_epoch_shard_rows(N, batch, rk, world))
+        if n_out < 0:
+            raise ValueError('gen_rays_device: bad shard %r' % (shard,))
         dev = self.device
         imgs, poses = self._dev()
         offs = np.zeros(plan.shape[0] + 1, dtype=np.int64)
@@ -573,14 +581,14 @@ class QuadTreeManager:
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         f32 = dict(device=dev, dtype=torch.float32)
-        ro, rd, rgb = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 3, **f32)
-        tag = torch.empty(N, 2, device=dev, dtype=torch.int32)
-        pix = torch.empty(N, 3, device=dev, dtype=torch.int32) if want_pix else None
+        ro, rd, rgb = torch.empty(n_out, 3, **f32), torch.empty(n_out, 3, **f32), torch.empty(n_out, 3, **f32)
+        tag = torch.empty(n_out, 2, device=dev, dtype=torch.int32)
+        pix = torch.empty(n_out, 3, device=dev, dtype=torch.int32) if want_pix else None
         K = self.K
-        check(lib().fastnerf_epoch_rays(N, plan.shape[0], ops.ptr(plan_d), ops.ptr(offs_d), ops.ptr(imgs.contiguous()), ops.ptr(poses.contiguous()),
-                                        self.n_images, self.h, self.w, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
-                                        int(seed), int(bool(shuffle)), *[ops.ptr(t) for t in wt], ops.ptr(ro), ops.ptr(rd), ops.ptr(rgb),
-                                        ops.ptr(tag), ops.ptr(pix), ops.stream()), 'fastnerf_epoch_rays')
+        check(lib().fastnerf_epoch_rays_shard(N, plan.shape[0], ops.ptr(plan_d), ops.ptr(offs_d), ops.ptr(imgs.contiguous()), ops.ptr(poses.contiguous()),
+                                              self.n_images, self.h, self.w, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
+                                              int(seed), int(bool(shuffle)), *[ops.ptr(t) for t in wt], batch, rk, world, ops.ptr(ro), ops.ptr(rd),
+                                              ops.ptr(rgb), ops.ptr(tag), ops.ptr(pix), ops.stream()), 'fastnerf_epoch_rays_shard')
         self.result_leaf_tag = tag
         self._tags_i32 = tag
         self._leaf_id = None
@@ -588,13 +596,15 @@ class QuadTreeManager:
         return ro, rd, rgb
 
     def gen_rays_v3_multiThread(self, down_scale=16, prob=True, randSamp_proc=0.95, debug=False, last_epoch=False,
-                                compat_rng=True):
+                                compat_rng=True, shard=None):
         """tree.py:377-428.  compat_rng=True draws pixels with torch's global CPU generator in the
         reference's exact call order (per image, per leaf: randint rows, randint cols; then one
         randperm), so a seeded run selects identical pixels; compat_rng=False generates the whole epoch
         in one device launch (gen_rays_device: same distribution).  Returns (origins, dirs, rgb) on the device."""
         if not compat_rng and self.device.type == 'cuda':
-            return self.gen_rays_device(down_scale, last_epoch, prob=prob, rand=randSamp_proc)
+            return self.gen_rays_device(down_scale, last_epoch, prob=prob, rand=randSamp_proc, shard=shard)
+        if shard is not None:
+            raise ValueError('shard= needs the device generator (compat_rng=False on a GPU): the reference-order host picks exist as a whole epoch only')
         pix = self.gen_pixels(down_scale, last_epoch, compat_rng, prob=prob, rand=randSamp_proc)
         self.result_leaf_tag = self._tags_i32.to(self.device).contiguous()
         return self.gather(pix)

@@ -275,6 +275,21 @@ int fastnerf_epoch_rays(int64_t N, int L, const int32_t* plan, const int64_t* of
                         uint64_t seed, int shuffle, const int32_t* n_weighted, const int64_t* seg_beg,
                         const int64_t* seg_end, const int32_t* order, const double* cum, float* rays_o, float* rays_d,
                         float* rgb, int32_t* tag, int32_t* pix, fn_stream_t stream);
+/* One rank's rows of the same epoch (data parallel): the reference cuts the shuffled epoch into batches of `batch` = N_rand
+ * consecutive rows (run_nerf.py:472-478); rank row0 of `stride` ranks steps rows row0 :: stride of every batch.  Only those rows are
+ * generated -- output row r = epoch row (r / per) * batch + row0 + (r % per) * stride, per = ceil((batch - row0) / stride) -- bit-identical to
+ * the corresponding rows of fastnerf_epoch_rays with the same seed (the row -> ray map is a keyed bijection of the row index).
+ * fastnerf_epoch_shard_rows: the number of output rows (host arithmetic; -1 on bad arguments). */
+int64_t fastnerf_epoch_shard_rows(int64_t N, int64_t batch, int row0, int stride);
+int fastnerf_epoch_rays_shard(int64_t N, int L, const int32_t* plan, const int64_t* offs, const float* images,
+                              const float* poses, int n_img, int H, int W, float fx, float fy, float cx, float cy,
+                              uint64_t seed, int shuffle, const int32_t* n_weighted, const int64_t* seg_beg,
+                              const int64_t* seg_end, const int32_t* order, const double* cum, int64_t batch, int row0, int stride,
+                              float* rays_o, float* rays_d, float* rgb, int32_t* tag, int32_t* pix, fn_stream_t stream);
+
+/* sigma noise (render.py:162, `torch.randn(raw[..., 3].shape) * raw_noise_std`): out[0..n) = N(0, std^2) draws of a Philox4x32-10 stream keyed
+ * by seed (Box-Muller), one launch for the noise of both passes of a render_rays call.  out must be 16-byte aligned. */
+int fastnerf_gauss_noise(int64_t n, float std, uint64_t seed, float* out, fn_stream_t stream);
 
 /* ---- exact zero-gradient point compaction of the training backward -------------------------------------------
  * loss.backward() (run_nerf.py:493) spends most of its time on samples whose d(loss)/d(raw) is exactly zero

@@ -40,7 +40,13 @@ def _worst_case_record(world=8):
         'siblings_summary': {'ms_per_step': {'fp32': 30.713, 'bf16x3': 12.582, 'drop_in_bf16x6': 18.999},
                              'sparse_scene_bf16x6': {'ms_per_step': 9.123, 'rays_per_s': 449000, 'live_fine': 0.1821, 'plain_ms': 19.012},
                              'configs_rays_per_s': {'configs[2]': 230377, 'configs[3]': 289625, 'configs[4]': 102061},
-                             'inference_rays_per_s': 777496},
+                             'inference_rays_per_s': 777496,
+                             'batch_ms': {'512': 2.539, '1024': 4.706, '1920': 8.640, '4096': 17.891},
+                             'batch_frac_of_4096_rate': {'512': 0.881, '1024': 0.950, '1920': 0.971, '4096': 1.0}, 'predicted_strong_8': 6.78},
+        'scaling_weak': None if world == 1 else {'rays_per_gpu_per_step': 4096, 'rays_per_step': 4096 * world, 'ms_per_step': 18.612345678,
+                                                 'value': 1760987.654321, 'unit': 'rays/s', 'steps': 20, 'warmup': 5, 'note': long},
+        'scaling_strong': None if world == 1 else {'rays_per_gpu_per_step': 4096 // world, 'rays_per_step': 4096, 'ms_per_step': 2.712345678,
+                                                   'value': 1510123.456789, 'unit': 'rays/s', 'steps': 20, 'warmup': 5, 'note': long},
         'errors': ['configs[2]: RuntimeError: ' + long] * 6,
         'full_record': ['bench_full.json', 'gpurun_out/bench_full.json'],
         'other_configs': {'configs[2]_quadtree': {'workload': long * 8}}, 'psnr_vs_cpu': {'gpu': {'bf16x6': {}}, 'note': long * 4},
@@ -56,6 +62,13 @@ def test_headline_is_short_and_complete():
         for k in CONTRACT_KEYS:
             assert k in h, k
         assert h['n_gpus'] == world and h['dtype'] == 'f32' and h['value'] == out['value']
+        if world > 1:      # --scaling both (the default on several GPUs): both curves' points of this N ride in the ONE line, parseable
+            back = json.loads(line)
+            assert back['scaling'] == 'weak' and back['scaling_weak']['value'] == out['scaling_weak']['value']
+            assert back['scaling_strong']['rays_per_gpu_per_step'] == 4096 // world and back['scaling_strong']['rays_per_step'] == 4096
+            assert back['scaling_strong']['value'] == out['scaling_strong']['value'] and back['scaling_strong']['ms_per_step'] > 0
+        else:
+            assert 'scaling_weak' not in h and 'scaling_strong' not in h
         r = h['roofline']
         assert r['bound'] == 'mfma' and r['frac'] == out['roofline']['frac'] and r['achieved'] > 0 and r['peak'] > 0
         assert r['traffic'] == out['roofline']['traffic'] and r['avg_launch_ms'] > 0 and r['flop_per_launch'] > 0

@@ -175,3 +175,30 @@ def test_epoch_generation_at_full_scale(fn, capsys):
     with capsys.disabled():
         print('\nEPOCHGEN 100x800x800 depth 7: %d rays in %.3f s (%.1f M rays/s)' % (ro.shape[0], dt, ro.shape[0] / dt / 1e6))
     assert dt < 5.0
+
+
+def test_a_ranks_rows_equal_the_rows_of_the_whole_epoch(fn):
+    """SURVEY 8(e) / VERDICT r5 item 7a: in a data-parallel run every rank generates ONLY the rows it steps (rows rank :: world of every
+    batch of N_rand consecutive epoch rows).  With the same seed they are bit for bit the corresponding rows of the unsharded launch
+    (the row -> ray map is a keyed bijection of the epoch row), for uniform and for variance-weighted picks, N_rand not a multiple of the
+    world, a short last batch, and a world larger than a batch."""
+    from fastnerf import parallel
+    rng = np.random.RandomState(2)
+    sharp = [np.abs(rng.randn(64, 48)) ** 2 * 0.05 for _ in range(3)]          # variance maps as an input fixture (prob=True picks)
+    mgr = _mgr(fn, n=3, H=64, W=48, depth=2, sharp=sharp)[0]
+    _refine(mgr)
+    for prob, rand in ((False, 1.0), (True, 0.5)):
+        full = mgr.gen_rays_device(down_scale=1, prob=prob, rand=rand, seed=1234, want_pix=True)
+        full_tag, full_pix, N = mgr.result_leaf_tag.clone(), mgr.result_pix.clone(), mgr.epoch_rows
+        assert full[0].shape[0] == N
+        for world, batch in ((8, 1920), (2, 1000), (8, 5)):
+            seen = 0
+            for rk in range(world):
+                part = mgr.gen_rays_device(down_scale=1, prob=prob, rand=rand, seed=1234, want_pix=True, shard=(rk, world, batch))
+                rows = torch.from_numpy(parallel.shard_global_rows(N, batch, rk, world)).cuda()
+                assert part[0].shape[0] == rows.numel() and mgr.epoch_rows == N
+                for a, b in zip(part, full):
+                    assert torch.equal(a, b[rows])
+                assert torch.equal(mgr.result_leaf_tag, full_tag[rows]) and torch.equal(mgr.result_pix, full_pix[rows])
+                seen += rows.numel()
+            assert seen == N

@@ -65,7 +65,7 @@ def test_bench_two_ranks(scaling, launcher, tmp_path):
     assert j['psnr'] is None and j['siblings'] is None and full['psnr_vs_cpu'] is None and full['drop_in_route'] is None  # 1-GPU legs
 
 
-@pytest.mark.parametrize('scaling', ['strong', 'weak'])
+@pytest.mark.parametrize('scaling', ['strong', 'both'])
 def test_bench_eight_ranks_on_what_the_box_has(scaling, tmp_path):
     """Multi-GPU readiness without the hardware: the BARE `python bench.py --gpus 8 ...` (no launcher: bench.py re-executes itself under
     torch.distributed.run; a harness that starts N=8 the way it starts N=1 must not die on an assert).  On a box with fewer
@@ -80,13 +80,21 @@ def test_bench_eight_ranks_on_what_the_box_has(scaling, tmp_path):
         env['FASTNERF_DIST_BACKEND'] = 'gloo'
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
+    # 'both' is what the bare driver command gets (--scaling auto -> both on several GPUs): `value` is the weak leg, both curves' points ride along
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--sustained-steps', '0',
-           '--scaling', scaling, '--full-out', os.path.join(str(tmp_path), 'full.json')]
+           '--full-out', os.path.join(str(tmp_path), 'full.json')] + (['--scaling', scaling] if scaling != 'both' else [])
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     j = _headline(out.stdout)
-    per_gpu = 4096 if scaling == 'weak' else 512
-    assert j['n_gpus'] == 8 and j['scaling'] == scaling and j['config']['parallelism'] == 'dp8'
+    per_gpu = 512 if scaling == 'strong' else 4096
+    assert j['n_gpus'] == 8 and j['scaling'] == ('strong' if scaling == 'strong' else 'weak') and j['config']['parallelism'] == 'dp8'
+    if scaling == 'both':
+        w, st = j['scaling_weak'], j['scaling_strong']
+        assert w['value'] == j['value'] and w['rays_per_gpu_per_step'] == 4096 and w['rays_per_step'] == 8 * 4096
+        assert st['rays_per_gpu_per_step'] == 512 and st['rays_per_step'] == 4096 and st['value'] > 0
+        assert abs(st['value'] - 4096 * 2 / (st['ms_per_step'] * 2e-3)) < 1e-6 * st['value']
+    else:
+        assert 'scaling_weak' not in j and 'scaling_strong' not in j
     assert j['config']['rays_per_gpu_per_step'] == per_gpu and j['config']['rays_per_step'] == 8 * per_gpu
     assert len(j['per_rank_ms_per_step']) == 8 and all(x > 0 for x in j['per_rank_ms_per_step'])
     assert abs(j['value'] - 8 * per_gpu * 2 / (j['ms_per_step'] * 2e-3)) < 1e-6 * j['value']

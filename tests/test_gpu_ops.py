@@ -251,3 +251,25 @@ def test_mse_leafmax_and_adam(fn):
         opt.step([gr])
         fn.ops.adam_step(pg, gr.cuda(), m, v, 5e-4, step)
     ok, e = close(pg, opt.params[0], 1e-7, 1e-6); assert ok, e
+
+
+def test_sigma_noise_is_one_philox_launch(fn):
+    """render.py:162 `noise = torch.randn(raw[..., 3].shape) * raw_noise_std`: ops.sigma_noise fills the noise of both passes in one launch.
+    N(0, std^2) to sampling accuracy (mean, variance, fourth moment, tails), a function of the seed alone, no repeated values between the
+    passes, odd sizes complete."""
+    n, S0, S1 = 4096, 64, 192
+    a0, a1 = fn.ops.sigma_noise(n, S0, S1, 2.0, 77, torch.device('cuda'))
+    b0, b1 = fn.ops.sigma_noise(n, S0, S1, 2.0, 77, torch.device('cuda'))
+    c0, _ = fn.ops.sigma_noise(n, S0, S1, 2.0, 78, torch.device('cuda'))
+    assert a0.shape == (n, S0) and a1.shape == (n, S1) and a0.is_contiguous() and a1.is_contiguous()
+    assert torch.equal(a0, b0) and torch.equal(a1, b1) and not torch.equal(a0, c0)
+    x = torch.cat([a0.reshape(-1), a1.reshape(-1)]).double() / 2.0
+    N = x.numel()
+    assert abs(float(x.mean())) < 5.0 / N ** 0.5 and abs(float(x.var()) - 1.0) < 5.0 * (2.0 / N) ** 0.5
+    assert abs(float((x ** 4).mean()) - 3.0) < 5.0 * (96.0 / N) ** 0.5 and torch.isfinite(x).all()
+    assert 3.5 < float(x.abs().max()) < 6.5 and abs(float((x.abs() > 1.96).double().mean()) - 0.05) < 2e-3
+    assert len(torch.unique(x[:100000])) > 99000
+    o0, o1 = fn.ops.sigma_noise(3, 5, 7, 1.0, 5, torch.device('cuda'))      # 15 + 21 values, the second view starts at a multiple of 4
+    assert o0.shape == (3, 5) and o1.shape == (3, 7) and torch.isfinite(o0).all() and torch.isfinite(o1).all() and float(o1.abs().min()) > 0
+    z0, z1 = fn.ops.sigma_noise(4, 8, 0, 1.0, 5, torch.device('cuda'))
+    assert z1 is None and z0.shape == (4, 8)

@@ -62,7 +62,7 @@ def test_psnr_at_equal_iterations(fn, math_mode):
     assert abs(tr.lr - opt.lr * 0 - O.lr_schedule(5e-4, 500, n_iters - 1)) < 1e-12
 
 
-def test_psnr_300_iterations_both_modes(fn):
+def _psnr_300_iterations(fn, n_seeds, study):
     """Long-horizon equivalence of the math modes: 300 optimisation steps on the synthetic scene, identical batches and
     injected randoms.  north_star: PSNR within 0.1 dB at equal iteration count.
 
@@ -79,7 +79,7 @@ def test_psnr_300_iterations_both_modes(fn):
     rd_all = torch.stack([r[1] for r in rays], 0).reshape(-1, 3).cuda()
     tgt_all = imgs.reshape(-1, 3).cuda()
     n_iters, n_prefix, N = 300, 40, 192       # (at 60 iterations single seeds are already 0.3 dB apart)
-    n_seeds, n_full = 128, 4                  # seeds 0..3 additionally run the compacted backward and the CPU oracle's prefix
+    n_full = 4                                # seeds 0..3 additionally run the compacted backward and the CPU oracle's prefix
     old, old_c = fn.ops.get_math(), fn.render.get_compact()
     keys = ('fp32', 'bf16x3', 'bf16x6', 'fp32_compacted', 'bf16x3_compacted')
     psnr = {k: [] for k in keys + ('oracle_prefix',) + tuple(k + '_prefix' for k in keys)}
@@ -137,8 +137,11 @@ def test_psnr_300_iterations_both_modes(fn):
     se = float(np.std(d, ddof=1) / np.sqrt(len(d)))
     print('PSNR300 modes: %d of %d seeds train in both modes; mean fp32 %.3f, mean bf16x3 %.3f, mean per-seed difference %+.3f dB, '
           'per-seed std %.3f, standard error %.3f' % (len(d), n_seeds, a32[ok].mean(), a16[ok].mean(), float(d.mean()), float(np.std(d, ddof=1)), se))
-    assert se < 0.045, se                                                    # the comparison has the power to see 0.1 dB (2.2 standard errors) ...
-    assert abs(float(d.mean())) < 0.1, (float(d.mean()), se)                 # ... and the modes agree within it (north_star)
+    if study:
+        assert se < 0.045, se                                                # the comparison has the power to see 0.1 dB (2.2 standard errors) ...
+        assert abs(float(d.mean())) < 0.1, (float(d.mean()), se)             # ... and the modes agree within it (north_star)
+    else:
+        assert abs(float(d.mean())) < 0.1 + 2.0 * se, (float(d.mean()), se)  # regression form: a bias of the north_star's size would show
     # the headline arithmetic (bf16x6) against the fp32 FMA chain, same seeds, same statistic
     ok6 = (a32 > 20) & (a6 > 20)
     assert ok6.sum() >= 0.7 * n_seeds and abs(int((a32 > 20).sum()) - int((a6 > 20).sum())) <= 3, (int((a32 > 20).sum()), int((a6 > 20).sum()))
@@ -146,13 +149,30 @@ def test_psnr_300_iterations_both_modes(fn):
     se6 = float(np.std(d6, ddof=1) / np.sqrt(len(d6)))
     print('PSNR300 bf16x6 - fp32: %d seeds, mean per-seed difference %+.3f dB, per-seed std %.3f, standard error %.3f' % (
         len(d6), float(d6.mean()), float(np.std(d6, ddof=1)), se6))
-    assert se6 < 0.045, se6
-    assert abs(float(d6.mean())) < 0.1, (float(d6.mean()), se6)
+    if study:
+        assert se6 < 0.045, se6
+        assert abs(float(d6.mean())) < 0.1, (float(d6.mean()), se6)
+    else:
+        assert abs(float(d6.mean())) < 0.1 + 2.0 * se6, (float(d6.mean()), se6)
     for k in keys:                                                           # vs the oracle, on its prefix (before the divergence)
         assert abs(float(np.mean(psnr[k + '_prefix'][:n_full])) - m['oracle_prefix']) < 0.1, (k, m)
     # the noise floor: same arithmetic, other summation grouping (one seed moves by up to 0.4 dB, the 4-seed mean by 0.12-0.15 dB)
     for base in ('fp32', 'bf16x3'):
         assert abs(float(np.mean(psnr[base + '_compacted'])) - float(np.mean(psnr[base][:n_full]))) < 0.3, m
+
+
+def test_psnr_300_iterations_both_modes(fn):
+    """The regression form of _psnr_300_iterations: 32 seeds per mode (~40 s): collapse counts agree, the mean per-seed difference between the
+    modes is within 0.1 dB + 2 standard errors, every mode follows the CPU oracle on its 40-iteration prefix, the compacted backward stays
+    inside the noise floor.  The 128-seed study with the power to see 0.1 dB is test_psnr_300_iterations_study (`-m "gpu and slow"`)."""
+    _psnr_300_iterations(fn, 32, False)
+
+
+@pytest.mark.slow
+def test_psnr_300_iterations_study(fn):
+    """128 seeds per mode (~2.5 minutes): standard error of the mean per-seed difference < 0.045 dB, |mean| < 0.1 dB (VERDICT r5 item 3:
+    a statistical study is not a regression test)."""
+    _psnr_300_iterations(fn, 128, True)
 
 
 def test_psnr_vs_cpu_at_the_baseline_shape(fn, request):
@@ -385,6 +405,9 @@ def _g23(fn, golden_dir, n_seeds, members):
         fn.ops.set_math(old)
         fn.render.set_compact(old_c)
     res = []
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir) and members > 1:      # (the study's GPU side for profiles/r06_psnr_null.md; not part of the test)
+        np.savez(os.path.join(out_dir, 'g23_gpu_bf16x6.npz'), seeds=np.array(seeds)[use], train=g[:, :, 0], held=g[:, :, 1])
     for k, (name, cv) in enumerate((('train', z['train_psnr_db'][use]), ('held-out', z['held_out_psnr_db'][use]))):
         alive_c = cv > 15.0
         assert ((g[:, 0, k] > 15.0) == alive_c).all(), (name, g[:, 0, k].tolist(), cv.tolist())

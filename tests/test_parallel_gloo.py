@@ -110,6 +110,18 @@ def _worker(rank, world, port, q):
     np.random.seed(5 + rank)
     seed = parallel.sync_seed()
     draws = (torch.randint(0, 10 ** 9, (4,)).tolist(), np.random.randint(0, 10 ** 9, 4).tolist(), int(seed))
+    # the epoch's rows dealt out batch by batch (run_nerf.train with the device generator: every rank generates ONLY its rows): the ranks'
+    # global-row lists, gathered, are a partition of the epoch, each equals the strided slices of the unsharded loop, and the C ABI's host
+    # arithmetic (fastnerf_epoch_shard_rows) counts them -- an epoch of 10 007 rows in batches of 1920 (lego.txt:16; not a multiple of 8)
+    from fastnerf import _lib
+    Nrows, batch = 10007, 1920
+    mine = parallel.shard_global_rows(Nrows, batch)
+    want = np.concatenate([np.arange(b0 + rank, min(b0 + batch, Nrows), world) for b0 in range(0, Nrows, batch)])
+    same = same and np.array_equal(mine, want) and len(mine) == parallel.shard_count(Nrows, batch) == int(
+        _lib.lib().fastnerf_epoch_shard_rows(Nrows, batch, rank, world))
+    box = [None] * world
+    torch.distributed.all_gather_object(box, mine.tolist())
+    same = same and sorted(i for part in box for i in part) == list(range(Nrows))
     parallel.barrier()
     q.put((rank, err, bool(same), n_local, draws))
     torch.distributed.destroy_process_group()
@@ -144,3 +156,25 @@ def test_shard_covers_batch():
         for world in (1, 2, 8):
             idx = sorted(i for r in range(world) for i in range(n)[parallel.shard(n, r, world)])
             assert idx == list(range(n))
+
+
+def test_affinity_helpers_and_shard_arithmetic():
+    """The host-side pieces of the multi-GPU hardening that need no GPU: sysfs cpulist parsing, the even split of a NUMA node's CPUs among
+    the GPUs that share it, and the shard row arithmetic against brute force (incl. batches smaller than the world)."""
+    sys.path.insert(0, ROOT)
+    from fastnerf import _lib, parallel
+    assert parallel.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11] and parallel.parse_cpulist('') == []
+    node = list(range(0, 32)) + list(range(128, 160))      # 32 cores + their SMT siblings
+    parts = [parallel.cpus_for_rank(node, 4, k) for k in range(4)]
+    assert sorted(c for p in parts for c in p) == node and all(len(p) == 16 for p in parts)
+    assert parts[1] == list(range(8, 16)) + list(range(136, 144))
+    assert parallel.cpus_for_rank([3, 1, 2], 1, 0) == [1, 2, 3] and parallel.cpus_for_rank([0, 1], 4, 3) == [0, 1]
+    assert parallel.affinity_report() is None and parallel.select_device(5) == 5 % max(1, torch.cuda.device_count())
+    for n, batch, world in ((0, 4, 2), (5, 1920, 8), (10007, 1920, 8), (4096, 4096, 8), (4097, 1024, 3), (100, 3, 8)):
+        got = []
+        for rk in range(world):
+            rows = parallel.shard_global_rows(n, batch, rk, world)
+            assert len(rows) == parallel.shard_count(n, batch, rk, world) == int(_lib.lib().fastnerf_epoch_shard_rows(n, batch, rk, world))
+            got += rows.tolist()
+        assert sorted(got) == list(range(n))
+    assert int(_lib.lib().fastnerf_epoch_shard_rows(10, 4, 2, 2)) == -1      # row0 must be below the stride
