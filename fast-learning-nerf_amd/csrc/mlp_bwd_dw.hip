@@ -551,14 +551,25 @@ __global__ void __launch_bounds__(256) reduce_all_kernel(RedTable tab, const flo
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(e / sg.cols), c = (int)(e % sg.cols);
     if (c >= sg.valid_cols) continue;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int w = 0;
-    for (; w + 8 <= sg.nwg; w += 8) {
+    // sixteen running sums (chunk w goes to sum w mod 16), combined pairwise: a fixed order that depends on the chunk count alone, and sixteen
+    // independent loads in flight per lane -- the kernel is a chain of dependent HBM round trips, not a bandwidth problem (round 6; it was
+    // 5 % of the 512-ray step)
+    float a[16];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
+    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+    int w = 0;
+    for (; w + 16 <= sg.nwg; w += 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
     }
-    for (; w < sg.nwg; ++w) a[0] += src[(int64_t)w * sg.wg_stride + e];
-    grads[sg.dst + (int64_t)r * sg.ld + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+#pragma unroll
+    for (int i = 0; i < 15; ++i)      // (the tail: chunk counts are multiples of ncu / 8, the head-gradient grid of 1024 -- normally empty)
+      if (w + i < sg.nwg) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+      for (int i = 0; i < h; ++i) a[i] += a[i + h];
+    grads[sg.dst + (int64_t)r * sg.ld + c] = a[0];
   }
 }
 
@@ -753,7 +764,7 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
     add_seg(T, hb, 388, hg, 1, 388, L.RW, 388, 387);   // dWr (384) + dbr (3), contiguous in every layout
     add_seg(T, hb + 387, 388, hg, 1, 1, L.AB, 1, 1);   // dba
   }
-  hipLaunchKernelGGL(reduce_all_kernel, dim3(64, T.n), dim3(256), 0, st, T, partial, grads, P, live_cnt, ncu);
+  hipLaunchKernelGGL(reduce_all_kernel, dim3(256, T.n), dim3(256), 0, st, T, partial, grads, P, live_cnt, ncu);   // (256 x 256 threads: one element of a 256 x 256 segment per lane)
   FN_LAUNCH_CHECK();
   return 0;
 }

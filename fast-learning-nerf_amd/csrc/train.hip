@@ -8,29 +8,30 @@
 // torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) run_nerf.py:99,494.
 #include "common.h"
 
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#define MSE_THREADS 1024   // 16 waves: a training batch (<= 64 k rays) is reduced by ONE workgroup (bit-reproducible loss) in n / 1024 rounds
+__device__ __forceinline__ float block_sum(float v, float* red) {      // fixed order: wave butterflies, then the 16 wave sums pairwise
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) red[w] = v;
   __syncthreads();
-  float t = (threadIdx.x < 4) ? red[threadIdx.x] : 0.f;
+  float t = (threadIdx.x < MSE_THREADS / 64) ? red[threadIdx.x] : 0.f;
   if (w == 0) {
-    t += __shfl_xor(t, 1, 64);
-    t += __shfl_xor(t, 2, 64);
+#pragma unroll
+    for (int o = 1; o < MSE_THREADS / 64; o <<= 1) t += __shfl_xor(t, o, 64);
   }
   __syncthreads();
   return t;  // valid in thread 0
 }
 
-__global__ void __launch_bounds__(256) mse_leafmax_kernel(int64_t n, const float* __restrict__ rgb,
+__global__ void __launch_bounds__(MSE_THREADS) mse_leafmax_kernel(int64_t n, const float* __restrict__ rgb,
                                                            const float* __restrict__ rgb0,
                                                            const float* __restrict__ target, float gscale,
                                                            float inv_count, float* __restrict__ g_rgb,
                                                            float* __restrict__ g_rgb0, float* __restrict__ loss2,
                                                            const int32_t* __restrict__ tag, int max_leaves,
                                                            uint32_t* __restrict__ table) {
-  __shared__ float red[4];
+  __shared__ float red[MSE_THREADS / 64];
   float se = 0.f, se0 = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float emax = 0.f;
@@ -52,11 +53,16 @@ __global__ void __launch_bounds__(256) mse_leafmax_kernel(int64_t n, const float
       atomicMax(table + slot, __float_as_uint(emax));
     }
   }
-  const float s = block_sum_256(se, red);
-  const float s0 = block_sum_256(se0, red);
+  const float s = block_sum(se, red);
+  const float s0 = block_sum(se0, red);
   if (threadIdx.x == 0 && loss2) {
-    atomicAdd(loss2 + 0, s * inv_count);
-    atomicAdd(loss2 + 1, s0 * inv_count);
+    if (gridDim.x == 1) {      // the whole batch in this workgroup: plain stores, no memset before the launch
+      loss2[0] = s * inv_count;
+      loss2[1] = s0 * inv_count;
+    } else {
+      atomicAdd(loss2 + 0, s * inv_count);
+      atomicAdd(loss2 + 1, s0 * inv_count);
+    }
   }
 }
 
@@ -99,14 +105,14 @@ extern "C" int fastnerf_mse_leafmax(int64_t n, const float* rgb, const float* rg
                                     const int32_t* leaf_tag, int max_leaves, uint32_t* table, fn_stream_t stream) {
   FN_CHECK_ARG(n > 0 && rgb && target, "n>0 and non-null rgb/target");
   FN_CHECK_ARG(!(table && !leaf_tag) && (!table || max_leaves > 0), "table needs leaf_tag and max_leaves>0");
-  if (loss2) FN_HIP(hipMemsetAsync(loss2, 0, 2 * sizeof(float), fn::S(stream)));
   // up to 64 k rays (every training batch) one workgroup does the whole reduction, so the reported losses are
   // bit-reproducible like the parameters; beyond that the block sums meet in fp32 atomics (last-bit order dependent)
-  int64_t g = (n <= 65536) ? 1 : (n + 255) / 256;
+  int64_t g = (n <= 65536) ? 1 : (n + MSE_THREADS - 1) / MSE_THREADS;
   if (g > 1024) g = 1024;
+  if (loss2 && g > 1) FN_HIP(hipMemsetAsync(loss2, 0, 2 * sizeof(float), fn::S(stream)));
   const float inv_count = (float)(1.0 / (3.0 * (double)n));
   const float gscale = (float)(2.0 / (3.0 * (double)n) * (double)grad_scale);
-  hipLaunchKernelGGL(mse_leafmax_kernel, dim3((int)g), dim3(256), 0, fn::S(stream), n, rgb, rgb0, target, gscale,
+  hipLaunchKernelGGL(mse_leafmax_kernel, dim3((int)g), dim3(MSE_THREADS), 0, fn::S(stream), n, rgb, rgb0, target, gscale,
                      inv_count, g_rgb, g_rgb0, loss2, leaf_tag, max_leaves, table);
   FN_LAUNCH_CHECK();
   return 0;
