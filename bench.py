@@ -75,6 +75,11 @@ MAC_PER_POINT_BG = MAC_PER_POINT + 2 * 21 * 256   # nerf++ background MLPNet: 84
 # measured ceiling of a bare v_mfma_f32_32x32x16_bf16 stream on uniform(-1, 1) data (tools/micro/mfma_power.hip, gap_probe.hip:
 # 1848 - 1871 TFLOP/s issued at the 1.79 GHz the power management grants it) -- a REPO CONSTANT from earlier runs, not measured here
 BF16_MFMA_REAL_DATA_TFLOPS = 1871.0
+# the same kind of ceiling for the instruction the bf16x6 forward / dX actually issue since round 4, v_mfma_f32_16x16x32_bf16 with two waves per
+# SIMD on random bf16 data: 2244 TFLOP/s issued against 1991 - 2002 for the 32x32x16 shape in the same call (tools/micro/mfma_shapes.hip,
+# profiles/r04_power_limit.md section 5) -- also a REPO CONSTANT.  frac_of_measured_peak keeps the 32x32x16 figure (the dW kernels' shape and the
+# comparison of rounds 3 - 5); frac_of_measured_peak_16x16x32 is the stricter one for the dominant kernel
+BF16_MFMA_16X16X32_RANDOM_DATA_TFLOPS = 2244.0
 PAIRED_PSNR_NOTE = 'tests/test_gpu_train.py::test_psnr_paired_study_g22 (profiles/r05_psnr_paired.md), null: profiles/r06_psnr_null.md'
 
 
@@ -107,7 +112,7 @@ def headline_record(out):
         r['traffic_source'] = _short(roof.get('traffic_source', ''), 110)
         if roof.get('step_traffic'):
             r['step_hbm_bytes'] = roof['step_traffic'].get('hbm_bytes_per_step')
-        for k in ('frac_of_measured_peak',):
+        for k in ('frac_of_measured_peak', 'frac_of_measured_peak_16x16x32'):
             if k in roof:
                 r[k] = roof[k]
         r['launches_ms'] = {_short(x['kernel'], 40): round(x['avg_launch_ms'], 4) for x in roof.get('launches', [])[:3]}
@@ -595,6 +600,8 @@ def main():
             roof['peak_measured_real_data'] = BF16_MFMA_REAL_DATA_TFLOPS / n_prod
             roof['peak_measured_real_data_source'] = 'REPO CONSTANT (tools/micro/mfma_power.hip on an earlier box), not measured in this run'
             roof['frac_of_measured_peak'] = dom['achieved'] / (BF16_MFMA_REAL_DATA_TFLOPS / n_prod)
+            if mode == 'bf16x6':
+                roof['frac_of_measured_peak_16x16x32'] = dom['achieved'] / (BF16_MFMA_16X16X32_RANDOM_DATA_TFLOPS / n_prod)
         return roof
 
     def launch_roofline(kernel, what, fn_, flop, mode):
