@@ -551,22 +551,22 @@ __global__ void __launch_bounds__(256) reduce_all_kernel(RedTable tab, const flo
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(e / sg.cols), c = (int)(e % sg.cols);
     if (c >= sg.valid_cols) continue;
-    // sixteen running sums (chunk w goes to sum w mod 16), combined pairwise: a fixed order that depends on the chunk count alone, and sixteen
-    // independent loads in flight per lane -- the kernel is a chain of dependent HBM round trips, not a bandwidth problem (round 6; it was
-    // 5 % of the 512-ray step)
-    float a[16];
+    // RS running sums (chunk w goes to sum w mod RS), combined pairwise: a fixed order that depends on the chunk count alone, and RS independent
+    // loads in flight per lane -- the kernel is a chain of dependent HBM round trips, not a bandwidth problem (round 6; it was 5 % of the 512-ray step)
+    constexpr int RS = 16;      // (32 measured 6x SLOWER: 46 -> 277 us at 512 rays -- the loads of a round no longer issue back to back)
+    float a[RS];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+    for (int i = 0; i < RS; ++i) a[i] = 0.f;
     int w = 0;
-    for (; w + 16 <= sg.nwg; w += 16) {
+    for (; w + RS <= sg.nwg; w += RS) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
+      for (int i = 0; i < RS; ++i) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
     }
 #pragma unroll
-    for (int i = 0; i < 15; ++i)      // (the tail: chunk counts are multiples of ncu / 8, the head-gradient grid of 1024 -- normally empty)
+    for (int i = 0; i < RS - 1; ++i)      // (the tail: chunk counts are multiples of ncu / 8, the head-gradient grid of 1024 -- normally empty)
       if (w + i < sg.nwg) a[i] += src[(int64_t)(w + i) * sg.wg_stride + e];
 #pragma unroll
-    for (int h = 8; h >= 1; h >>= 1)
+    for (int h = RS / 2; h >= 1; h >>= 1)
 #pragma unroll
       for (int i = 0; i < h; ++i) a[i] += a[i + h];
     grads[sg.dst + (int64_t)r * sg.ld + c] = a[0];
