@@ -687,7 +687,8 @@ static int bwd_launch_t(int kind, int64_t n, int S, const float* draw, const flo
   // L0 (+ L5's pe part in the same job under MM_X6: one read and one split of the positional encoding for both;
   //     8 waves x (64 outputs x all pe tiles), partials [512][pe] + bias [256] across the neighbouring regions of jobs 0 and 8)
   if constexpr (MW == MM_X6) {
-    if (PEP == 64) rc = launch_dw<8, 1, 2, 2, true, false, MW, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
+    // (16 waves x one X tile each for the 64-channel encoding: 225 us against 243 for 8 waves x both tiles, 326 for 4 waves -- the job is HBM-latency-bound, more waves in flight win; `tools/ab_kstats.sh`, round 6)
+    if (PEP == 64) rc = launch_dw<8, 2, 2, 1, true, false, MW, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 64, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
     else rc = launch_dw<8, 1, 2, 3, true, false, MW, 0, 8>(P, dact + dact_y(P, 0), 256, a_pe, 96, nullptr, region(0), nwg, st, live_idx, live_cnt, nullptr, dact + dact_y(P, 5));
     if (rc) return rc;
     const int64_t b0 = dw_job_base(0, ncu, PEP);
