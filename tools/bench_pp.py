@@ -1,4 +1,4 @@
-"""nerf++ (BASELINE configs[4]) cascade step throughput on one GPU, both math modes: 2 levels x (fg + bg) nets,
+"""nerf++ (BASELINE configs[4]) cascade step throughput on one GPU, every math mode (or those named after N): 2 levels x (fg + bg) nets,
 64 / 128 samples, synthetic cameras inside the unit sphere.  Not the headline bench (bench.py is); DESIGN.md cites it."""
 import sys, time, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -6,7 +6,7 @@ import fastnerf as fn
 from fastnerf import ops, nerfpp
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 dev = torch.device('cuda')
-for mode in (sys.argv[2:] or ['fp32', 'bf16x3']):
+for mode in (sys.argv[2:] or ['bf16x6', 'fp32', 'bf16x3']):
     ops.set_math(mode)
     torch.manual_seed(0)
     nets = [nerfpp.NerfNet(device=dev) for _ in range(2)]
