@@ -40,6 +40,11 @@ def main():
     ap.add_argument('--quantile', type=float, default=0.5)
     ap.add_argument('--thres', type=float, default=1e-3, help='subdivide_thres (lego.txt: 1e-3); 0: calibrate at the first adjust (--quantile)')
     ap.add_argument('--check-images', type=int, default=2)
+    ap.add_argument('--full', action='store_true', help='NO sub-sampling: every batch of every epoch is trained (the reference\'s run; ~1 GPU-hour)')
+    ap.add_argument('--always-split', action='store_true', help='the NON-adaptive member of the pair: thres -1, every finest leaf splits at every adjust, every epoch is every pixel')
+    ap.add_argument('--eval-views', type=int, default=0, help='after training: PSNR of this many HELD-OUT full-resolution views (cameras half-way between training views, '
+                    'another elevation) through render() with the test kwargs')
+    ap.add_argument('--compact', default='0', help="FASTNERF_COMPACT policy of the steps: '0' plain backward (the headline protocol), 'auto' the product default")
     ap.add_argument('--cutoff', type=float, default=1.5, help='scene: density exactly zero beyond this many sigma of a blob (solid bodies in EMPTY space, '
                     'like the Lego bulldozer on its white background: 27 %% of the pixels covered); 0 = Gaussian tails that never vanish')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'r06_quadtree_adaptive.json'))
@@ -51,7 +56,11 @@ def main():
     H = W = a.res
     N_RAND, INIT_LEVEL, EVERY = 4096, 2, 3
     ops.set_math('bf16x6')
-    fn.render.set_compact('0')
+    fn.render.set_compact(a.compact)
+    if a.full:
+        a.steps_subdivide = a.steps_other = 10 ** 9
+    if a.always_split:
+        a.thres = -1.0
     fn.synthetic.CUTOFF = a.cutoff
     imgs, poses, focal = fn.synthetic.make_dataset(n_images=a.views, H=H, W=W, device='cuda')
     covered = float((imgs < 1.0).any(-1).float().mean())      # pixels that see a body (the others are EXACTLY white)
@@ -59,7 +68,8 @@ def main():
     args = fn.run_nerf.make_args(N_importance=128, N_samples=64, perturb=1.0, white_bkgd=True, no_reload=True, N_rand=N_RAND, n_epoch=a.n_epoch,
                                  init_level=INIT_LEVEL, subdivide_every=EVERY, subdivide_thres=1e-3, lrate=5e-4, lrate_decay=500)
     K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
-    kw_train = fn.run_nerf.create_nerf(args, device=dev)[0]
+    kw_train, kw_test = fn.run_nerf.create_nerf(args, device=dev)[:2]
+    kw_test.update(near=2.0, far=6.0)
     kw_train.update(near=2.0, far=6.0)
     trainer = fn.run_nerf.Trainer(kw_train, H, W, K, 2.0, 6.0, lrate=args.lrate, lrate_decay=args.lrate_decay)
     mgr = fn.tree.QuadTreeManager(H, W, K, imgs, poses[:, :3, :4], mseThres=0.0, max_depth=INIT_LEVEL, device=dev)
@@ -68,21 +78,24 @@ def main():
 
     def run(ro, rd, tgt, tags, table, ml, n_steps, decay=True):
         n_total, it, loss2 = ro.shape[0], 0, None
+        acc.zero_()
         for b0 in range(0, n_total, N_RAND):
             sl = slice(b0, min(b0 + N_RAND, n_total))
             loss2, _ = trainer.step(ro[sl], rd[sl], tgt[sl], leaf_tag=None if tags is None else tags[sl], table=table, max_leaves=ml, decay=decay)
+            acc.add_(loss2[:2].detach().to(acc.dtype))
             it += 1
             if it >= n_steps:
                 break
         return loss2, it
 
+    acc = torch.zeros(2, device=dev, dtype=torch.float64)      # the epoch's summed [fine, coarse] batch MSEs (one tiny launch per step, no host sync)
     g = torch.Generator().manual_seed(1)
     pix = torch.stack([torch.randint(0, a.views, (a.warmup_steps * N_RAND,), generator=g), torch.randint(H // 4, 3 * H // 4, (a.warmup_steps * N_RAND,), generator=g),
                        torch.randint(W // 4, 3 * W // 4, (a.warmup_steps * N_RAND,), generator=g)], 1)
     ro, rd, tgt = mgr.gather(pix)
     run(ro, rd, tgt, None, None, 0, a.warmup_steps, decay=False)
     torch.cuda.synchronize()
-    thres, epochs, adjust_checks = (a.thres if a.thres > 0 else None), [], []
+    thres, epochs, adjust_checks = (a.thres if a.thres != 0 else None), [], []
     for ep in range(1, a.n_epoch + 1):
         last = ep == a.n_epoch
         subdiv = ep % EVERY == 0 and ep < a.n_epoch - 1
@@ -100,9 +113,10 @@ def main():
         loss2, it = run(ro, rd, tgt, tags, table, ml, n_steps)
         torch.cuda.synchronize(); t_steps = time.perf_counter() - t0
         rec = {'epoch': ep, 'last_epoch_full_images': bool(last), 'rays_generated': int(ro.shape[0]), 'fraction_of_all_pixels': ro.shape[0] / float(a.views * H * W),
+               'backward': 'compacted' if trainer.last_step_live else 'plain', 'live_fraction': trainer.live.frac,
                'gen_seconds': t_gen, 'steps': it, 'steps_seconds': t_steps, 'rays_per_s_steps': it * N_RAND / t_steps,
                'leaves_per_image': {'min': int(nl.min()), 'median': float(np.median(nl)), 'max': int(nl.max())}, 'leaves_total': int(nl.sum()),
-               'psnr_db': float(-10 * np.log10(float(loss2[0]))), 'sampled_fraction_of_epoch': min(1.0, it * N_RAND / float(ro.shape[0]))}
+               'psnr_db': float(-10 * np.log10(float(loss2[0]))), 'psnr_db_epoch_mean_mse': float(-10 * np.log10(float(acc[0]) / it)), 'sampled_fraction_of_epoch': min(1.0, it * N_RAND / float(ro.shape[0]))}
         if subdiv:
             tab = table.view(mgr.n_images, ml).view(torch.float32)
             finest = torch.zeros(mgr.n_images, ml, dtype=torch.bool)
@@ -130,6 +144,23 @@ def main():
         epochs.append(rec)
         print(json.dumps(rec), flush=True)
         del ro, rd, tgt, tags, table
+    # ---- held-out views (never trained on): cameras half-way between training views at another elevation ----------------------------
+    held = None
+    if a.eval_views > 0:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        vals = []
+        for k in range(a.eval_views):
+            c2w = fn.synthetic.pose_spherical(-180.0 + 360.0 * (k + 0.5) / a.eval_views, -20.0, 4.0)[:3, :4].to(dev)
+            rgb = fn.render.render(H, W, K, chunk=1 << 16, c2w=c2w, **kw_test)[0]
+            ro_e, rd_e = ops.gen_rays(H, W, K, c2w)
+            fo, fd = ro_e.reshape(-1, 3), rd_e.reshape(-1, 3)
+            gt = torch.cat([fn.synthetic.render_rays(fo[s:s + 65536], fd[s:s + 65536], n_quad=256) for s in range(0, H * W, 65536)], 0).reshape(H, W, 3)
+            vals.append(float(-10 * torch.log10(((rgb - gt) ** 2).mean())))
+        torch.cuda.synchronize()
+        held = {'views': a.eval_views, 'psnr_db_mean': float(np.mean(vals)), 'psnr_db_min': float(np.min(vals)), 'psnr_db_max': float(np.max(vals)), 'psnr_db': vals,
+                'seconds': time.perf_counter() - t0, 'what': 'full %dx%d views at elevation -20 deg (training: -30), azimuths between the training cameras; '
+                                                               'render() with the test kwargs (perturb 0), targets by the 256-step quadrature of the scene' % (H, W)}
+        print(json.dumps({'held_out': held}), flush=True)
     # ---- final state: leaf-area histogram and the per-leaf plan against the oracle ------------------------------------------------
     plan, n_rays = mgr.epoch_plan(1, False)
     hist = {}
@@ -153,9 +184,12 @@ def main():
         'workload': 'BASELINE configs[2] at the reference\'s scale, ADAPTIVE regime: %d analytic views of %dx%d, init_level 2, subdivide_every 3, n_epoch %d, 4096 rays x '
                     '(64+128) samples per step, bf16x6, plain backward, device ray generation; scene cutoff %.1f sigma (%.1f %% of the pixels see a body, the rest are '
                     'exactly white); subdivide_thres %s' % (a.views, H, W, a.n_epoch, a.cutoff, 100 * covered,
-                                                            '%g (fixed)' % a.thres if a.thres > 0 else 'calibrated once at the first adjust (quantile %.2f)' % a.quantile),
+                                                            '%g (fixed)' % a.thres if a.thres != 0 else 'calibrated once at the first adjust (quantile %.2f)' % a.quantile),
         'pixels_covered_by_a_body': covered,
-        'threshold': thres, 'epochs': epochs,
+        'threshold': thres, 'epochs': epochs, 'sub_sampling': 'NONE: every batch of every epoch trained' if a.full else 'training sub-sampled as in bench_quadtree_full.py',
+        'member': 'NON-adaptive (thres -1: every finest leaf splits, every epoch is every pixel)' if a.always_split else 'adaptive', 'held_out': held,
+        'total_gen_seconds': float(sum(e['gen_seconds'] for e in epochs)), 'total_adjust_seconds': float(sum(e.get('adjust_seconds', 0.0) for e in epochs)),
+        'compact_policy': a.compact, 'total_training_seconds': float(sum(e['steps_seconds'] for e in epochs)), 'total_rays_trained': int(sum(e['steps'] for e in epochs)) * N_RAND,
         'final': {'depth_reached': max(depth_of.values()), 'leaves_per_image': epochs[-2]['leaves_per_image'], 'leaves_total': int(sum(hist.values())),
                   'leaves_by_depth': {str(depth_of[ar]): n for ar, n in sorted(hist.items(), reverse=True)},
                   'rays_per_epoch': int(n_rays), 'fraction_of_all_pixels': n_rays / float(a.views * H * W),
