@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--always-split', action='store_true', help='the NON-adaptive member of the pair: thres -1, every finest leaf splits at every adjust, every epoch is every pixel')
     ap.add_argument('--eval-views', type=int, default=0, help='after training: PSNR of this many HELD-OUT full-resolution views (cameras half-way between training views, '
                     'another elevation) through render() with the test kwargs')
+    ap.add_argument('--save', default='', help='write the final parameters (both nets, flat fp32) here (.pt)')
     ap.add_argument('--compact', default='0', help="FASTNERF_COMPACT policy of the steps: '0' plain backward (the headline protocol), 'auto' the product default")
     ap.add_argument('--cutoff', type=float, default=1.5, help='scene: density exactly zero beyond this many sigma of a blob (solid bodies in EMPTY space, '
                     'like the Lego bulldozer on its white background: 27 %% of the pixels covered); 0 = Gaussian tails that never vanish')
@@ -148,19 +149,26 @@ def main():
     held = None
     if a.eval_views > 0:
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        vals = []
-        for k in range(a.eval_views):
-            c2w = fn.synthetic.pose_spherical(-180.0 + 360.0 * (k + 0.5) / a.eval_views, -20.0, 4.0)[:3, :4].to(dev)
+        def eval_view(theta, phi):
+            c2w = fn.synthetic.pose_spherical(theta, phi, 4.0)[:3, :4].to(dev)
             rgb = fn.render.render(H, W, K, chunk=1 << 16, c2w=c2w, **kw_test)[0]
             ro_e, rd_e = ops.gen_rays(H, W, K, c2w)
             fo, fd = ro_e.reshape(-1, 3), rd_e.reshape(-1, 3)
             gt = torch.cat([fn.synthetic.render_rays(fo[s:s + 65536], fd[s:s + 65536], n_quad=256) for s in range(0, H * W, 65536)], 0).reshape(H, W, 3)
-            vals.append(float(-10 * torch.log10(((rgb - gt) ** 2).mean())))
+            return float(-10 * torch.log10(((rgb - gt) ** 2).mean()))
+        # off the ring: another elevation (the training cameras all sit at -30 deg: view directions the nets never saw); on the ring: the
+        # training elevation, azimuths half-way between two training cameras (interpolation)
+        vals = [eval_view(-180.0 + 360.0 * (k + 0.5) / a.eval_views, -20.0) for k in range(a.eval_views)]
+        ring = [eval_view(-180.0 + 360.0 * (k * (a.views // a.eval_views) + 0.5) / a.views, -30.0) for k in range(a.eval_views)]
         torch.cuda.synchronize()
         held = {'views': a.eval_views, 'psnr_db_mean': float(np.mean(vals)), 'psnr_db_min': float(np.min(vals)), 'psnr_db_max': float(np.max(vals)), 'psnr_db': vals,
-                'seconds': time.perf_counter() - t0, 'what': 'full %dx%d views at elevation -20 deg (training: -30), azimuths between the training cameras; '
-                                                               'render() with the test kwargs (perturb 0), targets by the 256-step quadrature of the scene' % (H, W)}
+                'on_ring_psnr_db_mean': float(np.mean(ring)), 'on_ring_psnr_db': ring,
+                'seconds': time.perf_counter() - t0, 'what': 'full %dx%d views; psnr_db*: elevation -20 deg (training: -30), azimuths between the training cameras; on_ring_*: the training '
+                                                               'elevation, azimuths half-way between two neighbouring training cameras; render() with the test kwargs (perturb 0), '
+                                                               'targets by the 256-step quadrature of the scene' % (H, W)}
         print(json.dumps({'held_out': held}), flush=True)
+    if a.save:
+        torch.save({'flat': trainer.flat.detach().cpu(), 'what': 'coarse | fine parameters, flat fp32 in model.parameters() order (run_nerf.create_nerf)'}, a.save)
     # ---- final state: leaf-area histogram and the per-leaf plan against the oracle ------------------------------------------------
     plan, n_rays = mgr.epoch_plan(1, False)
     hist = {}
@@ -182,9 +190,10 @@ def main():
     sub = [e for e in epochs if 'adjust_seconds' in e]
     out = {
         'workload': 'BASELINE configs[2] at the reference\'s scale, ADAPTIVE regime: %d analytic views of %dx%d, init_level 2, subdivide_every 3, n_epoch %d, 4096 rays x '
-                    '(64+128) samples per step, bf16x6, plain backward, device ray generation; scene cutoff %.1f sigma (%.1f %% of the pixels see a body, the rest are '
-                    'exactly white); subdivide_thres %s' % (a.views, H, W, a.n_epoch, a.cutoff, 100 * covered,
-                                                            '%g (fixed)' % a.thres if a.thres != 0 else 'calibrated once at the first adjust (quantile %.2f)' % a.quantile),
+                    '(64+128) samples per step, bf16x6, %s, device ray generation; scene cutoff %.1f sigma (%.1f %% of the pixels see a body, the rest are '
+                    'exactly white); subdivide_thres %s' % (a.views, H, W, a.n_epoch, 'plain backward' if a.compact == '0' else 'backward policy %r (exact zero-gradient compaction when it pays)' % a.compact,
+                                                            a.cutoff, 100 * covered,
+                                                            ('-1: EVERY finest leaf splits' if a.thres < 0 else '%g (fixed)' % a.thres) if a.thres != 0 else 'calibrated once at the first adjust (quantile %.2f)' % a.quantile),
         'pixels_covered_by_a_body': covered,
         'threshold': thres, 'epochs': epochs, 'sub_sampling': 'NONE: every batch of every epoch trained' if a.full else 'training sub-sampled as in bench_quadtree_full.py',
         'member': 'NON-adaptive (thres -1: every finest leaf splits, every epoch is every pixel)' if a.always_split else 'adaptive', 'held_out': held,
