@@ -100,7 +100,7 @@ def main():
         bad = 0
         for s in pick:
             t0 = time.time()
-            r = P.cpu_run(s, data)
+            r = P.cpu_run(s, data, member=a.member)
             same = abs(r[0] - done[s][0]) < 1e-3 and abs(r[1] - done[s][1]) < 1e-3
             print('seed %d (%d threads): train %.4f vs %.4f, held-out %.4f vs %.4f  %s  (%.0f s)' % (
                 s, threads, r[0], done[s][0], r[1], done[s][1], 'ok' if same else 'DIFFERS', time.time() - t0), flush=True)
